@@ -1,0 +1,61 @@
+"""ctypes binding of libea_mi355x.so (C ABI declared in include/ea_mi355x.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libea_mi355x.so")
+
+_P = c_void_p
+_I = c_int
+_L = c_int64
+_F = c_float
+
+# name -> argtypes, exactly as include/ea_mi355x.h
+PROTOTYPES = {
+    "ea_layernorm_modulate_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _L, _F, _P],
+    "ea_rmsnorm_bf16": [_P, _P, _P, _I, _I, _F, _P],
+    "ea_linear_small_m": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ea_timestep_sinusoid": [_P, _P, _I, _I, _I, _P],
+    "ea_gemm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _I, _P],
+    "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "ea_attention_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P],
+    "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ea_unpatchify": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ea_cfg_euler_step": [_P, _P, _L, _F, _F, _I, _I, _P],
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m easyanimate_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.ea_last_error_string.restype = ctypes.c_char_p
+    lib.ea_last_error_string.argtypes = []
+    lib.ea_version.restype = c_int
+    lib.ea_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.ea_last_error_string().decode()}")

@@ -1,0 +1,67 @@
+"""Builds libea_mi355x.so (HIP kernels + C ABI) for gfx950 with hipcc.  No GPU is needed to build.
+
+    python -m easyanimate_amd.build [--force]
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libea_mi355x.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/ea_mi355x.h"]:
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p):
+            h.update(f.encode())
+            h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str, objdir: str) -> str:
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+    cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.sha256")
+    dg = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dg:
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = _sources()
+    if verbose:
+        print(f"[easyanimate_amd.build] hipcc {' '.join(FLAGS)}: {', '.join(srcs)}", file=sys.stderr)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, objdir), srcs))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    open(stamp, "w").write(dg + "\n")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

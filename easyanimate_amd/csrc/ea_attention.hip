@@ -1,0 +1,374 @@
+// Joint text/video attention for the MMDiT block: qk-LayerNorm + RoPE + head-major scatter, and the
+// flash-style forward  O = softmax(Q K^T * scale) V  for head_dim 64 (MFMA 32x32x16 bf16).
+//
+// ea_attention_fwd_bf16, mapping to CDNA4 (details + roofline in DESIGN.md):
+//   * everything is computed TRANSPOSED: S^T = K.Q^T and O^T = V^T.P^T.  In the MFMA C layout a lane then
+//     owns ONE query column, so the softmax running max / sum / rescale are lane-local (one cross-half
+//     exchange per tile for the max), and the exponentiated S^T accumulator registers ARE the B operand of
+//     the PV MFMA -- no LDS round trip, no permutes.  K rows (and V^T rows) are fed to the MFMA in
+//     bit-2/bit-3-swapped order so that each lane's 8 consecutive accumulator registers are 8 consecutive
+//     keys (resp. 8 consecutive output channels: 16-byte output stores).
+//   * V is stored transposed in HBM ([B,H,64,S], written by ea_qknorm_rope_bf16), so both the K tile
+//     ([64 keys][64 d]) and the V^T tile ([64 d][64 keys]) are plain 128-byte-row tiles, staged by LDS-DMA
+//     (global_load_lds_dwordx4) with the 16-byte-chunk XOR swizzle ((row>>1)&7) on the source address:
+//     every fragment is one conflict-free ds_read_b128.
+//   * workgroup = 4 waves x 64 queries = 256 queries; KV tile = 64 keys, double-buffered (32 KiB LDS),
+//     one s_barrier per tile, next tile's DMA in flight under the MFMAs; 2 workgroups per CU.
+//   * blockIdx -> (XCD, head, q-block): all workgroups resident on one XCD work on the same (batch, head),
+//     so its K / V^T stream (S*256 B) is served from that XCD's L2.
+#include "ea_common.h"
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+
+// ------------------------------------------------------------------------------------------------
+// qk-LayerNorm + RoPE + scatter.  reference: easyanimate/models/processor.py:251-285
+// block = 256 threads handles 64 tokens of one (batch, head): thread -> (token = t/8 (+32), 8 channels).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(
+    const unsigned short* __restrict__ qkv, int64_t qkv_bs, unsigned short* __restrict__ q_out,
+    unsigned short* __restrict__ k_out, unsigned short* __restrict__ vt_out, const float* __restrict__ nq_w,
+    const float* __restrict__ nq_b, const float* __restrict__ nk_w, const float* __restrict__ nk_b,
+    const float* __restrict__ cosT, const float* __restrict__ sinT, int heads, int n_tok, int seq_off, int s_pad,
+    float eps) {
+    __shared__ unsigned short vtile[64][72];  // [token][channel], padded
+    const int tid = threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int tok0 = blockIdx.x * 64;
+    const int inner = heads * 64;
+    const int sub = tid & 7;  // channels sub*8 .. sub*8+7
+    const int64_t bh = (int64_t)b * heads + h;
+
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int tl = it * 32 + (tid >> 3);
+        const int tok = tok0 + tl;
+        const bool valid = tok < n_tok;
+        const int tokc = valid ? tok : n_tok - 1;
+        const unsigned short* src = qkv + b * qkv_bs + (int64_t)tokc * 3 * inner + h * 64 + sub * 8;
+        float cs[8], sn[8];
+        if (cosT) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosT + (int64_t)tokc * 64 + sub * 8 + e);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinT + (int64_t)tokc * 64 + sub * 8 + e);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cs[e + u] = c4[u];
+                    sn[e + u] = s4[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {  // 0 = q, 1 = k
+            const u16x8 raw = *reinterpret_cast<const u16x8*>(src + which * inner);
+            float v[8];
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = bf16_bits_to_f32(raw[e]);
+                s += v[e];
+            }
+            // reduce over the 8 lanes that share a (token, head) row
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            const float mean = s * (1.0f / 64.0f);
+            float qd = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[e] - mean;
+                qd += d * d;
+            }
+            qd += __shfl_xor(qd, 1, 64);
+            qd += __shfl_xor(qd, 2, 64);
+            qd += __shfl_xor(qd, 4, 64);
+            const float rstd = rsqrtf(qd * (1.0f / 64.0f) + eps);
+            const float* gw = which ? nk_w : nq_w;
+            const float* gb = which ? nk_b : nq_b;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[e] - mean) * rstd * gw[sub * 8 + e] + gb[sub * 8 + e];
+                // nn.LayerNorm output is rounded to the model dtype before RoPE (processor.py:255-258)
+                v[e] = bf16_bits_to_f32(f32_to_bf16_bits(t));
+            }
+            u16x8 o;
+            if (cosT) {
+                // diffusers apply_rotary_emb, interleaved pairs: out[2i] = x[2i]c - x[2i+1]s ; out[2i+1] = x[2i+1]c + x[2i]s
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float x0 = v[e], x1 = v[e + 1];
+                    o[e] = f32_to_bf16_bits(x0 * cs[e] - x1 * sn[e]);
+                    o[e + 1] = f32_to_bf16_bits(x1 * cs[e + 1] + x0 * sn[e + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+            }
+            if (valid) {
+                unsigned short* dst = (which ? k_out : q_out) + (bh * s_pad + seq_off + tok) * 64 + sub * 8;
+                *reinterpret_cast<u16x8*>(dst) = o;
+            }
+        }
+        {
+            u16x8 raw = *reinterpret_cast<const u16x8*>(src + 2 * inner);
+            if (!valid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[e] = 0;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vtile[tl][sub * 8 + e] = raw[e];
+        }
+    }
+    __syncthreads();
+    // transposed write: thread -> channel d = tid/4, 16 tokens (tid%4)*16.. ; destination columns seq_off+tok
+    {
+        const int d = tid >> 2;
+        const int t0 = (tid & 3) * 16;
+        unsigned short* dst = vt_out + (bh * 64 + d) * (int64_t)s_pad + seq_off + tok0 + t0;
+        const bool aligned = (((seq_off + tok0) & 7) == 0);
+        if (aligned && tok0 + t0 + 16 <= n_tok) {
+            u16x8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o0[e] = vtile[t0 + e][d];
+                o1[e] = vtile[t0 + 8 + e][d];
+            }
+            *reinterpret_cast<u16x8*>(dst) = o0;
+            *reinterpret_cast<u16x8*>(dst + 8) = o1;
+        } else {
+            for (int e = 0; e < 16; ++e)
+                if (tok0 + t0 + e < n_tok) dst[e] = vtile[t0 + e][d];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flash attention forward, head_dim 64.  reference: easyanimate/models/processor.py:287-291
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_QB = 256;                 // queries per workgroup
+constexpr int ATT_KV = 64;                  // keys per tile
+constexpr int ATT_TILE = ATT_KV * 64 * 2;   // 8 KiB (K tile; V^T tile has the same size)
+constexpr int ATT_STAGE = 2 * ATT_TILE;     // 16 KiB
+constexpr int ATT_LDS = 2 * ATT_STAGE;      // 32 KiB
+
+__global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
+    const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K, const unsigned short* __restrict__ Vt,
+    unsigned short* __restrict__ O, int64_t o_bs, int heads, int bh_total, int seq, int s_pad, int q_begin,
+    int nqb, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // block -> (xcd, slot) -> (bh, q-block): all blocks of an XCD walk the same head together
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = (slot / nqb) * 8 + xcd;
+    const int qb = slot % nqb;
+    if (bh >= bh_total) return;
+    const int b = bh / heads, h = bh % heads;
+    const int q0 = q_begin + qb * ATT_QB + wave * 64;  // first query row of this wave
+
+    const unsigned short* Qh = Q + (int64_t)bh * s_pad * 64;
+    const unsigned short* Kh = K + (int64_t)bh * s_pad * 64;
+    const unsigned short* Vh = Vt + (int64_t)bh * 64 * s_pad;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane (n = query l31, k-half hi)
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        int qr = q0 + qi * 32 + l31;
+        qr = qr < s_pad ? qr : s_pad - 1;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+            qf[qi][ds] = *reinterpret_cast<const bf16x8*>(Qh + (int64_t)qr * 64 + ds * 16 + hi * 8);
+    }
+
+    // ---- DMA source pointers: per wave 2 pieces of K tile + 2 pieces of V^T tile (1 KiB each)
+    const unsigned short* ksrc[2];
+    const unsigned short* vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wave * 2 + i) * 64 + lane;
+        const int r = L >> 3, c = L & 7;
+        const int cs = c ^ ((r >> 1) & 7);
+        ksrc[i] = Kh + (int64_t)r * 64 + cs * 8;       // + kv0*64 per tile
+        vsrc[i] = Vh + (int64_t)r * s_pad + cs * 8;    // + kv0 per tile
+    }
+    auto issue = [&](int t, int stage) {
+        char* sk = smem + stage * ATT_STAGE + wave * 2048;
+        char* sv = sk + ATT_TILE;
+        const int kv0 = t * ATT_KV;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(ksrc[i] + (int64_t)kv0 * 64, sk + i * 1024);
+            glds16(vsrc[i] + kv0, sv + i * 1024);
+        }
+    };
+
+    // fragment read offsets: K row for MFMA row index l31 is swap23(l31) (+32 per key block);
+    // V^T row likewise (+32 per output-channel tile).
+    const int frow = swap23(l31);
+    int f_off[2], f_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = i * 32 + frow;
+        f_off[i] = r * 128;
+        f_sw[i] = (r >> 1) & 7;
+    }
+
+    f32x16 o[2][2];  // [d tile][q tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][j][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+
+    const int nt = (seq + ATT_KV - 1) / ATT_KV;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const char* sk = smem + (t & 1) * ATT_STAGE;
+        const char* sv = sk + ATT_TILE;
+        const int kv0 = t * ATT_KV;
+        const bool tail = kv0 + ATT_KV > seq;
+
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            // ---- S^T[kb] = K[kb] . Q^T : 32 keys x (2 x 32 queries)
+            f32x16 s[2];
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qi][r] = 0.f;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const int ch = ds * 2 + hi;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + f_off[kb] + ((ch ^ f_sw[kb]) << 4));
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+                    s[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ds], s[qi], 0, 0, 0);
+            }
+            // lane (query l31 of tile qi, half hi): s[qi][r] is key  kv0 + kb*32 + 16*(r>>3) + 8*hi + (r&7)
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (key >= seq) {
+                        s[0][r] = -INFINITY;
+                        s[1][r] = -INFINITY;
+                    }
+                }
+            }
+            // ---- online softmax (exp2 domain), per query = per lane
+            bf16x8 pf[2][2];  // [q tile][key slab of 16]
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                float mx = s[qi][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qi][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[qi], mx * scale_log2e);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+                m_run[qi] = m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][r], scale_log2e, -m_new));
+                    psum += p;
+                    pf[qi][r >> 3][r & 7] = (bf16_t)p;
+                }
+                l_run[qi] = l_run[qi] * alpha + psum;
+                if (__any(alpha != 1.0f)) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][qi][r] *= alpha;
+                }
+            }
+            // ---- O^T += V^T[:, keys of kb] . P^T
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = kb * 4 + ks * 2 + hi;  // 16-byte chunk = 8 keys
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + f_off[dt] + ((ch ^ f_sw[dt]) << 4));
+#pragma unroll
+                    for (int qi = 0; qi < 2; ++qi)
+                        o[dt][qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][ks], o[dt][qi], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- normalise and store: lane (query, hi) holds channels dt*32 + 16*g + 8*hi + 0..7
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const float l = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+        const float inv = 1.0f / l;
+        const int qr = q0 + qi * 32 + l31;
+        if (qr < seq) {
+            unsigned short* dst = O + b * o_bs + (int64_t)qr * heads * 64 + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    u16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16_bits(o[dt][qi][g * 8 + e] * inv);
+                    *reinterpret_cast<u16x8*>(dst + dt * 32 + g * 16 + hi * 8) = ov;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q_out, ea_bf16* k_out,
+                                   ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
+                                   const float* nk_b, const float* cos, const float* sin, int batch, int heads,
+                                   int n_tok, int seq_off, int s_pad, float ln_eps, void* stream) {
+    EA_REQUIRE(qkv && q_out && k_out && vt_out && nq_w && nq_b && nk_w && nk_b, "ea_qknorm_rope_bf16: null tensor");
+    EA_REQUIRE((cos == nullptr) == (sin == nullptr), "ea_qknorm_rope_bf16: cos/sin must come together");
+    EA_REQUIRE(batch > 0 && heads > 0 && n_tok >= 0 && seq_off >= 0, "ea_qknorm_rope_bf16: bad sizes");
+    EA_REQUIRE(s_pad % 64 == 0 && seq_off + n_tok <= s_pad, "ea_qknorm_rope_bf16: s_pad must be a multiple of 64 and cover the rows");
+    EA_REQUIRE(heads <= 65535 && batch <= 65535, "ea_qknorm_rope_bf16: grid too large");
+    if (n_tok == 0) return EA_OK;
+    dim3 grid((n_tok + 63) / 64, heads, batch);
+    hipLaunchKernelGGL(qknorm_rope_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_batch_stride, q_out,
+                       k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, heads, n_tok, seq_off, s_pad, ln_eps);
+    return ea_check_launch("ea_qknorm_rope_bf16");
+}
+
+extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                     int64_t out_batch_stride, int batch, int heads, int seq, int s_pad, int q_begin,
+                                     int q_end, float scale, void* stream) {
+    EA_REQUIRE(q && k && vt && out, "ea_attention_fwd_bf16: null tensor");
+    EA_REQUIRE(batch > 0 && heads > 0 && seq > 0, "ea_attention_fwd_bf16: bad sizes");
+    EA_REQUIRE(s_pad % ATT_QB == 0 && s_pad >= seq, "ea_attention_fwd_bf16: s_pad must be a multiple of 256 and >= seq");
+    EA_REQUIRE(q_begin >= 0 && q_begin <= q_end && q_end <= seq, "ea_attention_fwd_bf16: bad query range");
+    EA_REQUIRE(q_begin % 64 == 0, "ea_attention_fwd_bf16: q_begin must be a multiple of 64");
+    if (q_end == q_begin) return EA_OK;
+    const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
+    const int bh = batch * heads;
+    const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
+    EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd_bf16: grid too large");
+    // NOTE: rows in [q_end, ...) of the last q-block are computed and stored if < seq; callers that shard
+    // queries (sequence parallel) pass q_end on a 256 boundary or own the trailing rows too.
+    const float scale_log2e = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt,
+                       out, out_batch_stride, heads, bh, seq, s_pad, q_begin, nqb, scale_log2e);
+    return ea_check_launch("ea_attention_fwd_bf16");
+}

@@ -1,0 +1,54 @@
+// Shared device/host helpers for libea_mi355x (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ea_mi355x.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+#define EA_WAVE 64
+
+// ---- error plumbing (host) --------------------------------------------------------------------
+void ea_set_error(const char* fmt, ...);
+int ea_check_launch(const char* what);
+
+#define EA_REQUIRE(cond, ...)        \
+    do {                             \
+        if (!(cond)) {               \
+            ea_set_error(__VA_ARGS__); \
+            return EA_ERR_ARG;       \
+        }                            \
+    } while (0)
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __builtin_bit_cast(float, ((unsigned int)b) << 16);
+}
+// round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    return __builtin_bit_cast(unsigned short, (bf16_t)f);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// tanh-approximate GELU exactly as torch: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1)
+    float e = __expf(2.0f * u);
+    float t = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}

@@ -1,0 +1,143 @@
+// Latent-space elementwise kernels: patchify gather, un-patchify scatter, CFG + Euler update.
+#include "ea_common.h"
+
+namespace {
+
+template <bool BF16>
+__device__ __forceinline__ float load_lat(const void* p, int64_t i) {
+    if (BF16) return bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p)[i]);
+    return reinterpret_cast<const float*>(p)[i];
+}
+
+// reference: easyanimate/models/transformer3d.py:1523-1531 (channel concat + Conv2d k=s=2 as im2col row)
+// cols[b, (f,i,j), c*4 + di*2 + dj] ; one thread per (token, channel): reads 2 x 8-byte-ish pairs.
+template <bool BF16>
+__global__ void patchify_kernel(const void* __restrict__ lat, const void* __restrict__ extra,
+                                unsigned short* __restrict__ cols, int c_lat, int c_extra, int F, int H, int W,
+                                int k_pad) {
+    const int h = H >> 1, w = W >> 1;
+    const int64_t ntok = (int64_t)F * h * w;
+    const int ctot = c_lat + c_extra;
+    const int kq = k_pad >> 2;  // channel slots incl. zero padding
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (idx >= ntok * kq) return;
+    const int c = (int)(idx % kq);
+    const int64_t tok = idx / kq;
+    const int j = (int)(tok % w);
+    const int i = (int)((tok / w) % h);
+    const int f = (int)(tok / ((int64_t)w * h));
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < ctot) {
+        const void* src = c < c_lat ? lat : extra;
+        const int cc = c < c_lat ? c : c - c_lat;
+        const int cn = c < c_lat ? c_lat : c_extra;
+        const int64_t base = ((((int64_t)b * cn + cc) * F + f) * H + 2 * i) * W + 2 * j;
+        v[0] = load_lat<BF16>(src, base);
+        v[1] = load_lat<BF16>(src, base + 1);
+        v[2] = load_lat<BF16>(src, base + W);
+        v[3] = load_lat<BF16>(src, base + W + 1);
+    }
+    unsigned short* dst = cols + ((int64_t)b * ntok + tok) * k_pad + c * 4;
+    ushort4 o;
+    o.x = f32_to_bf16_bits(v[0]);
+    o.y = f32_to_bf16_bits(v[1]);
+    o.z = f32_to_bf16_bits(v[2]);
+    o.w = f32_to_bf16_bits(v[3]);
+    *reinterpret_cast<ushort4*>(dst) = o;
+}
+
+// reference: easyanimate/models/transformer3d.py:1683-1685
+// tokens [b, (f,i,j), (c,di,dj)] -> out [b, c, f, 2i+di, 2j+dj]; one thread per output pixel pair (dj=0,1)
+template <bool BF16>
+__global__ void unpatchify_kernel(const unsigned short* __restrict__ tok, void* __restrict__ out, int C, int F,
+                                  int h, int w) {
+    const int H = 2 * h, W = 2 * w;
+    const int64_t n = (int64_t)C * F * H * w;  // pairs
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (idx >= n) return;
+    const int j = (int)(idx % w);
+    const int y = (int)((idx / w) % H);
+    const int f = (int)((idx / ((int64_t)w * H)) % F);
+    const int c = (int)(idx / ((int64_t)w * H * F));
+    const int i = y >> 1, di = y & 1;
+    const int64_t t = ((int64_t)f * h + i) * w + j;
+    const unsigned short* src = tok + (((int64_t)b * F * h * w + t) * (C * 4)) + c * 4 + di * 2;
+    const int64_t o = ((((int64_t)b * C + c) * F + f) * H + y) * W + 2 * j;
+    if (BF16) {
+        unsigned short* d = reinterpret_cast<unsigned short*>(out);
+        d[o] = src[0];
+        d[o + 1] = src[1];
+    } else {
+        float* d = reinterpret_cast<float*>(out);
+        d[o] = bf16_bits_to_f32(src[0]);
+        d[o + 1] = bf16_bits_to_f32(src[1]);
+    }
+}
+
+// reference: easyanimate/pipeline/pipeline_easyanimate.py:1102-1104 (CFG) and :1111 (scheduler.step)
+template <bool BF16>
+__global__ void cfg_euler_kernel(const void* __restrict__ v, void* __restrict__ x, int64_t n, float g, float dsigma,
+                                 int do_cfg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float vu = load_lat<BF16>(v, i);
+    float vv = vu;
+    if (do_cfg) {
+        const float vt = load_lat<BF16>(v, n + i);
+        vv = vu + g * (vt - vu);
+        // the reference combines in the model dtype: round like it does
+        if (BF16) vv = bf16_bits_to_f32(f32_to_bf16_bits(vv));
+    }
+    const float xn = load_lat<BF16>(x, i) + dsigma * vv;
+    if (BF16)
+        reinterpret_cast<unsigned short*>(x)[i] = f32_to_bf16_bits(xn);
+    else
+        reinterpret_cast<float*>(x)[i] = xn;
+}
+
+}  // namespace
+
+extern "C" int ea_patchify(const void* latents, const void* extra, ea_bf16* cols, int batch, int c_lat, int c_extra,
+                           int frames, int height, int width, int k_pad, int lat_is_bf16, void* stream) {
+    EA_REQUIRE(latents && cols, "ea_patchify: null tensor");
+    EA_REQUIRE((extra != nullptr) == (c_extra > 0), "ea_patchify: extra and c_extra disagree");
+    EA_REQUIRE(height % 2 == 0 && width % 2 == 0, "ea_patchify: height/width must be even");
+    EA_REQUIRE(k_pad % 4 == 0 && k_pad >= 4 * (c_lat + c_extra), "ea_patchify: k_pad too small");
+    const int64_t n = (int64_t)frames * (height / 2) * (width / 2) * (k_pad / 4);
+    dim3 grid((unsigned)((n + 255) / 256), batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (lat_is_bf16)
+        hipLaunchKernelGGL(patchify_kernel<true>, grid, dim3(256), 0, st, latents, extra, cols, c_lat, c_extra, frames,
+                           height, width, k_pad);
+    else
+        hipLaunchKernelGGL(patchify_kernel<false>, grid, dim3(256), 0, st, latents, extra, cols, c_lat, c_extra, frames,
+                           height, width, k_pad);
+    return ea_check_launch("ea_patchify");
+}
+
+extern "C" int ea_unpatchify(const ea_bf16* tokens, void* out, int batch, int channels, int frames, int h, int w,
+                             int out_is_bf16, void* stream) {
+    EA_REQUIRE(tokens && out, "ea_unpatchify: null tensor");
+    const int64_t n = (int64_t)channels * frames * (2 * h) * w;
+    dim3 grid((unsigned)((n + 255) / 256), batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_is_bf16)
+        hipLaunchKernelGGL(unpatchify_kernel<true>, grid, dim3(256), 0, st, tokens, out, channels, frames, h, w);
+    else
+        hipLaunchKernelGGL(unpatchify_kernel<false>, grid, dim3(256), 0, st, tokens, out, channels, frames, h, w);
+    return ea_check_launch("ea_unpatchify");
+}
+
+extern "C" int ea_cfg_euler_step(const void* v, void* latents, int64_t n, float guidance, float dsigma, int do_cfg,
+                                 int is_bf16, void* stream) {
+    EA_REQUIRE(v && latents && n > 0, "ea_cfg_euler_step: bad arguments");
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16)
+        hipLaunchKernelGGL(cfg_euler_kernel<true>, grid, dim3(256), 0, st, v, latents, n, guidance, dsigma, do_cfg);
+    else
+        hipLaunchKernelGGL(cfg_euler_kernel<false>, grid, dim3(256), 0, st, v, latents, n, guidance, dsigma, do_cfg);
+    return ea_check_launch("ea_cfg_euler_step");
+}

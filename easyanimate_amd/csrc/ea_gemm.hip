@@ -1,0 +1,236 @@
+// bf16 GEMM with fused epilogues for the DiT linears:  C_b = epi(A_b . W^T + bias)   (MFMA 32x32x16).
+//
+// Mapping to CDNA4 (see DESIGN.md "ea_gemm_bf16"):
+//   * workgroup = 256 threads = 4 waves (2 x 2), block tile 128(M) x 128(N) x 64(K); wave tile 64 x 64
+//     = 2 x 2 MFMA tiles; 16 v_mfma_f32_32x32x16_bf16 per wave per K-tile.
+//   * both operands are K-contiguous ([M,K] activations, [N,K] nn.Linear weights), so both are staged
+//     with LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) into 128-byte rows; the 16-byte
+//     chunk index is XOR-swizzled with ((row>>1)&7) -- applied on the per-lane SOURCE address because the
+//     DMA destination is lane-linear -- which makes every ds_read_b128 fragment read conflict-free.
+//   * double-buffered LDS (2 x 32 KiB), one s_barrier per K-tile, next tile's DMA in flight during the
+//     MFMAs; 2 workgroups per CU hide each other's barrier.
+//   * the MFMA computes C^T tiles (A-operand = W rows, B-operand = activation rows) and the W rows are
+//     fed in bit-2/bit-3-swapped order, so each lane ends with 8 *contiguous* output columns per 8
+//     accumulator registers: 16-byte bf16 stores, 16-byte residual loads, vector bias/gate loads.
+//   * blockIdx is remapped so that the 8 XCDs (private L2s) each walk a contiguous band of M-tiles.
+#include "ea_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;       // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffer = 64 KiB
+
+struct GemmArgs {
+    const unsigned short* A;
+    const unsigned short* W;
+    const float* bias;
+    unsigned short* C;
+    const unsigned short* res;
+    const float* gate;
+    int M, N, K;
+    int64_t lda, abs_, ldc, cbs, ldres, rbs, gbs;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int swap23(int m) {  // swap bits 2 and 3
+    return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous range of tiles,
+    // ordered N-fastest so concurrently-running blocks of an XCD share A rows and the whole W panel set.
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    const int b = blockIdx.y;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    const unsigned short* Ab = p.A + b * p.abs_;
+
+    // ---- per-lane DMA source pointers (4 x 1 KiB pieces per wave per operand tile)
+    const unsigned short* asrc[4];
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = (wave * 4 + i) * 64 + lane;
+        const int r = L >> 3, c = L & 7;
+        const int cs = c ^ ((r >> 1) & 7);
+        int ra = row0 + r;
+        ra = ra < p.M ? ra : p.M - 1;
+        int rw = col0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
+        wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (bytes) inside a tile: row*128 + ((chunk ^ ((row>>1)&7)) * 16)
+    int a_off[2], w_off[2], a_sw[2], w_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + l31;            // activation row = MFMA column
+        const int rw = wn * 64 + i * 32 + swap23(l31);    // weight row, bit2/3 swapped (see header)
+        a_off[i] = ra * 128;
+        a_sw[i] = (ra >> 1) & 7;
+        w_off[i] = rw * 128;
+        w_sw[i] = (rw >> 1) & 7;
+    }
+
+    const int nk = p.K / BK;
+    auto issue = [&](int t, int stage) {
+        char* sa = smem + stage * STAGE_BYTES + wave * 4096;
+        char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(asrc[i] + t * BK, sa + i * 1024);
+            glds16(wsrc[i] + t * BK, sw + i * 1024);
+        }
+    };
+
+    issue(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+        const char* sa = smem + (t & 1) * STAGE_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ks * 2 + hi;
+            bf16x8 af[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + ((ch ^ a_sw[i]) << 4));
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + w_off[i] + ((ch ^ w_sw[i]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns row m, columns n0..n0+7 per (j, g)
+    unsigned short* Cb = p.C + b * p.cbs;
+    const unsigned short* Rb = EPI == EA_EPI_BIAS_GATE_RES ? p.res + b * p.rbs : nullptr;
+    const float* gb = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = row0 + wm * 64 + i * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int n0 = col0 + wn * 64 + j * 32 + g * 16 + hi * 8;
+                if (n0 >= p.N) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += b0[e];
+                        v[4 + e] += b1[e];
+                    }
+                }
+                if (EPI == EA_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                if (EPI == EA_EPI_BIAS_GATE_RES) {
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + n0);
+                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gb + n0 + 4);
+                    const u16x8 rr = *reinterpret_cast<const u16x8*>(Rb + (int64_t)m * p.ldres + n0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = bf16_bits_to_f32(rr[e]) + g0[e] * v[e];
+                        v[4 + e] = bf16_bits_to_f32(rr[4 + e]) + g1[e] * v[4 + e];
+                    }
+                }
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+                *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + n0) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16* C,
+                            const ea_bf16* res, const float* gate, int batch, int M, int N, int K, int64_t lda,
+                            int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
+                            int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream) {
+    EA_REQUIRE(A && W && C, "ea_gemm_bf16: null tensor");
+    EA_REQUIRE(batch > 0 && batch <= 65535 && M >= 0 && N > 0 && K > 0, "ea_gemm_bf16: bad sizes");
+    EA_REQUIRE(K % BK == 0, "ea_gemm_bf16: K=%d must be a multiple of %d", K, BK);
+    EA_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldc % 8 == 0, "ea_gemm_bf16: N, lda, ldc must be multiples of 8");
+    EA_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0, "ea_gemm_bf16: pointers must be 16-byte aligned");
+    EA_REQUIRE(epilogue >= 0 && epilogue <= 2, "ea_gemm_bf16: unknown epilogue %d", epilogue);
+    if (epilogue == EA_EPI_BIAS_GATE_RES)
+        EA_REQUIRE(res && gate && ldres % 8 == 0 && ((uintptr_t)res % 16 == 0) && ((uintptr_t)gate % 16 == 0),
+                   "ea_gemm_bf16: gated-residual epilogue needs aligned res and gate");
+    if (bias) EA_REQUIRE((uintptr_t)bias % 16 == 0, "ea_gemm_bf16: bias must be 16-byte aligned");
+    if (M == 0) return EA_OK;
+    GemmArgs p;
+    p.A = A; p.W = W; p.bias = bias; p.C = C; p.res = res; p.gate = gate;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.abs_ = a_batch_stride; p.ldc = ldc; p.cbs = c_batch_stride;
+    p.ldres = ldres; p.rbs = res_batch_stride; p.gbs = gate_batch_stride;
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = (N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n, batch);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_done = true;
+    }
+    switch (epilogue) {
+        case EA_EPI_BIAS:
+            hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, dim3(256), GEMM_LDS, st, p);
+            break;
+        case EA_EPI_BIAS_GELU_TANH:
+            hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, dim3(256), GEMM_LDS, st, p);
+            break;
+        default:
+            hipLaunchKernelGGL(gemm_bf16_kernel<2>, grid, dim3(256), GEMM_LDS, st, p);
+            break;
+    }
+    return ea_check_launch("ea_gemm_bf16");
+}

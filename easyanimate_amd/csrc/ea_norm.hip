@@ -1,0 +1,257 @@
+// HBM-bound row kernels: FP32 LayerNorm + adaLN modulation, RMSNorm, small-M linear, sinusoid.
+// One wave (64 lanes) owns one row; each lane keeps its 16-byte vectors of the row in registers, so a
+// row is read once and written once (roofline: 4 bytes/element, SURVEY.md 2.2 "1 read, 1 write").
+#include "ea_common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 16;  // up to 16 x (64 lanes x 8 elems) = 8192 columns
+
+// reference: easyanimate/models/norm.py:16-26 (FP32LayerNorm) + :164-165 (modulation)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_modulate_kernel(
+    const unsigned short* __restrict__ x, unsigned short* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift,
+    int64_t mod_stride, int rows, int dim, int64_t xbs, int64_t ybs, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    const int b = blockIdx.y;
+    if (row >= rows) return;
+    const unsigned short* xr = x + b * xbs + row * dim;
+    unsigned short* yr = y + b * ybs + row * dim;
+    const int nvec = dim >> 3;
+
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * 64 + lane;
+        if (vi < nvec) {
+            u16x8 raw = *reinterpret_cast<const u16x8*>(xr + vi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = bf16_bits_to_f32(raw[j]);
+                s += v[i][j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * 64 + lane;
+        if (vi < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+    const float* sc = scale ? scale + b * mod_stride : nullptr;
+    const float* sh = shift ? shift + b * mod_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * 64 + lane;
+        if (vi < nvec) {
+            const int c0 = vi * 8;
+            u16x8 out;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = (v[i][j] - mean) * rstd;
+                if (gamma) t = t * gamma[c0 + j] + beta[c0 + j];
+                // the reference rounds LN output to bf16 before the modulation (FP32LayerNorm .to(dtype));
+                // we keep fp32 through the modulation: strictly closer to the fp32 oracle.
+                if (sc) t = t * (1.0f + sc[c0 + j]) + sh[c0 + j];
+                out[j] = f32_to_bf16_bits(t);
+            }
+            *reinterpret_cast<u16x8*>(yr + c0) = out;
+        }
+    }
+}
+
+// reference: easyanimate/models/norm.py:28-42 (EasyAnimateRMSNorm)
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __restrict__ x,
+                                                      unsigned short* __restrict__ y,
+                                                      const float* __restrict__ w, int rows, int dim,
+                                                      float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const unsigned short* xr = x + row * dim;
+    unsigned short* yr = y + row * dim;
+    const int nvec = dim >> 3;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * 64 + lane;
+        if (vi < nvec) {
+            u16x8 raw = *reinterpret_cast<const u16x8*>(xr + vi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = bf16_bits_to_f32(raw[j]);
+                s += v[i][j] * v[i][j];
+            }
+        }
+    }
+    const float r = rsqrtf(wave_sum(s) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * 64 + lane;
+        if (vi < nvec) {
+            const int c0 = vi * 8;
+            u16x8 out;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // weight * (x*rsqrt).to(input_dtype): round once to bf16, multiply in fp32, round again
+                const float n = bf16_bits_to_f32(f32_to_bf16_bits(v[i][j] * r));
+                out[j] = f32_to_bf16_bits(w[c0 + j] * n);
+            }
+            *reinterpret_cast<u16x8*>(yr + c0) = out;
+        }
+    }
+}
+
+// y[m,n] = act_out(sum_k act_in(x[m,k]) W[n,k] + bias[n]); one wave per output column n, all m rows.
+// Weight-streaming GEMV: W is read exactly once (bf16x8 per lane), x lives in L1/L2.
+template <int MAXM>
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const float* __restrict__ x,
+                                                             const unsigned short* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ y, int m, int n, int k,
+                                                             int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= n) return;
+    const unsigned short* wr = W + (int64_t)col * k;
+    float acc[MAXM];
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) acc[i] = 0.f;
+    for (int k0 = lane * 8; k0 < k; k0 += 512) {
+        u16x8 raw = *reinterpret_cast<const u16x8*>(wr + k0);
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = bf16_bits_to_f32(raw[j]);
+#pragma unroll
+        for (int i = 0; i < MAXM; ++i) {
+            if (i < m) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float xv = x[(int64_t)i * k + k0 + j];
+                    if (act_in == 1) xv = silu_f(xv);
+                    acc[i] += xv * wv[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) {
+        if (i < m) {
+            float r = wave_sum(acc[i]);
+            if (lane == 0) {
+                if (bias) r += bias[col];
+                if (act_out == 1) r = silu_f(r);
+                y[(int64_t)i * n + col] = r;
+            }
+        }
+    }
+}
+
+// reference: diffusers get_timestep_embedding as called at transformer3d.py:1399,1519
+__global__ void timestep_sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int batch,
+                                         int dim, int round_bf16) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * half) return;
+    const int b = i / half, c = i % half;
+    const float f = expf(-logf(10000.0f) * (float)c / (float)half);
+    const float a = t[b] * f;
+    float cs = cosf(a), sn = sinf(a);
+    if (round_bf16) {
+        cs = bf16_bits_to_f32(f32_to_bf16_bits(cs));
+        sn = bf16_bits_to_f32(f32_to_bf16_bits(sn));
+    }
+    out[(int64_t)b * dim + c] = cs;          // flip_sin_to_cos=True -> [cos | sin]
+    out[(int64_t)b * dim + half + c] = sn;
+}
+
+template <int NV>
+int launch_ln(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* beta, const float* scale,
+              const float* shift, int64_t mod_stride, int batch, int rows, int dim, int64_t xbs,
+              int64_t ybs, float eps, hipStream_t st) {
+    dim3 grid((rows + 3) / 4, batch);
+    hipLaunchKernelGGL(layernorm_modulate_kernel<NV>, grid, dim3(256), 0, st, x, y, gamma, beta, scale, shift,
+                       mod_stride, rows, dim, xbs, ybs, eps);
+    return ea_check_launch("ea_layernorm_modulate_bf16");
+}
+
+}  // namespace
+
+extern "C" int ea_layernorm_modulate_bf16(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* beta,
+                                          const float* scale, const float* shift, int64_t mod_stride,
+                                          int batch, int rows, int dim, int64_t x_batch_stride,
+                                          int64_t y_batch_stride, float eps, void* stream) {
+    EA_REQUIRE(x && y, "ea_layernorm_modulate_bf16: null tensor");
+    EA_REQUIRE(dim > 0 && dim % 8 == 0 && dim <= LN_MAXV * 512, "ea_layernorm_modulate_bf16: dim %d unsupported", dim);
+    EA_REQUIRE((gamma == nullptr) == (beta == nullptr), "ea_layernorm_modulate_bf16: gamma/beta must come together");
+    EA_REQUIRE((scale == nullptr) == (shift == nullptr), "ea_layernorm_modulate_bf16: scale/shift must come together");
+    EA_REQUIRE(batch > 0 && rows >= 0 && batch <= 65535, "ea_layernorm_modulate_bf16: bad batch/rows");
+    if (rows == 0) return EA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nv = (dim / 8 + 63) / 64;
+#define EA_LN_CASE(N)                                                                                          \
+    if (nv <= N)                                                                                               \
+        return launch_ln<N>(x, y, gamma, beta, scale, shift, mod_stride, batch, rows, dim, x_batch_stride, \
+                            y_batch_stride, eps, st);
+    EA_LN_CASE(1) EA_LN_CASE(2) EA_LN_CASE(4) EA_LN_CASE(6) EA_LN_CASE(8) EA_LN_CASE(16)
+#undef EA_LN_CASE
+    return EA_ERR_ARG;
+}
+
+extern "C" int ea_rmsnorm_bf16(const ea_bf16* x, ea_bf16* y, const float* w, int rows, int dim, float eps,
+                               void* stream) {
+    EA_REQUIRE(x && y && w, "ea_rmsnorm_bf16: null tensor");
+    EA_REQUIRE(dim > 0 && dim % 8 == 0 && dim <= LN_MAXV * 512, "ea_rmsnorm_bf16: dim %d unsupported", dim);
+    if (rows <= 0) return EA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nv = (dim / 8 + 63) / 64;
+    dim3 grid((rows + 3) / 4);
+    if (nv <= 2)
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, y, w, rows, dim, eps);
+    else if (nv <= 8)
+        hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, dim3(256), 0, st, x, y, w, rows, dim, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, y, w, rows, dim, eps);
+    return ea_check_launch("ea_rmsnorm_bf16");
+}
+
+extern "C" int ea_linear_small_m(const float* x, const ea_bf16* W, const float* bias, float* y, int m, int n,
+                                 int k, int act_in, int act_out, void* stream) {
+    EA_REQUIRE(x && W && y, "ea_linear_small_m: null tensor");
+    EA_REQUIRE(m > 0 && m <= 8, "ea_linear_small_m: m=%d must be in 1..8", m);
+    EA_REQUIRE(k > 0 && k % 8 == 0 && n > 0, "ea_linear_small_m: k %% 8 != 0 or bad n");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((n + 3) / 4);
+    if (m <= 2)
+        hipLaunchKernelGGL(linear_small_m_kernel<2>, grid, dim3(256), 0, st, x, W, bias, y, m, n, k, act_in, act_out);
+    else
+        hipLaunchKernelGGL(linear_small_m_kernel<8>, grid, dim3(256), 0, st, x, W, bias, y, m, n, k, act_in, act_out);
+    return ea_check_launch("ea_linear_small_m");
+}
+
+extern "C" int ea_timestep_sinusoid(const float* t, float* out, int batch, int dim, int round_bf16,
+                                    void* stream) {
+    EA_REQUIRE(t && out && batch > 0 && dim > 0 && dim % 2 == 0, "ea_timestep_sinusoid: bad arguments");
+    const int n = batch * (dim / 2);
+    hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out,
+                       batch, dim, round_bf16);
+    return ea_check_launch("ea_timestep_sinusoid");
+}

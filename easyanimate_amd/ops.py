@@ -1,0 +1,205 @@
+"""torch.Tensor-level wrappers over the C ABI (include/ea_mi355x.h).
+
+PyTorch is used here only for device memory and streams; every arithmetic op on the hot path is a
+HIP kernel in libea_mi355x.so.  There is no CPU / eager fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+EPI_BIAS = 0
+EPI_BIAS_GELU_TANH = 1
+EPI_BIAS_GATE_RES = 2
+
+_BF16 = torch.bfloat16
+_F32 = torch.float32
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("easyanimate_amd.ops: tensors must live on the GPU -- the hot path has no CPU fallback")
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------------
+def layernorm_modulate(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
+                       scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], eps: float,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 [B,R,D] (last two dims contiguous); scale/shift fp32 [B,D] views with unit inner stride."""
+    _dev(x, gamma, beta, scale, shift, out)
+    _chk(x, _BF16, "x")
+    assert x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2]
+    B, R, D = x.shape
+    if out is None:
+        out = torch.empty((B, R, D), dtype=_BF16, device=x.device)
+    assert out.stride(2) == 1 and out.stride(1) == D
+    mod_stride = 0
+    if scale is not None:
+        _chk(scale, _F32, "scale"); _chk(shift, _F32, "shift")
+        assert scale.shape == (B, D) and shift.shape == (B, D)
+        assert scale.stride(1) == 1 and shift.stride(1) == 1 and scale.stride(0) == shift.stride(0)
+        mod_stride = scale.stride(0)
+    if gamma is not None:
+        _chk(gamma, _F32, "gamma"); _chk(beta, _F32, "beta")
+        assert gamma.is_contiguous() and beta.is_contiguous()
+    _lib.call("ea_layernorm_modulate_bf16", _p(x), _p(out), _p(gamma), _p(beta), _p(scale), _p(shift),
+              mod_stride, B, R, D, x.stride(0), out.stride(0), float(eps), _stream())
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    _dev(x, w)
+    _chk(x, _BF16, "x"); _chk(w, _F32, "w")
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.call("ea_rmsnorm_bf16", _p(x), _p(out), _p(w), x.numel() // D, D, float(eps), _stream())
+    return out
+
+
+def linear_small_m(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act_in: int = 0,
+                   act_out: int = 0) -> torch.Tensor:
+    """x fp32 [m,k] (m<=8), W bf16 [n,k], bias fp32 [n] -> fp32 [m,n]."""
+    _dev(x, W, bias)
+    _chk(x, _F32, "x"); _chk(W, _BF16, "W")
+    assert x.is_contiguous() and W.is_contiguous()
+    m, k = x.shape
+    n = W.shape[0]
+    assert W.shape[1] == k
+    y = torch.empty((m, n), dtype=_F32, device=x.device)
+    _lib.call("ea_linear_small_m", _p(x), _p(W), _p(bias), _p(y), m, n, k, act_in, act_out, _stream())
+    return y
+
+
+def timestep_sinusoid(t: torch.Tensor, dim: int, round_bf16: bool = True) -> torch.Tensor:
+    _dev(t)
+    _chk(t, _F32, "t")
+    out = torch.empty((t.numel(), dim), dtype=_F32, device=t.device)
+    _lib.call("ea_timestep_sinusoid", _p(t), _p(out), t.numel(), dim, int(round_bf16), _stream())
+    return out
+
+
+def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int = EPI_BIAS,
+         out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+         gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = epi(A[b] @ W.T + bias).  A bf16 [B,M,K] or [M,K] (row stride free, inner stride 1),
+    W bf16 [N,K] contiguous, bias fp32 [N]; res bf16 like out (may alias out); gate fp32 [B,N]."""
+    _dev(A, W, bias, out, res, gate)
+    _chk(A, _BF16, "A"); _chk(W, _BF16, "W")
+    squeeze = A.dim() == 2
+    if squeeze:
+        A = A.unsqueeze(0)
+        if out is not None:
+            out = out.unsqueeze(0)
+        if res is not None:
+            res = res.unsqueeze(0)
+        if gate is not None and gate.dim() == 1:
+            gate = gate.unsqueeze(0)
+    B, M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and W.is_contiguous() and A.stride(2) == 1
+    if out is None:
+        out = torch.empty((B, M, N), dtype=_BF16, device=A.device)
+    assert out.shape == (B, M, N) and out.stride(2) == 1
+    if bias is not None:
+        _chk(bias, _F32, "bias")
+    ldres = rbs = gbs = 0
+    if epilogue == EPI_BIAS_GATE_RES:
+        assert res is not None and gate is not None
+        _chk(res, _BF16, "res"); _chk(gate, _F32, "gate")
+        assert res.shape == (B, M, N) and res.stride(2) == 1 and gate.shape == (B, N) and gate.stride(1) == 1
+        ldres, rbs, gbs = res.stride(1), res.stride(0), gate.stride(0)
+    _lib.call("ea_gemm_bf16", _p(A), _p(W), _p(bias), _p(out), _p(res), _p(gate), B, M, N, K,
+              A.stride(1), A.stride(0), out.stride(1), out.stride(0), ldres, rbs, gbs, epilogue, _stream())
+    return out.squeeze(0) if squeeze else out
+
+
+def qknorm_rope(qkv: torch.Tensor, q_out: torch.Tensor, k_out: torch.Tensor, vt_out: torch.Tensor,
+                nq_w, nq_b, nk_w, nk_b, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
+                seq_off: int, eps: float) -> None:
+    """qkv bf16 [B,n_tok,3*H*64]; q_out/k_out bf16 [B,H,S_pad,64]; vt_out bf16 [B,H,64,S_pad]."""
+    _dev(qkv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin)
+    _chk(qkv, _BF16, "qkv")
+    B, n_tok, three_inner = qkv.shape
+    _, H, s_pad, dh = q_out.shape
+    assert dh == 64 and three_inner == 3 * H * 64 and qkv.stride(2) == 1 and qkv.stride(1) == three_inner
+    assert q_out.is_contiguous() and k_out.is_contiguous() and vt_out.is_contiguous()
+    assert vt_out.shape == (B, H, 64, s_pad)
+    if cos is not None:
+        _chk(cos, _F32, "cos"); _chk(sin, _F32, "sin")
+        assert cos.shape == (n_tok, 64) and cos.is_contiguous() and sin.is_contiguous()
+    _lib.call("ea_qknorm_rope_bf16", _p(qkv), qkv.stride(0), _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b),
+              _p(nk_w), _p(nk_b), _p(cos), _p(sin), B, H, n_tok, seq_off, s_pad, float(eps), _stream())
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scale: float,
+              out: Optional[torch.Tensor] = None, q_begin: int = 0, q_end: Optional[int] = None) -> torch.Tensor:
+    """q,k bf16 [B,H,S_pad,64], vt bf16 [B,H,64,S_pad] -> out bf16 [B,seq,H*64]."""
+    _dev(q, k, vt, out)
+    B, H, s_pad, dh = q.shape
+    assert dh == 64 and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    if out is None:
+        out = torch.empty((B, seq, H * 64), dtype=_BF16, device=q.device)
+    assert out.stride(2) == 1 and out.stride(1) == H * 64
+    if q_end is None:
+        q_end = seq
+    _lib.call("ea_attention_fwd_bf16", _p(q), _p(k), _p(vt), _p(out), out.stride(0), B, H, seq, s_pad, q_begin,
+              q_end, float(scale), _stream())
+    return out
+
+
+def patchify(latents: torch.Tensor, extra: Optional[torch.Tensor], k_pad: int) -> torch.Tensor:
+    """latents [B,C,F,H,W] (+ extra [B,C2,F,H,W]) -> bf16 [B, F*(H/2)*(W/2), k_pad]."""
+    _dev(latents, extra)
+    assert latents.is_contiguous() and latents.dtype in (_BF16, _F32)
+    B, C, F, H, W = latents.shape
+    c2 = 0
+    if extra is not None:
+        assert extra.is_contiguous() and extra.dtype == latents.dtype and extra.shape[0] == B and extra.shape[2:] == latents.shape[2:]
+        c2 = extra.shape[1]
+    cols = torch.empty((B, F * (H // 2) * (W // 2), k_pad), dtype=_BF16, device=latents.device)
+    _lib.call("ea_patchify", _p(latents), _p(extra), _p(cols), B, C, c2, F, H, W, k_pad,
+              int(latents.dtype == _BF16), _stream())
+    return cols
+
+
+def unpatchify(tokens: torch.Tensor, channels: int, frames: int, h: int, w: int, out_dtype) -> torch.Tensor:
+    _dev(tokens)
+    _chk(tokens, _BF16, "tokens")
+    assert tokens.is_contiguous() and tokens.shape[1] == frames * h * w and tokens.shape[2] == channels * 4
+    B = tokens.shape[0]
+    out = torch.empty((B, channels, frames, 2 * h, 2 * w), dtype=out_dtype, device=tokens.device)
+    _lib.call("ea_unpatchify", _p(tokens), _p(out), B, channels, frames, h, w, int(out_dtype == _BF16), _stream())
+    return out
+
+
+def cfg_euler_step(v: torch.Tensor, latents: torch.Tensor, guidance: float, dsigma: float, do_cfg: bool) -> None:
+    """In-place: latents <- latents + dsigma * cfg(v).  v [2 or 1, ...] same dtype as latents."""
+    _dev(v, latents)
+    assert v.is_contiguous() and latents.is_contiguous() and v.dtype == latents.dtype
+    n = latents.numel()
+    assert v.numel() == (2 * n if do_cfg else n)
+    _lib.call("ea_cfg_euler_step", _p(v), _p(latents), n, float(guidance), float(dsigma), int(do_cfg),
+              int(latents.dtype == _BF16), _stream())

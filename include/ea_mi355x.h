@@ -1,0 +1,141 @@
+/*
+ * ea_mi355x.h -- C ABI of libea_mi355x.so: the MI355X (gfx950) kernels behind EasyAnimate's
+ * diffusion sampling hot path.
+ *
+ * The reference is 100% Python and has no FFI of its own; every entry point
+ * below therefore replaces a *library call site* on the path, cited as
+ * /root/reference/<file>:<line>.  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add at each site.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never allocates,
+ *     frees or synchronises.  All launches are asynchronous on `stream` (a hipStream_t passed as
+ *     void*; NULL = the legacy default stream).
+ *   - bf16 tensors are raw uint16 storage (`ea_bf16`); fp32 tensors are float.
+ *   - return value: 0 = success; EA_ERR_ARG = invalid argument / unsupported shape; any other value
+ *     is the hipError_t of the failed launch.  ea_last_error_string() describes the last non-zero
+ *     return on the calling thread.  Nothing aborts or throws across this boundary.
+ *   - re-entrant, stateless; safe to call from one thread per process (one process per GPU).
+ */
+#ifndef EA_MI355X_H
+#define EA_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t ea_bf16;
+
+#define EA_OK 0
+#define EA_ERR_ARG (-1)
+
+/* epilogues of ea_gemm_bf16 */
+#define EA_EPI_BIAS 0           /* C = A.W^T + bias                                              */
+#define EA_EPI_BIAS_GELU_TANH 1 /* C = gelu_tanh(A.W^T + bias)       (diffusers FeedForward.net.0) */
+#define EA_EPI_BIAS_GATE_RES 2  /* C = res + gate[b,:] * (A.W^T + bias)  (attention.py:1140,1161)  */
+
+const char* ea_last_error_string(void);
+int ea_version(void);
+
+/* ---- normalisation ------------------------------------------------------------------------- */
+
+/* FP32 LayerNorm + affine + adaLN modulation, one pass:
+ *   y[b,r,:] = (LN_fp32(x[b,r,:]; gamma, beta, eps)) * (1 + scale[b,:]) + shift[b,:]
+ * Replaces easyanimate/models/norm.py:164-165 (EasyAnimateLayerNormZero.forward, FP32LayerNorm
+ * norm.py:16-26) and, with the same operand order, diffusers AdaLayerNorm as used at
+ * easyanimate/models/transformer3d.py:1678.  gamma/beta may be NULL (no affine); scale/shift may be
+ * NULL (plain LayerNorm, transformer3d.py:1674).  scale/shift are fp32 rows of a [batch, mod_stride]
+ * table (the chunked output of the adaLN Linear), so no chunk copies are needed.
+ * x/y: bf16 [batch, rows, dim], row-contiguous, batch strides in elements.  dim % 8 == 0, dim <= 8192. */
+int ea_layernorm_modulate_bf16(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* beta,
+                               const float* scale, const float* shift, int64_t mod_stride,
+                               int batch, int rows, int dim, int64_t x_batch_stride,
+                               int64_t y_batch_stride, float eps, void* stream);
+
+/* EasyAnimateRMSNorm (easyanimate/models/norm.py:28-42): y = w * bf16(x * rsqrt(mean(x^2)+eps)).
+ * x,y bf16 [rows, dim]; w fp32 [dim]. */
+int ea_rmsnorm_bf16(const ea_bf16* x, ea_bf16* y, const float* w, int rows, int dim, float eps,
+                    void* stream);
+
+/* ---- small-M linear (adaLN tables, timestep MLP) -------------------------------------------- */
+
+/* y[m,n] = act_out( sum_k act_in(x[m,k]) * W[n,k] + bias[n] ),  m < 16.
+ * act_in: 0 none, 1 SiLU (norm.py:163 `linear(silu(temb))`).  act_out: 0 none, 1 SiLU
+ * (diffusers TimestepEmbedding).  x fp32 [m,k]; W bf16 [n,k]; bias fp32 [n] or NULL; y fp32 [m,n]. */
+int ea_linear_small_m(const float* x, const ea_bf16* W, const float* bias, float* y, int m, int n,
+                      int k, int act_in, int act_out, void* stream);
+
+/* diffusers Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0) (transformer3d.py:1399,1519):
+ * out[b, 0:half] = cos(t_b * f_i), out[b, half:] = sin(t_b * f_i), f_i = exp(-ln(1e4) * i / half).
+ * The result is rounded to bf16 and widened again (the reference casts to the latent dtype). */
+int ea_timestep_sinusoid(const float* t, float* out, int batch, int dim, int round_bf16, void* stream);
+
+/* ---- GEMM ---------------------------------------------------------------------------------- */
+
+/* Batched-over-rows GEMM with shared weight and fused epilogue (MFMA bf16, fp32 accumulate):
+ *   for b in [0,batch): C_b[M,N] = epi( A_b[M,K] . W[N,K]^T + bias[N] )
+ * A_b = A + b*a_batch_stride (row stride lda), C_b likewise (ldc), res_b likewise (ldres; may alias C),
+ * gate row = gate + b*gate_batch_stride (fp32 [N]).  W is nn.Linear.weight layout [N,K] row-major.
+ * Replaces nn.Linear at processor.py:244-246,261-263,303-311, diffusers FeedForward (attention.py:
+ * 1156-1160), transformer3d.py:1531 (patch embed as GEMM), :1533, :1680.
+ * Requirements: K % 64 == 0, lda/ldc/ldres % 8 == 0, N % 8 == 0, all base pointers 16-byte aligned. */
+int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16* C,
+                 const ea_bf16* res, const float* gate, int batch, int M, int N, int K, int64_t lda,
+                 int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
+                 int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream);
+
+/* ---- attention ----------------------------------------------------------------------------- */
+
+/* qk-LayerNorm(head_dim=64) + interleaved RoPE + head-major scatter, one pass over a QKV buffer.
+ * Replaces processor.py:251-258,268-285 (view/transpose, norm_q/norm_k, torch.cat, apply_rotary_emb).
+ *   qkv   : bf16 [batch, n_tok, 3*heads*64]  (q | k | v along the last axis), batch stride given
+ *   q_out : bf16 [batch, heads, s_pad, 64]   rows [seq_off, seq_off+n_tok) are written
+ *   k_out : same
+ *   vt_out: bf16 [batch, heads, 64, s_pad]   (V transposed: the PV operand layout of ea_attention_fwd)
+ *   nq_w,nq_b,nk_w,nk_b: fp32 [64] LayerNorm affine of norm_q / norm_k (eps = ln_eps)
+ *   cos,sin: fp32 [n_tok, 64] or NULL (text tokens: no RoPE), row r applies to token r
+ * s_pad % 64 == 0. */
+int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q_out, ea_bf16* k_out,
+                        ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
+                        const float* nk_b, const float* cos, const float* sin, int batch, int heads,
+                        int n_tok, int seq_off, int s_pad, float ln_eps, void* stream);
+
+/* Non-causal, unmasked softmax(Q K^T * scale) V, head_dim 64, bf16 in/out, fp32 softmax state.
+ * Replaces F.scaled_dot_product_attention at processor.py:287-289 plus the transpose/reshape at :291.
+ *   q,k : bf16 [batch, heads, s_pad, 64];  vt: bf16 [batch, heads, 64, s_pad]; rows/cols >= seq are
+ *         never read as valid keys (they are masked) but must be finite-or-zero in vt.
+ *   out : bf16 [batch, seq, heads*64] (out_batch_stride elements between batches)
+ * Only query rows [q_begin, q_end) are computed (sequence parallelism: a rank owns a query range but
+ * sees all keys).  s_pad % 256 == 0 and s_pad >= seq. */
+int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                          int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
+                          int q_begin, int q_end, float scale, void* stream);
+
+/* ---- latent-space elementwise ---------------------------------------------------------------- */
+
+/* Patchify gather for the 2x2/stride-2 Conv2d patch embedding (transformer3d.py:1523-1531):
+ *   cols[b, (f,i,j), (c,di,dj)] = cat(latents, extra)[b, c, f, 2i+di, 2j+dj], zero-padded to k_pad.
+ * latents fp32-or-bf16 selected by lat_is_bf16; extra may be NULL (c_extra = 0). */
+int ea_patchify(const void* latents, const void* extra, ea_bf16* cols, int batch, int c_lat,
+                int c_extra, int frames, int height, int width, int k_pad, int lat_is_bf16,
+                void* stream);
+
+/* Un-patchify (transformer3d.py:1683-1685): tokens bf16 [batch, F*h*w, C*2*2] -> out [batch,C,F,2h,2w]
+ * (out fp32 or bf16). */
+int ea_unpatchify(const ea_bf16* tokens, void* out, int batch, int channels, int frames, int h, int w,
+                  int out_is_bf16, void* stream);
+
+/* CFG combine + Flow-matching Euler step, fp32 math (pipeline_easyanimate.py:1102-1104,1111;
+ * diffusers FlowMatchEulerDiscreteScheduler.step):
+ *   v = v_uncond + g*(v_text - v_uncond);  x <- bf16/float( float(x) + dsigma * v )
+ * v: [2, n] (uncond, text) when do_cfg else [1, n]; model-dtype in/out selected by is_bf16. */
+int ea_cfg_euler_step(const void* v, void* latents, int64_t n, float guidance, float dsigma, int do_cfg,
+                      int is_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EA_MI355X_H */

@@ -1,0 +1,293 @@
+"""GPU parity of every HIP kernel, called through the C ABI (easyanimate_amd.ops -> ctypes), against a
+plain PyTorch fp32/fp64 statement of the same op on the same bf16-rounded inputs.
+
+Tolerances are stated per test; bf16 output rounding alone is 2^-9 relative (3.9e-3)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from easyanimate_amd import ops
+    return ops
+
+
+def _report(name, got, ref):
+    got = got.double().cpu()
+    ref = ref.double().cpu()
+    err = (got - ref).abs().max().item()
+    rel = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    print(f"[parity] {name}: max_abs={err:.3e} rel_l2={rel:.3e} ref_absmax={ref.abs().max().item():.3e}")
+    return err, rel
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,R,D", [(2, 37, 3072), (1, 5, 128), (2, 300, 512), (1, 9, 8192)])
+@pytest.mark.parametrize("affine,mod", [(True, True), (False, True), (True, False)])
+def test_layernorm_modulate(B, R, D, affine, mod):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = _bf(torch.randn(B, R, D, generator=g) * 2 + 0.3).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV) if affine else None
+    beta = (0.1 * torch.randn(D, generator=g)).to(DEV) if affine else None
+    table = torch.randn(B, 6 * D, generator=g).to(DEV)
+    shift, scale = (table[:, 0:D], table[:, D:2 * D]) if mod else (None, None)
+    y = ops.layernorm_modulate(x, gamma, beta, scale, shift, 1e-6)
+    xr = x.double()
+    ref = torch.nn.functional.layer_norm(xr, (D,), gamma.double() if affine else None,
+                                         beta.double() if affine else None, 1e-6)
+    if mod:
+        ref = ref * (1 + scale.double()[:, None]) + shift.double()[:, None]
+    err, rel = _report(f"layernorm_modulate {B}x{R}x{D}", y, ref)
+    assert rel < 4e-3 and err < 0.08  # one bf16 rounding of values up to ~16
+
+
+def test_rmsnorm():
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = _bf(torch.randn(512, 3584, generator=g) * 30).to(DEV)
+    w = (1 + 0.1 * torch.randn(3584, generator=g)).to(DEV)
+    y = ops.rmsnorm(x, w, 1e-6)
+    xr = x.double()
+    ref = w.double() * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    err, rel = _report("rmsnorm", y, ref)
+    assert rel < 6e-3
+
+
+@pytest.mark.parametrize("m,n,k,ai,ao", [(2, 18432, 512, 1, 0), (2, 512, 3072, 0, 1), (1, 100, 64, 0, 0), (4, 77, 512, 1, 1)])
+def test_linear_small_m(m, n, k, ai, ao):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(m, k, generator=g).to(DEV)
+    W = _bf(torch.randn(n, k, generator=g) / math.sqrt(k)).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    y = ops.linear_small_m(x, W, b, ai, ao)
+    xi = torch.nn.functional.silu(x.double()) if ai else x.double()
+    ref = xi @ W.double().t() + b.double()
+    if ao:
+        ref = torch.nn.functional.silu(ref)
+    err, rel = _report(f"linear_small_m {m}x{n}x{k}", y, ref)
+    assert rel < 1e-5
+
+
+def test_timestep_sinusoid():
+    ops = _ops()
+    t = torch.tensor([999.0, 500.5, 1.0], device=DEV)
+    dim = 3072
+    y = ops.timestep_sinusoid(t, dim, round_bf16=False)
+    half = dim // 2
+    f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=DEV) / half)
+    a = t[:, None].float() * f[None]
+    ref = torch.cat([torch.cos(a), torch.sin(a)], -1)
+    err, rel = _report("timestep_sinusoid", y, ref)
+    assert err < 2e-3  # fp32 sin/cos of arguments up to 1e3: argument rounding dominates
+    yb = ops.timestep_sinusoid(t, dim, round_bf16=True)
+    assert torch.equal(yb, yb.to(torch.bfloat16).float())
+
+
+GEMM_SHAPES = [
+    # B, M, N, K
+    (1, 128, 128, 64),
+    (1, 300, 192, 128),     # M and N tails
+    (2, 257, 3072, 3072),   # batch, tail
+    (1, 1000, 12288, 3072),
+    (1, 512, 3072, 12288),
+    (2, 64, 64, 3584),      # narrow N (proj_out-like), K = 56*64
+    (1, 5, 8, 64),
+]
+
+
+@pytest.mark.parametrize("B,M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm(B, M, N, K, epi):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    # A is a strided view (row stride K+8, batch gap) to exercise lda / batch strides
+    Abuf = _bf(torch.randn(B, M + 3, K + 8, generator=g)).to(DEV)
+    A = Abuf[:, 1:M + 1, :K]
+    W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = _bf(torch.randn(B, M, N, generator=g)).to(DEV)
+    gate = torch.randn(B, N, generator=g).to(DEV)
+    ref = A.double() @ W.double().t() + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    if epi == 2:
+        ref = res.double() + gate.double()[:, None, :] * ref
+        out = res.clone()  # in-place residual update, as the DiT block uses it
+        y = ops.gemm(A, W, bias, epi, out=out, res=out, gate=gate)
+    else:
+        y = ops.gemm(A, W, bias, epi)
+    err, rel = _report(f"gemm B{B} {M}x{N}x{K} epi{epi}", y, ref)
+    assert rel < 4e-3, (err, rel)
+    assert err < 0.06 * max(1.0, ref.abs().max().item() / 4)
+
+
+def test_gemm_identity_transpose_detect():
+    """A = I with asymmetric W: catches swapped row/col in the C write (guide rule 16)."""
+    ops = _ops()
+    K = 128
+    A = torch.eye(K, dtype=torch.bfloat16, device=DEV)
+    W = _bf(torch.arange(256 * K, dtype=torch.float32).reshape(256, K) % 251 - 125).to(DEV)
+    y = ops.gemm(A, W, None, 0)
+    assert torch.equal(y.float(), W.float().t())
+
+
+def _ref_qknorm_rope(qkv, H, nq_w, nq_b, nk_w, nk_b, cos, sin, eps):
+    B, n, _ = qkv.shape
+    q, k, v = qkv.float().chunk(3, dim=-1)
+
+    def heads(t):
+        return t.view(B, n, H, 64).transpose(1, 2)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    q = torch.nn.functional.layer_norm(q, (64,), nq_w, nq_b, eps).to(torch.bfloat16)
+    k = torch.nn.functional.layer_norm(k, (64,), nk_w, nk_b, eps).to(torch.bfloat16)
+
+    def rope(x):
+        if cos is None:
+            return x
+        xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+        rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+        return (x.float() * cos[None, None] + rot.float() * sin[None, None]).to(torch.bfloat16)
+
+    return rope(q), rope(k), v.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,H,n_tok,seq_off,use_rope", [(2, 3, 200, 256, True), (1, 2, 77, 0, False), (2, 48, 130, 8, True), (1, 2, 64, 3, True)])
+def test_qknorm_rope(B, H, n_tok, seq_off, use_rope):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    qkv = _bf(torch.randn(B, n_tok, 3 * H * 64, generator=g) * 1.5 + 0.2).to(DEV)
+    nq_w, nk_w = [(1 + 0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    nq_b, nk_b = [(0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    ang = torch.rand(n_tok, 32, generator=g) * 6.28
+    cos = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV) if use_rope else None
+    sin = ang.sin().repeat_interleave(2, 1).contiguous().to(DEV) if use_rope else None
+    s_pad = ops.round_up(seq_off + n_tok, 256)
+    q = torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=DEV)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=DEV)
+    ops.qknorm_rope(qkv, q, k, vt, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off, 1e-6)
+    rq, rk, rv = _ref_qknorm_rope(qkv, H, nq_w, nq_b, nk_w, nk_b, cos, sin, 1e-6)
+    sl = slice(seq_off, seq_off + n_tok)
+    for name, got, ref in (("q", q[:, :, sl], rq), ("k", k[:, :, sl], rk), ("v", vt[:, :, :, sl].transpose(2, 3), rv)):
+        err, rel = _report(f"qknorm_rope {name} B{B}H{H}n{n_tok}", got, ref)
+        assert rel < 4e-3, name
+    assert torch.equal(rv, vt[:, :, :, sl].transpose(2, 3))  # V is a pure copy/transposition
+    # rows outside the written window stay zero
+    assert q[:, :, :seq_off].abs().max().item() == 0 if seq_off else True
+    assert q[:, :, seq_off + n_tok:].abs().max().item() == 0
+    assert vt[:, :, :, seq_off + n_tok:].abs().max().item() == 0
+
+
+def _attn_inputs(B, H, S, seed, scale_q=1.0):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    s_pad = ops.round_up(S, 256)
+    q = torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=DEV)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=DEV)
+    q[:, :, :S] = _bf(torch.randn(B, H, S, 64, generator=g) * scale_q).to(DEV)
+    k[:, :, :S] = _bf(torch.randn(B, H, S, 64, generator=g)).to(DEV)
+    v = _bf(torch.randn(B, H, S, 64, generator=g)).to(DEV)
+    vt[:, :, :, :S] = v.transpose(2, 3)
+    return q, k, vt, v
+
+
+def _attn_ref(q, k, v, S):
+    qf, kf, vf = q[:, :, :S].double(), k[:, :, :S].double(), v.double()
+    p = torch.softmax(qf @ kf.transpose(2, 3) / 8.0, dim=-1)
+    o = p @ vf
+    B, H = q.shape[:2]
+    return o.transpose(1, 2).reshape(B, S, H * 64)
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (1, 2, 256), (2, 3, 333), (1, 2, 1000), (2, 9, 2048 + 77), (1, 1, 5)])
+def test_attention(B, H, S):
+    ops = _ops()
+    q, k, vt, v = _attn_inputs(B, H, S, 7, scale_q=2.0)
+    out = ops.attention(q, k, vt, S, 0.125)
+    ref = _attn_ref(q, k, v, S)
+    err, rel = _report(f"attention B{B}H{H}S{S}", out, ref)
+    assert rel < 8e-3 and err < 0.05, (err, rel)
+
+
+def test_attention_forced_rescale_and_padding_garbage():
+    """Spike keys late in the sequence so the running max jumps in a late tile (online-softmax rescale branch),
+    and poison the padded tail of q/k to prove masked keys cannot leak (vt tail must stay finite by contract)."""
+    ops = _ops()
+    B, H, S = 1, 2, 700
+    q, k, vt, v = _attn_inputs(B, H, S, 11)
+    k[:, :, 650] = q[:, :, 3] * 6  # huge score for query 3 at key 650 (tile 10)
+    k[:, :, 130] = q[:, :, 300] * 5
+    q[:, :, S:] = 1e30
+    k[:, :, S:] = -1e30
+    out = ops.attention(q, k, vt, S, 0.125)
+    ref = _attn_ref(q, k, v, S)
+    err, rel = _report("attention forced-rescale", out, ref)
+    assert torch.isfinite(out.float()).all()
+    assert rel < 8e-3 and err < 0.05
+
+
+def test_attention_query_range():
+    """Sequence-parallel use: only rows [q_begin, q_end) are produced, the rest of `out` is untouched."""
+    ops = _ops()
+    B, H, S = 1, 2, 1300
+    q, k, vt, v = _attn_inputs(B, H, S, 13)
+    ref = _attn_ref(q, k, v, S)
+    out = torch.full((B, S, H * 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.attention(q, k, vt, S, 0.125, out=out, q_begin=512, q_end=1024)
+    err, rel = _report("attention q-range", out[:, 512:1024], ref[:, 512:1024])
+    assert rel < 8e-3
+    assert (out[:, :512] == 7.0).all() and (out[:, 1024:] == 7.0).all()
+
+
+def test_patchify_unpatchify_cfg_euler():
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(17)
+    B, C, F, H, W = 2, 16, 3, 8, 12
+    lat = torch.randn(B, C, F, H, W, generator=g).to(DEV)
+    extra = torch.randn(B, 17, F, H, W, generator=g).to(DEV)
+    for ex, kp in ((None, 64), (extra, 192)):
+        for dt in (torch.float32, torch.bfloat16):
+            l = lat.to(dt)
+            e = ex.to(dt) if ex is not None else None
+            cols = ops.patchify(l, e, kp)
+            x = l if e is None else torch.cat([l, e], 1)
+            Ct = x.shape[1]
+            ref = x.reshape(B, Ct, F, H // 2, 2, W // 2, 2).permute(0, 2, 3, 5, 1, 4, 6).reshape(B, F * (H // 2) * (W // 2), Ct * 4)
+            assert torch.equal(cols[:, :, :Ct * 4], ref.to(torch.bfloat16))
+            assert cols[:, :, Ct * 4:].abs().max().item() == 0 if kp > Ct * 4 else True
+    tok = _bf(torch.randn(B, F * (H // 2) * (W // 2), C * 4, generator=g)).to(DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        out = ops.unpatchify(tok, C, F, H // 2, W // 2, dt)
+        ref = tok.reshape(B, F, H // 2, W // 2, C, 2, 2).permute(0, 4, 1, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+        assert torch.equal(out, ref.to(dt))
+    for dt in (torch.float32, torch.bfloat16):
+        v = torch.randn(2, C, F, H, W, generator=g).to(DEV).to(dt)
+        x = torch.randn(1, C, F, H, W, generator=g).to(DEV).to(dt)
+        x0 = x.clone()
+        ops.cfg_euler_step(v, x, 6.0, -0.02, True)
+        vv = (v[0:1] + 6.0 * (v[1:2] - v[0:1]))
+        ref = (x0.float() + (-0.02) * vv.float()).to(dt)
+        err, rel = _report(f"cfg_euler {dt}", x, ref)
+        assert rel < (1e-6 if dt == torch.float32 else 6e-3)
+
+
+def test_errors_are_reported_not_fatal():
+    ops = _ops()
+    A = torch.zeros(4, 100, dtype=torch.bfloat16, device=DEV)  # K=100 is not a multiple of 64
+    W = torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(A, W, None, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(A.cpu(), W.cpu(), None, 0)
