@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoise-steps/s of the EasyAnimate V5.1 12B MMDiT at 49 frames x 1024^2 (BASELINE.json
+`metric`) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One *step* = one iteration of the sampling loop (pipeline_easyanimate.py:1069-1111): transformer forward on the
+CFG pair (B=2) + CFG combine + Flow-matching Euler update, TeaCache off.  Synthetic data: random-init weights of
+the declared 12B architecture, N(0,1) latents and text embeddings.  N>1 = sequence parallel
+over the video tokens (strong scaling: the job is one video).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # name: (layers, frames, height, width)   -- all: d=3072 (48x64), ff 12288, text 256 x 3584, CFG batch 2
+    "c3": dict(desc="12B DiT (48 MMDiT layers, d=3072), 49f x 1024x1024, T=256 text tokens, CFG batch 2, bf16",
+               layers=48, frames=49, height=1024, width=1024),
+    "c2": dict(desc="7B-class DiT (28 MMDiT layers, d=3072), 49f x 512x512, T=256, CFG batch 2, bf16",
+               layers=28, frames=49, height=512, width=512),
+    "tiny": dict(desc="2-layer d=3072 DiT, 5f x 128x128 (debug)", layers=2, frames=5, height=128, width=128),
+}
+
+
+def build_model(layers: int, device):
+    from easyanimate_amd import EasyAnimateTransformer3DModel
+    with torch.device("meta"):
+        m = EasyAnimateTransformer3DModel(num_attention_heads=48, attention_head_dim=64, in_channels=16, out_channels=16,
+                                          patch_size=2, num_layers=layers, time_embed_dim=512, add_norm_text_encoder=True,
+                                          text_embed_dim=3584, text_embed_dim_t5=None, norm_eps=1e-5,
+                                          time_position_encoding_type="3d_rope", enable_text_attention_mask=True)
+    m = m.to(torch.bfloat16).to_empty(device=device)
+    torch.cuda.manual_seed(0)  # identical weights on every rank
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+            elif name.endswith("bias"):
+                p.uniform_(-0.02, 0.02)
+            else:  # norm gains
+                p.fill_(1.0)
+    return m.eval()
+
+
+def cpu_baseline(budget_s: float = 25.0):
+    """The oracle restatement (a port: kind="port") of one full-width MMDiT block, fp32, on the host cores,
+    on a bounded sample: B=1, 1024 video + 256 text tokens.  Extrapolated to one denoise step of the benchmark
+    shape with the algorithmic-FLOP ratio, labelled as such."""
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle import restatement as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    d, H, T, N = 3072, 48, 256, 1024
+    shapes = {}
+    for n in ("norm1", "norm2"):
+        shapes.update({f"{n}.linear.weight": (6 * d, 512), f"{n}.linear.bias": (6 * d,), f"{n}.norm.weight": (d,), f"{n}.norm.bias": (d,)})
+    for a in ("attn1", "attn2"):
+        for l in ("to_q", "to_k", "to_v", "to_out.0"):
+            shapes.update({f"{a}.{l}.weight": (d, d), f"{a}.{l}.bias": (d,)})
+        for l in ("norm_q", "norm_k"):
+            shapes.update({f"{a}.{l}.weight": (64,), f"{a}.{l}.bias": (64,)})
+    for f in ("ff", "txt_ff"):
+        shapes.update({f"{f}.net.0.proj.weight": (4 * d, d), f"{f}.net.0.proj.bias": (4 * d,), f"{f}.net.2.weight": (d, 4 * d), f"{f}.net.2.bias": (d,)})
+    sd = synth_state_dict(shapes, 0)
+    g = torch.Generator().manual_seed(0)
+    h, e, temb = torch.randn(1, N, d, generator=g), torch.randn(1, T, d, generator=g), torch.randn(1, 512, generator=g)
+    rope = R.rope_3d(64, ((0, 8), (30, 38)), (32, 32), 1)
+    with torch.no_grad():
+        R.dit_block(sd, "", h, e, temb, rope, H, 1e-5)  # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 and time.perf_counter() - t0 < budget_s:
+            R.dit_block(sd, "", h, e, temb, rope, H, 1e-5)
+            reps += 1
+        dt = (time.perf_counter() - t0) / max(reps, 1)
+    S_s = T + N
+    flop_sample = 24.0 * S_s * d * d + 4.0 * S_s * S_s * d
+    return dt, flop_sample, f"oracle/restatement.dit_block fp32, 1 block, B=1, {N} video + {T} text tokens, d=3072 ({reps} reps, {dt:.2f} s each)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from easyanimate_amd import FlowMatchEulerDiscreteScheduler, ops, sequence_parallel
+    from easyanimate_amd.pipeline import EasyAnimatePipeline
+
+    cfg = CONFIGS[args.config]
+    model = build_model(cfg["layers"], device)
+    if world > 1:
+        sequence_parallel.enable(model)
+    sched = FlowMatchEulerDiscreteScheduler(shift=1.0)
+    pipe = EasyAnimatePipeline(vae=None, transformer=model, scheduler=sched)
+
+    K, W = args.steps, args.warmup
+    n_sched = max(50, K + W)
+    sched.set_timesteps(n_sched, device=device, mu=1)
+    g = torch.Generator(device="cpu").manual_seed(43)
+    latents = pipe.prepare_latents(1, 16, cfg["frames"], cfg["height"], cfg["width"], torch.bfloat16, device, g)
+    embeds = torch.randn(2, 256, 3584, generator=torch.Generator(device="cpu").manual_seed(1)).to(device, torch.bfloat16)
+    rope = pipe.rotary_embedding(cfg["height"], cfg["width"], latents.size(2))
+    Fl, hl, wl = latents.shape[2:]
+    N_tok = Fl * (hl // 2) * (wl // 2)
+    S = 256 + N_tok
+    B, H, d, L = 2, 48, 3072, cfg["layers"]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        if W > 0:
+            latents = pipe.denoise(latents, embeds, rope, sched.timesteps[:W], 6.0)
+        sync()
+        t0 = time.perf_counter()
+        with ops.KernelTimer("attention") as kt:
+            latents = pipe.denoise(latents, embeds, rope, sched.timesteps[W:W + K], 6.0)
+        sync()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    finite = bool(torch.isfinite(latents.float()).all().item())
+
+    # ---- roofline of the dominant kernel (attention forward): algorithmic FLOPs per launch / HIP-event duration
+    durs = kt.durations_ms()
+    if world > 1:
+        n_q = max(d_ for d_ in [model.sequence_parallel.shard_range()[1] - model.sequence_parallel.shard_range()[0]])
+        # two launches per block per rank (text rows + own video rows): use the video launches (every 2nd event)
+        durs = durs[1::2]
+        q_rows = n_q
+    else:
+        q_rows = S
+    att_ms = sum(durs) / max(len(durs), 1)
+    att_flop = 4.0 * q_rows * S * 64 * B * H
+    achieved = att_flop / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
+    flop_step = B * L * (24.0 * S * d * d + 4.0 * S * S * d)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "attention_hbm_bytes_per_launch.json")
+    if os.path.exists(pmc) and world == 1 and args.config == "c3":
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "denoise-steps/sec (49f x 1024^2, 12B DiT)" if args.config == "c3" else f"denoise-steps/sec ({args.config})",
+        "value": K / elapsed,
+        "unit": "denoise-steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (random-init weights of the declared 12B architecture, N(0,1) latents + text embeddings)",
+        "config": {"workload": cfg["desc"], "video_tokens": N_tok, "seq_len": S, "cfg_batch": 2,
+                   "parallelism": "single GPU" if world == 1 else f"sp{world} (video-token sequence parallel, K/V all-gather)",
+                   "flop_per_step": flop_step, "step_mfma_frac": flop_step * K / elapsed / (PEAK_BF16_TFLOPS * 1e12 * world),
+                   "finite_output": finite},
+        "roofline": {"bound": "mfma", "kernel": "attention_fwd_kernel (ea_attention_fwd_bf16)", "achieved": achieved,
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "flop_per_launch": att_flop, "avg_launch_ms": att_ms, "launches_timed": len(durs)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        dt, flop_sample, sample = cpu_baseline()
+        est_step_s = dt * flop_step / flop_sample
+        out["cpu_baseline"] = {"value": 1.0 / est_step_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": sample + f"; extrapolated to the full step by the algorithmic-FLOP ratio {flop_step / flop_sample:.3e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,26 @@
+"""easyanimate_amd -- MI355X-native implementation of EasyAnimate's diffusion sampling hot path.
+
+Host code mirrors the reference's module / processor / pipeline interface (same class names, constructor
+and forward signatures, config attributes and state-dict keys); all arithmetic on the path runs in the
+hand-written gfx950 kernels of libea_mi355x.so (include/ea_mi355x.h) -- there is no eager fallback.
+"""
+__version__ = "0.1.0"
+
+_LAZY = {
+    "EasyAnimateTransformer3DModel": "transformer3d",
+    "EasyAnimateDiTBlock": "attention",
+    "EasyAnimateAttnProcessor2_0": "processor",
+    "AutoencoderKLMagvit": "autoencoder_magvit",
+    "FlowMatchEulerDiscreteScheduler": "scheduler",
+    "EasyAnimatePipeline": "pipeline",
+    "EasyAnimateInpaintPipeline": "pipeline",
+    "name_to_transformer3d": "registry",
+    "name_to_autoencoder_magvit": "registry",
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        return getattr(importlib.import_module(f".{_LAZY[name]}", __name__), name)
+    raise AttributeError(name)

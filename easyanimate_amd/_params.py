@@ -1,0 +1,52 @@
+"""Derived-parameter cache: the kernels want fp32 biases/norm affines and bf16 GEMM weights (optionally
+K-padded).  Derived copies are cached per parameter and invalidated when the parameter is modified in place
+(`_version`), re-pointed (`data_ptr`) or moved, so load_state_dict / LoRA merges are observed."""
+from __future__ import annotations
+
+import weakref
+from typing import Callable, Dict, Tuple
+
+import torch
+
+_cache: Dict[Tuple[int, str], Tuple[tuple, torch.Tensor]] = {}
+
+
+def _key(p: torch.Tensor):
+    return (p.data_ptr(), p._version, p.device, p.dtype, tuple(p.shape))
+
+
+def derived(p: torch.Tensor, tag: str, fn: Callable[[torch.Tensor], torch.Tensor]) -> torch.Tensor:
+    k = (id(p), tag)
+    ent = _cache.get(k)
+    sig = _key(p)
+    if ent is not None and ent[0] == sig:
+        return ent[1]
+    with torch.no_grad():
+        val = fn(p.detach())
+    _cache[k] = (sig, val)
+    try:
+        weakref.finalize(p, _cache.pop, k, None)
+    except TypeError:
+        pass
+    return val
+
+
+def f32(p):
+    """fp32 contiguous view/copy of a parameter (bias, LayerNorm affine)."""
+    if p is None:
+        return None
+    if p.dtype == torch.float32 and p.is_contiguous():
+        return p.detach()
+    return derived(p, "f32", lambda t: t.float().contiguous())
+
+
+def bf16_weight(p, k_pad: int | None = None):
+    """bf16 [N, K(_pad)] GEMM weight; the parameter itself when it already is contiguous bf16."""
+    def make(t):
+        t2 = t.reshape(t.shape[0], -1).to(torch.bfloat16)
+        if k_pad is not None and k_pad != t2.shape[1]:
+            t2 = torch.nn.functional.pad(t2, (0, k_pad - t2.shape[1]))
+        return t2.contiguous()
+    if p.dtype == torch.bfloat16 and p.dim() == 2 and p.is_contiguous() and (k_pad is None or k_pad == p.shape[1]):
+        return p.detach()
+    return derived(p, f"bf16w{k_pad}", make)

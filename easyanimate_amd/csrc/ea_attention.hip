@@ -160,7 +160,7 @@ constexpr int ATT_LDS = 2 * ATT_STAGE;      // 32 KiB
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K, const unsigned short* __restrict__ Vt,
     unsigned short* __restrict__ O, int64_t o_bs, int heads, int bh_total, int seq, int s_pad, int q_begin,
-    int nqb, float scale_log2e) {
+    int q_end, int nqb, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
         const float l = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
         const float inv = 1.0f / l;
         const int qr = q0 + qi * 32 + l31;
-        if (qr < seq) {
+        if (qr < q_end) {
             unsigned short* dst = O + b * o_bs + (int64_t)qr * heads * 64 + h * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -359,16 +359,13 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
     EA_REQUIRE(batch > 0 && heads > 0 && seq > 0, "ea_attention_fwd_bf16: bad sizes");
     EA_REQUIRE(s_pad % ATT_QB == 0 && s_pad >= seq, "ea_attention_fwd_bf16: s_pad must be a multiple of 256 and >= seq");
     EA_REQUIRE(q_begin >= 0 && q_begin <= q_end && q_end <= seq, "ea_attention_fwd_bf16: bad query range");
-    EA_REQUIRE(q_begin % 64 == 0, "ea_attention_fwd_bf16: q_begin must be a multiple of 64");
     if (q_end == q_begin) return EA_OK;
     const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
     const int bh = batch * heads;
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
     EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd_bf16: grid too large");
-    // NOTE: rows in [q_end, ...) of the last q-block are computed and stored if < seq; callers that shard
-    // queries (sequence parallel) pass q_end on a 256 boundary or own the trailing rows too.
     const float scale_log2e = scale * 1.4426950408889634f;
     hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt,
-                       out, out_batch_stride, heads, bh, seq, s_pad, q_begin, nqb, scale_log2e);
+                       out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
     return ea_check_launch("ea_attention_fwd_bf16");
 }

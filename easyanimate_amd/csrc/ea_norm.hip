@@ -55,21 +55,38 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
     const float* sc = scale ? scale + b * mod_stride : nullptr;
     const float* sh = shift ? shift + b * mod_stride : nullptr;
+    const bool has_affine = gamma != nullptr, has_mod = sc != nullptr;  // block-uniform
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int vi = i * 64 + lane;
         if (vi < nvec) {
             const int c0 = vi * 8;
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (v[i][j] - mean) * rstd;
+            if (has_affine) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[j] = t[j] * g0[j] + b0[j];
+                    t[4 + j] = t[4 + j] * g1[j] + b1[j];
+                }
+            }
+            // the reference rounds the LN output to bf16 before the modulation (FP32LayerNorm .to(dtype));
+            // we keep fp32 through the modulation: strictly closer to the fp32 oracle.
+            if (has_mod) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + c0), s1 = *reinterpret_cast<const f32x4*>(sc + c0 + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + c0), h1 = *reinterpret_cast<const f32x4*>(sh + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[j] = t[j] * (1.0f + s0[j]) + h0[j];
+                    t[4 + j] = t[4 + j] * (1.0f + s1[j]) + h1[j];
+                }
+            }
             u16x8 out;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float t = (v[i][j] - mean) * rstd;
-                if (gamma) t = t * gamma[c0 + j] + beta[c0 + j];
-                // the reference rounds LN output to bf16 before the modulation (FP32LayerNorm .to(dtype));
-                // we keep fp32 through the modulation: strictly closer to the fp32 oracle.
-                if (sc) t = t * (1.0f + sc[c0 + j]) + sh[c0 + j];
-                out[j] = f32_to_bf16_bits(t);
-            }
+            for (int j = 0; j < 8; ++j) out[j] = f32_to_bf16_bits(t[j]);
             *reinterpret_cast<u16x8*>(yr + c0) = out;
         }
     }
@@ -204,6 +221,9 @@ extern "C" int ea_layernorm_modulate_bf16(const ea_bf16* x, ea_bf16* y, const fl
     EA_REQUIRE((gamma == nullptr) == (beta == nullptr), "ea_layernorm_modulate_bf16: gamma/beta must come together");
     EA_REQUIRE((scale == nullptr) == (shift == nullptr), "ea_layernorm_modulate_bf16: scale/shift must come together");
     EA_REQUIRE(batch > 0 && rows >= 0 && batch <= 65535, "ea_layernorm_modulate_bf16: bad batch/rows");
+    EA_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
+                   mod_stride % 4 == 0 && x_batch_stride % 8 == 0 && y_batch_stride % 8 == 0,
+               "ea_layernorm_modulate_bf16: pointers must be 16-byte aligned (mod_stride %% 4 == 0)");
     if (rows == 0) return EA_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nv = (dim / 8 + 63) / 64;

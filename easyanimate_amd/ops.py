@@ -39,6 +39,46 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
+class KernelTimer:
+    """HIP-event timing of selected kernels on the stream they are launched on (torch's current stream).
+    Used by bench.py for the roofline of the dominant kernel: `with ops.KernelTimer("attention") as kt: ...`,
+    then kt.mean_ms() after a synchronize."""
+    active = None
+
+    def __init__(self, name: str):
+        self.name = name
+        self.events = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimer.active = None
+
+    def wrap(self, name, fn):
+        if name != self.name:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self.events.append((s, e))
+        return r
+
+    def durations_ms(self):
+        return [s.elapsed_time(e) for s, e in self.events]
+
+    def mean_ms(self):
+        d = self.durations_ms()
+        return sum(d) / max(1, len(d))
+
+
+def _timed(name, fn):
+    kt = KernelTimer.active
+    return fn() if kt is None else kt.wrap(name, fn)
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -131,8 +171,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
         _chk(res, _BF16, "res"); _chk(gate, _F32, "gate")
         assert res.shape == (B, M, N) and res.stride(2) == 1 and gate.shape == (B, N) and gate.stride(1) == 1
         ldres, rbs, gbs = res.stride(1), res.stride(0), gate.stride(0)
-    _lib.call("ea_gemm_bf16", _p(A), _p(W), _p(bias), _p(out), _p(res), _p(gate), B, M, N, K,
-              A.stride(1), A.stride(0), out.stride(1), out.stride(0), ldres, rbs, gbs, epilogue, _stream())
+    _timed("gemm", lambda: _lib.call("ea_gemm_bf16", _p(A), _p(W), _p(bias), _p(out), _p(res), _p(gate), B, M, N, K,
+                                     A.stride(1), A.stride(0), out.stride(1), out.stride(0), ldres, rbs, gbs, epilogue,
+                                     _stream()))
     return out.squeeze(0) if squeeze else out
 
 
@@ -165,8 +206,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scal
     assert out.stride(2) == 1 and out.stride(1) == H * 64
     if q_end is None:
         q_end = seq
-    _lib.call("ea_attention_fwd_bf16", _p(q), _p(k), _p(vt), _p(out), out.stride(0), B, H, seq, s_pad, q_begin,
-              q_end, float(scale), _stream())
+    _timed("attention", lambda: _lib.call("ea_attention_fwd_bf16", _p(q), _p(k), _p(vt), _p(out), out.stride(0), B, H,
+                                          seq, s_pad, q_begin, q_end, float(scale), _stream()))
     return out
 
 

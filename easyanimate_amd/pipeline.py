@@ -1,0 +1,260 @@
+"""EasyAnimatePipeline / EasyAnimateInpaintPipeline: the denoise loop and latent plumbing of
+/root/reference/easyanimate/pipeline/pipeline_easyanimate.py:175-1149 and pipeline_easyanimate_inpaint.py
+(constructor slots, __call__ keywords and `.frames` output kept; text encoding is out of scope -- callers pass
+prompt_embeds / negative_prompt_embeds, SURVEY.md section 7 "hard parts")."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .embeddings import get_3d_rotary_pos_embed, get_resize_crop_region_for_grid
+from .scheduler import FlowMatchEulerDiscreteScheduler
+
+
+@dataclass
+class EasyAnimatePipelineOutput:
+    frames: Union[torch.Tensor, np.ndarray]
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """diffusers randn_tensor: sample on the generator's device, then move (CPU generator + GPU target => CPU sample)."""
+    gen_device = generator.device if generator is not None else torch.device(device or "cpu")
+    return torch.randn(shape, generator=generator, device=gen_device, dtype=dtype).to(device or gen_device)
+
+
+def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):
+    if timesteps is not None or sigmas is not None:
+        raise NotImplementedError("custom timesteps/sigmas")
+    scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+    return scheduler.timesteps, num_inference_steps
+
+
+def resize_mask(mask, latent, process_first_frame_only=True):
+    """reference: pipeline_easyanimate_inpaint.py:116-149 (trilinear resize, first frame separately)."""
+    import torch.nn.functional as F
+    latent_size = latent.size()
+    if process_first_frame_only:
+        target_size = list(latent_size[2:])
+        target_size[0] = 1
+        first = F.interpolate(mask[:, :, 0:1, :, :], size=target_size, mode="trilinear", align_corners=False)
+        target_size = list(latent_size[2:])
+        target_size[0] = target_size[0] - 1
+        if target_size[0] != 0:
+            rest = F.interpolate(mask[:, :, 1:, :, :], size=target_size, mode="trilinear", align_corners=False)
+            return torch.cat([first, rest], dim=2)
+        return first
+    return F.interpolate(mask, size=list(latent_size[2:]), mode="trilinear", align_corners=False)
+
+
+class EasyAnimatePipeline:
+    """Text-to-video sampling loop (reference: pipeline_easyanimate.py:175, __call__ :769-1149)."""
+
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, text_encoder_2=None, tokenizer_2=None,
+                 transformer=None, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None):
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
+        self.transformer, self.scheduler = transformer, scheduler
+        self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+        self._interrupt = False
+        self._guidance_scale = 1.0
+        self._guidance_rescale = 0.0
+        self._num_timesteps = 0
+
+    # -- properties mirrored from the reference ------------------------------------------------
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def guidance_rescale(self):
+        return self._guidance_rescale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    def to(self, device):
+        self.transformer.to(device)
+        if self.vae is not None:
+            self.vae.to(device)
+        return self
+
+    # -- helpers --------------------------------------------------------------------------------
+    def latent_shape(self, batch_size, num_channels_latents, video_length, height, width):
+        """reference: prepare_latents :677-690 (3-D VAE with cache_mag_vae)."""
+        mbe = getattr(self.vae, "mini_batch_encoder", 4) if self.vae is not None else 4
+        mbd = getattr(self.vae, "mini_batch_decoder", 1) if self.vae is not None else 1
+        cache = getattr(self.vae, "cache_mag_vae", True) if self.vae is not None else True
+        if video_length == 1:
+            f = 1
+        elif cache:
+            f = int((video_length - 1) // mbe * mbd + 1)
+        else:
+            f = int(video_length // mbe * mbd)
+        return (batch_size, num_channels_latents, f, height // self.vae_scale_factor, width // self.vae_scale_factor)
+
+    def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator,
+                        latents=None):
+        shape = self.latent_shape(batch_size, num_channels_latents, video_length, height, width)
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        return latents
+
+    def rotary_embedding(self, height, width, latent_frames):
+        """reference: :999-1011"""
+        p = self.transformer.config.patch_size
+        gh, gw = height // 8 // p, width // 8 // p
+        base_w, base_h = 720 // 8 // p, 480 // 8 // p
+        cc = get_resize_crop_region_for_grid((gh, gw), base_w, base_h)
+        return get_3d_rotary_pos_embed(self.transformer.config.attention_head_dim, cc, grid_size=(gh, gw),
+                                       temporal_size=latent_frames, use_real=True)
+
+    def decode_latents(self, latents):
+        """reference: :722-742"""
+        latents = 1 / self.vae.config.scaling_factor * latents
+        video = self.vae.decode(latents)[0]
+        video = video.clamp(-1, 1)
+        video = (video / 2 + 0.5).clamp(0, 1)
+        return video.cpu().float().numpy()
+
+    def _embeds(self, prompt_embeds, negative_prompt_embeds, device, dtype):
+        if prompt_embeds is None:
+            raise NotImplementedError(
+                "text encoding (Qwen2-VL / T5 / BERT) is out of scope of this build: pass prompt_embeds and "
+                "negative_prompt_embeds (SURVEY.md section 2 row 8)")
+        pe = prompt_embeds.to(device=device, dtype=dtype)
+        if self.do_classifier_free_guidance:
+            if negative_prompt_embeds is None:
+                raise ValueError("negative_prompt_embeds is required when guidance_scale > 1")
+            pe = torch.cat([negative_prompt_embeds.to(device=device, dtype=dtype), pe])
+        return pe
+
+    def denoise(self, latents, prompt_embeds, image_rotary_emb, timesteps, guidance_scale, inpaint_latents=None,
+                prompt_embeds_2=None, callback_on_step_end=None):
+        """The hot loop (reference :1069-1134): CFG duplicate, bf16 timestep, transformer, CFG combine + Euler
+        update fused in one kernel.  No host synchronisation inside the loop."""
+        do_cfg = guidance_scale > 1
+        for i, t in enumerate(timesteps):
+            if self._interrupt:
+                continue
+            latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
+            t_expand = t.reshape(1).expand(latent_model_input.shape[0]).to(dtype=latent_model_input.dtype)
+            noise_pred = self.transformer(
+                latent_model_input, t_expand, encoder_hidden_states=prompt_embeds,
+                encoder_hidden_states_t5=prompt_embeds_2, image_rotary_emb=image_rotary_emb,
+                inpaint_latents=inpaint_latents, return_dict=False)[0]
+            if noise_pred.size(1) != latents.size(1):
+                noise_pred, _ = noise_pred.chunk(2, dim=1)
+                noise_pred = noise_pred.contiguous()
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False,
+                                          guidance_scale=guidance_scale if do_cfg else None)[0]
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, t, {"latents": latents})
+                latents = out.pop("latents", latents) if out else latents
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, video_length: Optional[int] = None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale: float = 5.0,
+                 negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, prompt_embeds=None, prompt_embeds_2=None,
+                 negative_prompt_embeds=None, negative_prompt_embeds_2=None, prompt_attention_mask=None,
+                 prompt_attention_mask_2=None, negative_prompt_attention_mask=None,
+                 negative_prompt_attention_mask_2=None, output_type: str = "latent", return_dict: bool = True,
+                 callback_on_step_end: Optional[Callable] = None, callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+                 guidance_rescale: float = 0.0, original_size=None, target_size=None, crops_coords_top_left=(0, 0),
+                 clip_image=None, clip_apply_ratio=0.40, comfyui_progressbar=False, timesteps=None):
+        if guidance_rescale != 0.0:
+            raise NotImplementedError("guidance_rescale > 0")
+        height = int(height // 16 * 16)
+        width = int(width // 16 * 16)
+        self._guidance_scale = guidance_scale
+        self._interrupt = False
+        device = self.transformer.device
+        dtype = self.transformer.dtype
+        pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype)
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, mu=1)
+        self._num_timesteps = len(timesteps)
+        nc = self.transformer.config.in_channels
+        latents = self.prepare_latents(1 * num_images_per_prompt, nc, video_length, height, width, dtype, device,
+                                       generator, latents)
+        rope = self.rotary_embedding(height, width, latents.size(2))
+        latents = self.denoise(latents, pe, rope, timesteps, guidance_scale, callback_on_step_end=callback_on_step_end)
+        if output_type == "latent" and self.vae is None:
+            video = latents
+        else:
+            video = self.decode_latents(latents)
+            if output_type == "latent":
+                video = torch.from_numpy(video)
+        if not return_dict:
+            return video
+        return EasyAnimatePipelineOutput(frames=video)
+
+
+class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
+    """I2V / inpaint variant (reference: pipeline_easyanimate_inpaint.py:978-1606): VAE-encode the masked video,
+    resize the mask to latent resolution, feed cat[mask(1), masked_latents(16)] as `inpaint_latents`."""
+
+    def prepare_mask_latents(self, mask_video, masked_video, dtype, device):
+        """reference: :769-826 (.mode() * scaling_factor)"""
+        lat = self.vae.encode(masked_video.to(device=device, dtype=self.vae.dtype))[0].mode()
+        return lat.to(dtype) * self.vae.config.scaling_factor
+
+    def inpaint_conditioning(self, video, mask_video, latents, dtype, device, do_cfg=True):
+        """reference: :1321-1383.  video in [-1,1] [B,3,F,H,W]; mask_video in [0,255]/255 -> [0,1] [B,1,F,H,W]."""
+        mask_condition = mask_video.to(device=device, dtype=torch.float32)
+        masked_video = video.to(device=device, dtype=torch.float32) * (mask_condition < 0.5) + \
+            torch.ones_like(video, device=device, dtype=torch.float32) * -1 * (mask_condition > 0.5)
+        masked_latents = self.prepare_mask_latents(None, masked_video, dtype, device)
+        mask = resize_mask(1 - mask_condition, masked_latents, self.transformer.resize_inpaint_mask_directly is False or True)
+        mask = mask.to(dtype) * self.vae.config.scaling_factor
+        inpaint = torch.cat([mask, masked_latents], dim=1)
+        return torch.cat([inpaint] * 2) if do_cfg else inpaint
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, video_length=None, video=None, mask_video=None, masked_video_latents=None,
+                 height=None, width=None, num_inference_steps: int = 50, guidance_scale: float = 5.0, generator=None,
+                 latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "latent",
+                 return_dict: bool = True, strength: float = 1.0, timesteps=None, **unused):
+        if strength != 1.0:
+            raise NotImplementedError("strength < 1 (V2V re-noising)")
+        height = int(height // 16 * 16)
+        width = int(width // 16 * 16)
+        self._guidance_scale = guidance_scale
+        self._interrupt = False
+        device = self.transformer.device
+        dtype = self.transformer.dtype
+        pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype)
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, mu=1)
+        nc = self.vae.config.latent_channels if self.vae is not None else 16
+        latents = self.prepare_latents(1, nc, video_length, height, width, dtype, device, generator, latents)
+        rope = self.rotary_embedding(height, width, latents.size(2))
+        if video is not None and mask_video is not None:
+            inpaint = self.inpaint_conditioning(video, mask_video, latents, dtype, device, self.do_classifier_free_guidance)
+        else:
+            n_extra = self.transformer.config.in_channels - nc
+            inpaint = torch.zeros((2 if self.do_classifier_free_guidance else 1, n_extra) + tuple(latents.shape[2:]),
+                                  dtype=dtype, device=device)
+        latents = self.denoise(latents, pe, rope, timesteps, guidance_scale, inpaint_latents=inpaint)
+        video_out = latents if (output_type == "latent" and self.vae is None) else self.decode_latents(latents)
+        if not return_dict:
+            return video_out
+        return EasyAnimatePipelineOutput(frames=video_out)

@@ -1,0 +1,138 @@
+"""Attention processor of the MMDiT block -- the narrowest drop-in seam.
+
+Same protocol as /root/reference/easyanimate/models/processor.py:218-312:
+    processor(attn, hidden_states, encoder_hidden_states, attention_mask=None, image_rotary_emb=None, attn2=None)
+        -> (hidden_states, encoder_hidden_states)
+plus four optional keyword arguments (residual / gate for both streams) that let the caller fuse the gated
+residual add of attention.py:1140-1141 into the output-projection GEMM epilogue.  diffusers' Attention.forward
+filters kwargs by this signature, so the extra names are protocol-compatible.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._params import bf16_weight, f32
+
+_ws: Dict[tuple, dict] = {}
+_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _workspace(B: int, H: int, s_pad: int, device) -> dict:
+    """q/k/v^T staging buffers, zero-initialised once: rows >= seq are never written, so they stay zero
+    (ea_attention_fwd_bf16 requires a finite V^T tail)."""
+    key = (B, H, s_pad, str(device))
+    ws = _ws.get(key)
+    if ws is None:
+        _ws.clear()  # one live shape at a time keeps the footprint bounded
+        ws = dict(q=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
+                  k=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
+                  vt=torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=device))
+        _ws[key] = ws
+    return ws
+
+
+def rope_to_device(image_rotary_emb, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The reference moves the CPU cos/sin tables to the device on every call (diffusers apply_rotary_emb);
+    here they are uploaded once and kept resident."""
+    cos, sin = image_rotary_emb
+    if cos.is_cuda and cos.dtype == torch.float32 and cos.is_contiguous():
+        return cos, sin.contiguous()
+    key = (cos.data_ptr(), sin.data_ptr(), tuple(cos.shape), str(device))
+    ent = _rope_cache.get(key)
+    if ent is None:
+        _rope_cache.clear()
+        ent = (cos.to(device=device, dtype=torch.float32).contiguous(), sin.to(device=device, dtype=torch.float32).contiguous())
+        _rope_cache[key] = ent
+    return ent
+
+
+def _bf16c(x):
+    x = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+class EasyAnimateAttnProcessor2_0:
+    def __init__(self):
+        pass
+
+    def __call__(
+        self,
+        attn,
+        hidden_states: torch.Tensor,
+        encoder_hidden_states: torch.Tensor,
+        attention_mask: Optional[torch.Tensor] = None,
+        image_rotary_emb: Optional[torch.Tensor] = None,
+        attn2=None,
+        residual: Optional[torch.Tensor] = None,
+        encoder_residual: Optional[torch.Tensor] = None,
+        gate: Optional[torch.Tensor] = None,
+        encoder_gate: Optional[torch.Tensor] = None,
+        sp=None,
+    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        if attention_mask is not None:
+            # the V5.1 path never passes a mask (transformer3d.py:1502 drops text_embedding_mask)
+            raise NotImplementedError("EasyAnimateAttnProcessor2_0 (HIP): attention_mask is not supported")
+        x = _bf16c(hidden_states)
+        e = _bf16c(encoder_hidden_states)
+        B, N, d = x.shape
+        T = e.shape[1]
+        H = attn.heads
+        assert d == H * 64, "head_dim must be 64"
+        tattn = attn2 if attn2 is not None else attn  # non-MMDiT blocks share the video weights (:241-242)
+        dev = x.device
+
+        # ---- QKV projections (processor.py:244-246, 261-263): three GEMMs into one [B, n, 3d] buffer each
+        qkv_v = torch.empty(B, N, 3 * d, dtype=torch.bfloat16, device=dev)
+        qkv_t = torch.empty(B, T, 3 * d, dtype=torch.bfloat16, device=dev)
+        for i, name in enumerate(("to_q", "to_k", "to_v")):
+            lv, lt = getattr(attn, name), getattr(tattn, name)
+            ops.gemm(x, bf16_weight(lv.weight), f32(lv.bias), ops.EPI_BIAS, out=qkv_v[:, :, i * d:(i + 1) * d])
+            ops.gemm(e, bf16_weight(lt.weight), f32(lt.bias), ops.EPI_BIAS, out=qkv_t[:, :, i * d:(i + 1) * d])
+
+        # ---- qk LayerNorm + RoPE + head-major scatter; text rows first, then video (torch.cat at :277-279)
+        if sp is not None:
+            S, q_begin, q_end, seq_off_v, s_pad = sp.layout(T, N)
+        else:
+            S = T + N
+            s_pad = ops.round_up(S, 256)
+            q_begin, q_end, seq_off_v = 0, S, T
+        ws = _workspace(B, H, s_pad, dev)
+        cos = sin = None
+        if image_rotary_emb is not None:
+            cos, sin = rope_to_device(image_rotary_emb, dev)
+        if attn.norm_q is None or attn.norm_k is None:
+            raise NotImplementedError("qk_norm=None is not supported by the HIP processor")
+        ops.qknorm_rope(qkv_t, ws["q"], ws["k"], ws["vt"], f32(tattn.norm_q.weight), f32(tattn.norm_q.bias),
+                        f32(tattn.norm_k.weight), f32(tattn.norm_k.bias), None, None, 0, tattn.norm_q.eps)
+        ops.qknorm_rope(qkv_v, ws["q"], ws["k"], ws["vt"], f32(attn.norm_q.weight), f32(attn.norm_q.bias),
+                        f32(attn.norm_k.weight), f32(attn.norm_k.bias), cos, sin, seq_off_v, attn.norm_q.eps)
+        if sp is not None:
+            sp.exchange_kv(ws, T, N)
+
+        # ---- joint attention (processor.py:287-291)
+        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        if sp is not None:
+            # replicated text queries (bit-identical on every rank) + this rank's video queries
+            ops.attention(ws["q"], ws["k"], ws["vt"], S, 1.0 / 8.0, out=o, q_begin=0, q_end=T)
+        ops.attention(ws["q"], ws["k"], ws["vt"], S, 1.0 / 8.0, out=o, q_begin=q_begin, q_end=q_end)
+        if sp is not None:
+            o_t, o_v = sp.split_output(o, T, N)
+        else:
+            o_t, o_v = o[:, :T], o[:, T:]
+
+        # ---- output projections (:293-311), optionally with the gated residual fused (attention.py:1140-1141)
+        lo_v, lo_t = attn.to_out[0], tattn.to_out[0]
+        if residual is not None:
+            g_v = gate.reshape(B, d)
+            g_t = encoder_gate.reshape(B, d)
+            h_out = ops.gemm(o_v, bf16_weight(lo_v.weight), f32(lo_v.bias), ops.EPI_BIAS_GATE_RES,
+                             res=_bf16c(residual), gate=g_v)
+            e_out = ops.gemm(o_t, bf16_weight(lo_t.weight), f32(lo_t.bias), ops.EPI_BIAS_GATE_RES,
+                             res=_bf16c(encoder_residual), gate=g_t)
+        else:
+            h_out = ops.gemm(o_v, bf16_weight(lo_v.weight), f32(lo_v.bias), ops.EPI_BIAS)
+            e_out = ops.gemm(o_t, bf16_weight(lo_t.weight), f32(lo_t.bias), ops.EPI_BIAS)
+        return h_out, e_out

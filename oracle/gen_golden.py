@@ -1,0 +1,126 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.pt by executing the UNCHANGED reference modules
+(/root/reference, through oracle/diffusers_shim.py) on seeded synthetic weights and inputs.
+
+    python -m oracle.gen_golden            (run in the build container; /root/reference does not travel)
+
+Weights are not stored: they are regenerated from (state-dict name, shape, seed, style) by
+easyanimate_amd.synthetic.synth_tensor, so the fixtures stay small; the shapes recorded here are the
+reference's own state-dict shapes, which also pins the key names of SURVEY Appendix C.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from easyanimate_amd.synthetic import synth_state_dict  # noqa: E402
+from oracle import ref_loader  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+TINY = dict(num_attention_heads=2, attention_head_dim=64, in_channels=16, out_channels=16, patch_size=2,
+            num_layers=2, time_embed_dim=64, add_norm_text_encoder=True, text_embed_dim=48, text_embed_dim_t5=None,
+            norm_eps=1e-5, time_position_encoding_type="3d_rope", enable_text_attention_mask=True)
+
+
+def _load_sd(module, seed, style):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth_state_dict(shapes, seed, style)
+    module.load_state_dict(sd, strict=True)
+    return shapes
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@torch.no_grad()
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_loader.load()
+    shim = ns.shim
+
+    # ---- rope tables + crop regions (pipeline_easyanimate.py:82-97, 999-1011)
+    rope = {}
+    for (gh, gw, f) in [(4, 4, 3), (16, 16, 1), (24, 42, 1), (6, 10, 4)]:
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((gh, gw), 45, 30)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (gh, gw), f, use_real=True)
+        rope[f"{gh}x{gw}x{f}"] = dict(crops=cc, cos=cos, sin=sin)
+    torch.save(rope, os.path.join(OUT, "rope.pt"))
+
+    # ---- scheduler (diffusers FlowMatchEulerDiscreteScheduler restated in the shim)
+    sched = {}
+    for n, shift in [(2, 1.0), (50, 1.0), (25, 3.0)]:
+        s = shim.FlowMatchEulerDiscreteScheduler(shift=shift)
+        s.set_timesteps(n, device="cpu", mu=1)
+        sched[f"n{n}_shift{shift}"] = dict(timesteps=s.timesteps.clone(), sigmas=s.sigmas.clone())
+    torch.save(sched, os.path.join(OUT, "scheduler.pt"))
+
+    # ---- one DiT block, stress init (attention.py:1028-1163)
+    for name, mmdit in (("dit_block_mmdit", True), ("dit_block_shared", False)):
+        blk = ns.attention.EasyAnimateDiTBlock(dim=128, num_attention_heads=2, attention_head_dim=64, time_embed_dim=64,
+                                               norm_eps=1e-5, is_mmdit_block=mmdit).eval()
+        shapes = _load_sd(blk, 11, "stress")
+        g = _g(5)
+        h = torch.randn(2, 40, 128, generator=g)
+        e = torch.randn(2, 7, 128, generator=g)
+        temb = torch.randn(2, 64, generator=g)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, ((0, 8), (30, 38)), (4, 5), 2, use_real=True)
+        ho, eo = blk(h, e, temb, image_rotary_emb=(cos, sin))
+        hb, eb = blk.to(torch.bfloat16)(h.bfloat16(), e.bfloat16(), temb.bfloat16(), image_rotary_emb=(cos, sin))
+        torch.save(dict(shapes=shapes, seed=11, style="stress", h=h, e=e, temb=temb, cos=cos, sin=sin, h_out=ho, e_out=eo,
+                        h_out_bf16=hb.float(), e_out_bf16=eb.float(), heads=2, norm_eps=1e-5),
+                   os.path.join(OUT, f"{name}.pt"))
+
+    # ---- tiny transformers: T2V (16 ch), InP (33 ch), mixed mmdit/shared blocks
+    for name, over, style in (("transformer_t2v", {}, "stress"), ("transformer_inp", dict(in_channels=33), "default"),
+                              ("transformer_mixed", dict(mmdit_layers=1), "stress")):
+        cfg = dict(TINY, **over)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+        shapes = _load_sd(m, 3, style)
+        g = _g(7)
+        B, Fr, H, W, T = 2, 3, 8, 12, 9
+        lat = torch.randn(B, 16, Fr, H, W, generator=g)
+        inp = torch.randn(B, 17, Fr, H, W, generator=g) if cfg["in_channels"] == 33 else None
+        enc = torch.randn(B, T, cfg["text_embed_dim"], generator=g) * 3
+        t = torch.tensor([999.0, 999.0]).to(torch.bfloat16).float()  # the pipeline rounds t to the latent dtype
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), inpaint_latents=inp, return_dict=False)[0]
+        mb = m.to(torch.bfloat16)
+        outb = mb(lat.bfloat16(), t.bfloat16(), encoder_hidden_states=enc.bfloat16(), image_rotary_emb=(cos, sin),
+                  inpaint_latents=None if inp is None else inp.bfloat16(), return_dict=False)[0]
+        torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=lat, inpaint=inp, enc=enc, t=t, cos=cos, sin=sin,
+                        out=out, out_bf16=outb.float()), os.path.join(OUT, f"{name}.pt"))
+
+    # ---- 2-step CFG denoise loop on the tiny T2V model (pipeline_easyanimate.py:1069-1111)
+    cfg = dict(TINY)
+    m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+    shapes = _load_sd(m, 3, "stress")
+    g = _g(43)
+    Fr, H, W, T = 2, 8, 8, 6
+    latents = torch.randn(1, 16, Fr, H, W, generator=g)
+    enc = torch.randn(2, T, cfg["text_embed_dim"], generator=g)
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+    cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(2, device="cpu", mu=1)
+    x = latents.clone()
+    trace = []
+    for t in s.timesteps:
+        li = torch.cat([x] * 2)
+        te = torch.tensor([t] * 2).to(dtype=li.dtype)
+        v = m(li, te, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), return_dict=False)[0]
+        vu, vt = v.chunk(2)
+        v = vu + 6.0 * (vt - vu)
+        x = s.step(v, t, x, return_dict=False)[0]
+        trace.append(x.clone())
+    torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style="stress", latents=latents, enc=enc, cos=cos, sin=sin,
+                    guidance=6.0, steps=2, trace=trace), os.path.join(OUT, "denoise_loop.pt"))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

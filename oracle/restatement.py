@@ -1,0 +1,256 @@
+"""TEST INFRASTRUCTURE ONLY -- the parity oracle.  Never imported by easyanimate_amd/ (the product).
+
+A plain-PyTorch CPU restatement of the reference's diffusion-sampling hot path, written as pure
+functions over a state dict (reference key names).  Each function cites the
+reference lines it follows.  It is pinned in two ways (tests/test_oracle_cpu.py):
+  1. against the golden vectors in tests/golden/ that oracle/gen_golden.py produced by executing the
+     UNCHANGED reference modules from /root/reference (through oracle/diffusers_shim.py), and
+  2. directly against the live reference whenever /root/reference is present.
+Caveat ("parity unpinned" at the diffusers boundary): the reference has no tests or golden vectors of
+its own, and diffusers 0.30/0.31 is not installable here, so the diffusers pieces
+(Attention, FeedForward, apply_rotary_emb, Timesteps, AdaLayerNorm, FlowMatchEulerDiscreteScheduler)
+are restated from their published behaviour in the shim and here.
+
+dtype policy: every function computes in the dtype of its inputs with the same rounding points as the
+reference modules (F.linear / F.layer_norm on bf16 tensors round their outputs to bf16, FP32LayerNorm
+up-casts, RoPE is fp32 then cast), so `dtype=torch.bfloat16` reproduces the reference's bf16 CPU path
+and `torch.float32` is the exact oracle.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+# ---------------------------------------------------------------------------------------------
+# embeddings / tables
+# ---------------------------------------------------------------------------------------------
+def timestep_sinusoid(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0) as called at
+    easyanimate/models/transformer3d.py:1399,1519."""
+    half = dim // 2
+    e = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = t[:, None].float() * e[None]
+    return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
+
+
+def time_embedding(sd: SD, t: torch.Tensor, inner_dim: int, dtype) -> torch.Tensor:
+    """transformer3d.py:1519-1520 (+ diffusers TimestepEmbedding: linear_2(silu(linear_1(x))))."""
+    x = timestep_sinusoid(t, inner_dim).to(dtype)
+    x = F.linear(x, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
+    x = F.silu(x)
+    return F.linear(x, sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+
+
+def get_resize_crop_region_for_grid(src, tgt_width, tgt_height):
+    """easyanimate/pipeline/pipeline_easyanimate.py:82-97"""
+    tw, th = tgt_width, tgt_height
+    h, w = src
+    r = h / w
+    if r > (th / tw):
+        rh, rw = th, int(round(th / h * w))
+    else:
+        rw, rh = tw, int(round(tw / w * h))
+    top, left = int(round((th - rh) / 2.0)), int(round((tw - rw) / 2.0))
+    return (top, left), (top + rh, left + rw)
+
+
+def rope_3d(embed_dim: int, crops_coords, grid_size, temporal_size: int, theta: float = 10000.0):
+    """diffusers get_3d_rotary_pos_embed, called at pipeline_easyanimate.py:1008."""
+    start, stop = crops_coords
+    gh, gw = grid_size
+
+    def one(dim, pos):
+        pos = torch.from_numpy(np.asarray(pos, dtype=np.float32))
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim))
+        ang = torch.outer(pos, freqs)
+        return ang.cos().repeat_interleave(2, 1).float(), ang.sin().repeat_interleave(2, 1).float()
+
+    gh_ = np.linspace(start[0], stop[0], gh, endpoint=False, dtype=np.float32)
+    gw_ = np.linspace(start[1], stop[1], gw, endpoint=False, dtype=np.float32)
+    gt_ = np.linspace(0, temporal_size, temporal_size, endpoint=False, dtype=np.float32)
+    ft, fh, fw = one(embed_dim // 4, gt_), one(embed_dim // 8 * 3, gh_), one(embed_dim // 8 * 3, gw_)
+
+    def comb(a, b, c):
+        a = a[:, None, None, :].expand(-1, gh, gw, -1)
+        b = b[None, :, None, :].expand(temporal_size, -1, gw, -1)
+        c = c[None, None, :, :].expand(temporal_size, gh, -1, -1)
+        return torch.cat([a, b, c], -1).reshape(temporal_size * gh * gw, -1)
+
+    return comb(ft[0], fh[0], fw[0]), comb(ft[1], fh[1], fw[1])
+
+
+def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """diffusers apply_rotary_emb(use_real=True, unbind_dim=-1), called at processor.py:283-285."""
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return (x.float() * cos[None, None] + rot.float() * sin[None, None]).to(x.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------------
+def fp32_layernorm(x, w, b, eps):
+    """easyanimate/models/norm.py:16-26"""
+    return F.layer_norm(x.float(), (x.shape[-1],), None if w is None else w.float(), None if b is None else b.float(),
+                        eps).to(x.dtype)
+
+
+def rmsnorm(x, w, eps=1e-6):
+    """easyanimate/models/norm.py:28-42"""
+    dt = x.dtype
+    h = x.to(torch.float32)
+    h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps)
+    return w * h.to(dt)
+
+
+def layernorm_zero(sd: SD, pre: str, h, e, temb, eps):
+    """EasyAnimateLayerNormZero.forward, norm.py:160-166"""
+    mod = F.linear(F.silu(temb), sd[pre + "linear.weight"], sd[pre + "linear.bias"])
+    shift, scale, gate, e_shift, e_scale, e_gate = mod.chunk(6, dim=1)
+    w, b = sd.get(pre + "norm.weight"), sd.get(pre + "norm.bias")
+    h = fp32_layernorm(h, w, b, eps) * (1 + scale)[:, None, :] + shift[:, None, :]
+    e = fp32_layernorm(e, w, b, eps) * (1 + e_scale)[:, None, :] + e_shift[:, None, :]
+    return h, e, gate[:, None, :], e_gate[:, None, :]
+
+
+# ---------------------------------------------------------------------------------------------
+# attention processor / block / transformer
+# ---------------------------------------------------------------------------------------------
+def attn_processor(sd: SD, pre1: str, pre2: Optional[str], h, e, rope, heads: int, qk_eps: float = 1e-6):
+    """EasyAnimateAttnProcessor2_0.__call__, processor.py:222-312 (attention_mask is None on this path)."""
+    T = e.shape[1]
+    B = h.shape[0]
+    if pre2 is None:
+        h = torch.cat([e, h], dim=1)
+
+    def qkv(pre, x):
+        q = F.linear(x, sd[pre + "to_q.weight"], sd[pre + "to_q.bias"])
+        k = F.linear(x, sd[pre + "to_k.weight"], sd[pre + "to_k.bias"])
+        v = F.linear(x, sd[pre + "to_v.weight"], sd[pre + "to_v.bias"])
+        dh = q.shape[-1] // heads
+        q, k, v = [t.view(B, -1, heads, dh).transpose(1, 2) for t in (q, k, v)]
+        q = F.layer_norm(q, (dh,), sd[pre + "norm_q.weight"], sd[pre + "norm_q.bias"], qk_eps)
+        k = F.layer_norm(k, (dh,), sd[pre + "norm_k.weight"], sd[pre + "norm_k.bias"], qk_eps)
+        return q, k, v
+
+    q, k, v = qkv(pre1, h)
+    if pre2 is not None:
+        qt, kt, vt = qkv(pre2, e)
+        q, k, v = torch.cat([qt, q], 2), torch.cat([kt, k], 2), torch.cat([vt, v], 2)
+    if rope is not None:
+        q = torch.cat([q[:, :, :T], apply_rotary_emb(q[:, :, T:], *rope)], 2)
+        k = torch.cat([k[:, :, :T], apply_rotary_emb(k[:, :, T:], *rope)], 2)
+    o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
+    o = o.transpose(1, 2).reshape(B, -1, q.shape[1] * q.shape[-1])
+    if pre2 is None:
+        o = F.linear(o, sd[pre1 + "to_out.0.weight"], sd[pre1 + "to_out.0.bias"])
+        return o[:, T:], o[:, :T]
+    oe, oh = o[:, :T], o[:, T:]
+    oh = F.linear(oh, sd[pre1 + "to_out.0.weight"], sd[pre1 + "to_out.0.bias"])
+    oe = F.linear(oe, sd[pre2 + "to_out.0.weight"], sd[pre2 + "to_out.0.bias"])
+    return oh, oe
+
+
+def feed_forward(sd: SD, pre: str, x):
+    """diffusers FeedForward('gelu-approximate'): net.0.proj -> gelu(tanh) -> net.2 (attention.py:1082-1098)"""
+    x = F.gelu(F.linear(x, sd[pre + "net.0.proj.weight"], sd[pre + "net.0.proj.bias"]), approximate="tanh")
+    return F.linear(x, sd[pre + "net.2.weight"], sd[pre + "net.2.bias"])
+
+
+def dit_block(sd: SD, pre: str, h, e, temb, rope, heads: int, norm_eps: float, return_parts: bool = False):
+    """EasyAnimateDiTBlock.forward, easyanimate/models/attention.py:1107-1163 (after_norm=False, not SWA)."""
+    mmdit = (pre + "attn2.to_q.weight") in sd
+    nh, ne, gate, egate = layernorm_zero(sd, pre + "norm1.", h, e, temb, norm_eps)
+    ah, ae = attn_processor(sd, pre + "attn1.", pre + "attn2." if mmdit else None, nh, ne, rope, heads)
+    h = h + gate * ah
+    e = e + egate * ae
+    nh, ne, gate_ff, egate_ff = layernorm_zero(sd, pre + "norm2.", h, e, temb, norm_eps)
+    fh = feed_forward(sd, pre + "ff.", nh)
+    fe = feed_forward(sd, pre + ("txt_ff." if (pre + "txt_ff.net.2.weight") in sd else "ff."), ne)
+    h2 = h + gate_ff * fh
+    e2 = e + egate_ff * fe
+    if return_parts:
+        return h2, e2, dict(attn_h=ah, attn_e=ae, ff_h=fh, ff_e=fe)
+    return h2, e2
+
+
+def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint_latents=None):
+    """EasyAnimateTransformer3DModel.forward, transformer3d.py:1496-1689 (teacache off, no ref/clip)."""
+    heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
+    inner = heads * dh
+    p = cfg["patch_size"]
+    B, C, Fr, H, W = latents.shape
+    dtype = latents.dtype
+    temb = time_embedding(sd, timestep, inner, dtype)
+    x = latents if inpaint_latents is None else torch.cat([latents, inpaint_latents], 1)
+    x = x.permute(0, 2, 1, 3, 4).reshape(B * Fr, x.shape[1], H, W)
+    x = F.conv2d(x, sd["proj.weight"], sd["proj.bias"], stride=p)
+    x = x.reshape(B, Fr, inner, H // p, W // p).permute(0, 2, 1, 3, 4).flatten(2).transpose(1, 2)
+    if "text_proj.0.weight" in sd:
+        e = F.linear(rmsnorm(enc, sd["text_proj.0.weight"]), sd["text_proj.1.weight"], sd["text_proj.1.bias"])
+    else:
+        e = F.linear(enc, sd["text_proj.weight"], sd["text_proj.bias"])
+    for i in range(cfg["num_layers"]):
+        x, e = dit_block(sd, f"transformer_blocks.{i}.", x, e, temb, rope, heads, cfg["norm_eps"])
+    T = e.shape[1]
+    x = torch.cat([e, x], dim=1)
+    x = F.layer_norm(x, (inner,), sd.get("norm_final.weight"), sd.get("norm_final.bias"), cfg["norm_eps"])
+    x = x[:, T:]
+    mod = F.linear(F.silu(temb), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
+    shift, scale = mod.chunk(2, dim=1)
+    x = F.layer_norm(x, (inner,), sd.get("norm_out.norm.weight"), sd.get("norm_out.norm.bias"), cfg["norm_eps"])
+    x = x * (1 + scale[:, None, :]) + shift[:, None, :]
+    x = F.linear(x, sd["proj_out.weight"], sd["proj_out.bias"])
+    out = x.reshape(B, Fr, H // p, W // p, C, p, p).permute(0, 4, 1, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# scheduler + denoise loop
+# ---------------------------------------------------------------------------------------------
+def flow_sigmas(num_inference_steps: int, shift: float = 1.0, use_dynamic_shifting: bool = False,
+                mu: Optional[float] = None, num_train_timesteps: int = 1000):
+    """diffusers FlowMatchEulerDiscreteScheduler.__init__ + set_timesteps.
+    Returns (timesteps fp32 [n], sigmas fp32 [n+1])."""
+    ts = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+    s0 = torch.from_numpy(ts).float() / num_train_timesteps
+    if not use_dynamic_shifting:
+        s0 = shift * s0 / (1 + (shift - 1) * s0)
+    smax, smin = s0[0].item(), s0[-1].item()
+    t = np.linspace(smax * num_train_timesteps, smin * num_train_timesteps, num_inference_steps)
+    s = t / num_train_timesteps
+    if use_dynamic_shifting:
+        s = math.exp(mu) / (math.exp(mu) + (1 / s - 1) ** 1.0)
+    else:
+        s = shift * s / (1 + (shift - 1) * s)
+    s = torch.from_numpy(s).to(torch.float32)
+    return s * num_train_timesteps, torch.cat([s, torch.zeros(1)])
+
+
+def euler_step(v, x, sigma, sigma_next):
+    """FlowMatchEulerDiscreteScheduler.step: fp32 update, cast to the model-output dtype."""
+    return (x.to(torch.float32) + (sigma_next - sigma) * v).to(v.dtype)
+
+
+def denoise_loop(sd: SD, cfg: dict, latents, enc_neg_pos, rope, num_steps: int, guidance_scale: float,
+                 inpaint_latents=None, shift: float = 1.0, return_all: bool = False):
+    """EasyAnimatePipeline.__call__ hot loop, pipeline_easyanimate.py:1069-1111 (CFG on, guidance_rescale 0)."""
+    timesteps, sigmas = flow_sigmas(num_steps, shift=shift)
+    trace = []
+    for i, t in enumerate(timesteps):
+        lat_in = torch.cat([latents] * 2)
+        t_expand = torch.tensor([t] * lat_in.shape[0]).to(dtype=lat_in.dtype)
+        v = transformer_forward(sd, cfg, lat_in, t_expand, enc_neg_pos, rope, inpaint_latents)
+        vu, vt = v.chunk(2)
+        v = vu + guidance_scale * (vt - vu)
+        latents = euler_step(v, latents, sigmas[i], sigmas[i + 1])
+        if return_all:
+            trace.append(latents.clone())
+    return (latents, trace) if return_all else latents

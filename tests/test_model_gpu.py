@@ -1,0 +1,134 @@
+"""GPU parity of the product modules (HIP path through the C ABI) against
+  (a) the committed golden vectors produced by the unchanged reference, and
+  (b) the oracle restatement run on the same seeded inputs (fp32 = exact oracle, bf16 = the reference's own
+      dtype path, whose distance to fp32 is the noise floor).
+Bar (BASELINE.json): MSE < 1e-4 vs the reference; reported with max-abs and relative L2."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=False)
+
+
+def _metrics(name, got, ref_fp32, ref_bf16=None):
+    got = got.double().cpu()
+    r = ref_fp32.double()
+    mse = ((got - r) ** 2).mean().item()
+    rel = ((got - r).norm() / r.norm()).item()
+    mx = (got - r).abs().max().item()
+    msg = f"[parity] {name}: new-bf16 vs ref-fp32 MSE={mse:.3e} rel_l2={rel:.3e} max_abs={mx:.3e} ref_std={r.std().item():.3f}"
+    floor = None
+    if ref_bf16 is not None:
+        b = ref_bf16.double()
+        floor = ((b - r) ** 2).mean().item()
+        msg += f" | ref-bf16 vs ref-fp32 (floor) MSE={floor:.3e} | new vs ref-bf16 MSE={((got - b) ** 2).mean().item():.3e}"
+    print(msg)
+    return mse, rel, floor
+
+
+def _product_model(cfg, shapes, seed, style):
+    from easyanimate_amd import EasyAnimateTransformer3DModel
+    from easyanimate_amd.synthetic import synth_state_dict
+    m = EasyAnimateTransformer3DModel.from_config(cfg)
+    m.load_state_dict(synth_state_dict(shapes, seed, style), strict=True)
+    return m.to(torch.bfloat16).to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", ["dit_block_mmdit", "dit_block_shared"])
+def test_block_vs_golden(name):
+    from easyanimate_amd import EasyAnimateDiTBlock
+    from easyanimate_amd.synthetic import synth_state_dict
+    g = _load(name + ".pt")
+    blk = EasyAnimateDiTBlock(dim=128, num_attention_heads=2, attention_head_dim=64, time_embed_dim=64, norm_eps=1e-5,
+                              is_mmdit_block=name.endswith("mmdit"))
+    blk.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    blk = blk.to(torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        h, e = blk(g["h"].to(DEV).bfloat16(), g["e"].to(DEV).bfloat16(), g["temb"].to(DEV), image_rotary_emb=(g["cos"], g["sin"]))
+    mse_h, rel_h, floor_h = _metrics(name + " hidden", h.float(), g["h_out"], g["h_out_bf16"])
+    mse_e, rel_e, floor_e = _metrics(name + " encoder", e.float(), g["e_out"], g["e_out_bf16"])
+    # not worse than 3x the reference's own bf16-vs-fp32 distance, and inside the 1e-4 bar when the floor is
+    assert mse_h <= max(3 * floor_h, 1e-4) and mse_e <= max(3 * floor_e, 1e-4)
+    assert rel_h < 2e-2 and rel_e < 2e-2
+
+
+@pytest.mark.parametrize("name", ["transformer_t2v", "transformer_inp", "transformer_mixed"])
+def test_transformer_vs_golden(name):
+    g = _load(name + ".pt")
+    m = _product_model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    inp = None if g["inpaint"] is None else g["inpaint"].to(DEV).bfloat16()
+    with torch.no_grad():
+        out = m(g["latents"].to(DEV).bfloat16(), g["t"].to(DEV).bfloat16(), encoder_hidden_states=g["enc"].to(DEV).bfloat16(),
+                image_rotary_emb=(g["cos"], g["sin"]), inpaint_latents=inp, return_dict=False)[0]
+    assert out.shape == g["out"].shape and out.dtype == torch.bfloat16
+    mse, rel, floor = _metrics(name, out.float(), g["out"], g["out_bf16"])
+    assert mse <= max(3 * floor, 1e-4), (mse, floor)
+    assert rel < 3e-2
+    # fp32 latents in -> fp32 out (config-1 style call), same numbers up to the output cast
+    with torch.no_grad():
+        out32 = m(g["latents"].to(DEV), g["t"].to(DEV), encoder_hidden_states=g["enc"].to(DEV),
+                  image_rotary_emb=(g["cos"], g["sin"]),
+                  inpaint_latents=None if g["inpaint"] is None else g["inpaint"].to(DEV), return_dict=True).sample
+    assert out32.dtype == torch.float32
+    mse32, _, _ = _metrics(name + " (fp32 io)", out32, g["out"], g["out_bf16"])
+    assert mse32 <= max(3 * floor, 1e-4)
+
+
+def test_denoise_loop_vs_golden():
+    """2 Flow steps with CFG (pipeline_easyanimate.py:1069-1111) through product transformer + scheduler."""
+    from easyanimate_amd import FlowMatchEulerDiscreteScheduler
+    g = _load("denoise_loop.pt")
+    m = _product_model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    s = FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(g["steps"], device=DEV, mu=1)
+    x = g["latents"].to(DEV).bfloat16()
+    enc = g["enc"].to(DEV).bfloat16()
+    with torch.no_grad():
+        for i, t in enumerate(s.timesteps):
+            li = torch.cat([x] * 2)
+            te = torch.stack([t] * 2).to(li.dtype)
+            v = m(li, te, encoder_hidden_states=enc, image_rotary_emb=(g["cos"], g["sin"]), return_dict=False)[0]
+            x = s.step(v, t, x, return_dict=False, guidance_scale=g["guidance"])[0]
+            mse, rel, _ = _metrics(f"loop latents step {i}", x.float(), g["trace"][i])
+            assert mse < 1e-4
+    assert s.step_index == g["steps"]
+
+
+def test_block_full_width_vs_oracle():
+    """One 12B-width block (d=3072, 48 heads, ff 12288) on 640 video + 256 text tokens, stress init, against the
+    fp32 oracle restatement on CPU; also checks the un-gated attention and FFN branch outputs."""
+    from easyanimate_amd import EasyAnimateDiTBlock
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle import restatement as R
+    torch.manual_seed(0)
+    d, H = 3072, 48
+    blk = EasyAnimateDiTBlock(dim=d, num_attention_heads=H, attention_head_dim=64, time_embed_dim=512, norm_eps=1e-6)
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    sd = synth_state_dict(shapes, 21, "stress")
+    sd = {k: v.bfloat16().float() for k, v in sd.items()}  # same bf16-rounded weights on both sides
+    blk.load_state_dict(sd)
+    blk = blk.to(torch.bfloat16).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    B, N, T = 1, 640, 256
+    h = torch.randn(B, N, d, generator=g).bfloat16().float()
+    e = torch.randn(B, T, d, generator=g).bfloat16().float()
+    temb = torch.randn(B, 512, generator=g)
+    rope = R.rope_3d(64, ((0, 8), (30, 38)), (16, 20), 2)
+    with torch.no_grad():
+        h_ref, e_ref, parts = R.dit_block(sd, "", h, e, temb, rope, H, 1e-6, return_parts=True)
+        h_new, e_new = blk(h.to(DEV).bfloat16(), e.to(DEV).bfloat16(), temb.to(DEV), image_rotary_emb=rope)
+        # un-gated branches through the plain processor protocol (no residual/gate kwargs)
+        nh, ne, _, _ = blk.norm1(h.to(DEV).bfloat16(), e.to(DEV).bfloat16(), temb.to(DEV))
+        ah, ae = blk.attn1(hidden_states=nh, encoder_hidden_states=ne, image_rotary_emb=rope, attn2=blk.attn2)
+    mse_h, rel_h, _ = _metrics("full-width block hidden", h_new.float(), h_ref)
+    mse_e, rel_e, _ = _metrics("full-width block encoder", e_new.float(), e_ref)
+    _, rel_ah, _ = _metrics("full-width un-gated attention (video)", ah.float(), parts["attn_h"])
+    _, rel_ae, _ = _metrics("full-width un-gated attention (text)", ae.float(), parts["attn_e"])
+    assert rel_h < 1.5e-2 and rel_e < 1.5e-2 and rel_ah < 2.5e-2 and rel_ae < 2.5e-2

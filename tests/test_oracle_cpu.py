@@ -1,0 +1,107 @@
+"""CPU tests (no GPU): pin the oracle restatement (oracle/restatement.py) to golden vectors produced by the
+unchanged reference (oracle/gen_golden.py), and -- when /root/reference is present -- to the live reference."""
+import os
+
+import pytest
+import torch
+
+from easyanimate_amd.synthetic import synth_state_dict
+from oracle import ref_loader
+from oracle import restatement as R
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=False)
+
+
+def _close(a, b, tol, what):
+    err = (a.double() - b.double()).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.2f})"
+
+
+@pytest.mark.parametrize("name", ["dit_block_mmdit", "dit_block_shared"])
+def test_restatement_block_vs_golden(name):
+    g = _load(name + ".pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    h, e = R.dit_block(sd, "", g["h"], g["e"], g["temb"], (g["cos"], g["sin"]), g["heads"], g["norm_eps"])
+    _close(h, g["h_out"], 2e-6, "hidden fp32")
+    _close(e, g["e_out"], 2e-6, "encoder fp32")
+    sdb = {k: v.bfloat16() for k, v in sd.items()}
+    hb, eb = R.dit_block(sdb, "", g["h"].bfloat16(), g["e"].bfloat16(), g["temb"].bfloat16(), (g["cos"], g["sin"]),
+                         g["heads"], g["norm_eps"])
+    # same ops on the same bf16 values: identical up to SDPA/cat kernel-selection noise of one bf16 ulp
+    _close(hb.float(), g["h_out_bf16"], 1.6e-2, "hidden bf16")
+    _close(eb.float(), g["e_out_bf16"], 1.6e-2, "encoder bf16")
+
+
+@pytest.mark.parametrize("name", ["transformer_t2v", "transformer_inp", "transformer_mixed"])
+def test_restatement_transformer_vs_golden(name):
+    g = _load(name + ".pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    out = R.transformer_forward(sd, g["cfg"], g["latents"], g["t"], g["enc"], (g["cos"], g["sin"]), g["inpaint"])
+    _close(out, g["out"], 5e-6, "transformer fp32")
+    sdb = {k: v.bfloat16() for k, v in sd.items()}
+    outb = R.transformer_forward(sdb, g["cfg"], g["latents"].bfloat16(), g["t"].bfloat16(), g["enc"].bfloat16(),
+                                 (g["cos"], g["sin"]), None if g["inpaint"] is None else g["inpaint"].bfloat16())
+    _close(outb.float(), g["out_bf16"], 3e-2, "transformer bf16")
+
+
+def test_restatement_rope_and_crops_vs_golden():
+    for key, v in _load("rope.pt").items():
+        gh, gw, f = [int(x) for x in key.split("x")]
+        cc = R.get_resize_crop_region_for_grid((gh, gw), 45, 30)
+        assert tuple(map(tuple, cc)) == tuple(map(tuple, v["crops"]))
+        cos, sin = R.rope_3d(64, cc, (gh, gw), f)
+        assert torch.equal(cos, v["cos"]) and torch.equal(sin, v["sin"])
+    # SURVEY Appendix A facts
+    assert R.get_resize_crop_region_for_grid((64, 64), 45, 30) == ((0, 8), (30, 38))
+    assert R.get_resize_crop_region_for_grid((24, 42), 45, 30) == ((2, 0), (28, 45))
+
+
+def test_restatement_scheduler_vs_golden():
+    for key, v in _load("scheduler.pt").items():
+        n = int(key.split("_")[0][1:])
+        shift = float(key.split("shift")[1])
+        ts, sig = R.flow_sigmas(n, shift=shift)
+        assert torch.equal(ts, v["timesteps"]) and torch.equal(sig, v["sigmas"])
+
+
+def test_restatement_denoise_loop_vs_golden():
+    g = _load("denoise_loop.pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    _, trace = R.denoise_loop(sd, g["cfg"], g["latents"], g["enc"], (g["cos"], g["sin"]), g["steps"], g["guidance"],
+                              return_all=True)
+    for a, b in zip(trace, g["trace"]):
+        _close(a, b, 5e-6, "loop latents")
+
+
+def test_rotation_preserves_pair_norms():
+    """closed-form property of the restated apply_rotary_emb (SURVEY section 7 hard parts)"""
+    x = torch.randn(1, 2, 12, 64)
+    cos, sin = R.rope_3d(64, ((0, 8), (30, 38)), (2, 3), 2)
+    y = R.apply_rotary_emb(x, cos, sin)
+    n0 = x.reshape(1, 2, 12, 32, 2).norm(dim=-1)
+    n1 = y.reshape(1, 2, 12, 32, 2).norm(dim=-1)
+    assert torch.allclose(n0, n1, atol=1e-5)
+    assert R.timestep_sinusoid(torch.tensor([0.0]), 8)[0].tolist() == [1, 1, 1, 1, 0, 0, 0, 0]
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="/root/reference not present (GPU box)")
+def test_restatement_vs_live_reference_block():
+    ns = ref_loader.load()
+    blk = ns.attention.EasyAnimateDiTBlock(dim=128, num_attention_heads=2, attention_head_dim=64, time_embed_dim=32,
+                                           norm_eps=1e-6).eval()
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    sd = synth_state_dict(shapes, 99, "stress")
+    blk.load_state_dict(sd)
+    g = torch.Generator().manual_seed(0)
+    h, e, temb = torch.randn(1, 24, 128, generator=g), torch.randn(1, 5, 128, generator=g), torch.randn(1, 32, generator=g)
+    rope = R.rope_3d(64, ((0, 8), (30, 38)), (4, 6), 1)
+    with torch.no_grad():
+        ho, eo = blk(h, e, temb, image_rotary_emb=rope)
+    h2, e2 = R.dit_block(sd, "", h, e, temb, rope, 2, 1e-6)
+    _close(h2, ho, 2e-6, "live block hidden")
+    _close(e2, eo, 2e-6, "live block encoder")
