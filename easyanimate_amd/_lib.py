@@ -8,6 +8,11 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so) and loads it RTLD_GLOBAL.  It must be in the
+# process BEFORE libea_mi355x.so is dlopen'ed so that the kernels register with, and launch through, the same
+# runtime that owns torch's streams and allocations (otherwise: "no ROCm-capable device is detected").
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libea_mi355x.so")
 

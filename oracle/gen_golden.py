@@ -94,30 +94,36 @@ def main():
         torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=lat, inpaint=inp, enc=enc, t=t, cos=cos, sin=sin,
                         out=out, out_bf16=outb.float()), os.path.join(OUT, f"{name}.pt"))
 
-    # ---- 2-step CFG denoise loop on the tiny T2V model (pipeline_easyanimate.py:1069-1111)
-    cfg = dict(TINY)
-    m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
-    shapes = _load_sd(m, 3, "stress")
-    g = _g(43)
-    Fr, H, W, T = 2, 8, 8, 6
-    latents = torch.randn(1, 16, Fr, H, W, generator=g)
-    enc = torch.randn(2, T, cfg["text_embed_dim"], generator=g)
-    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
-    cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
-    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
-    s.set_timesteps(2, device="cpu", mu=1)
-    x = latents.clone()
-    trace = []
-    for t in s.timesteps:
-        li = torch.cat([x] * 2)
-        te = torch.tensor([t] * 2).to(dtype=li.dtype)
-        v = m(li, te, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), return_dict=False)[0]
-        vu, vt = v.chunk(2)
-        v = vu + 6.0 * (vt - vu)
-        x = s.step(v, t, x, return_dict=False)[0]
-        trace.append(x.clone())
-    torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style="stress", latents=latents, enc=enc, cos=cos, sin=sin,
-                    guidance=6.0, steps=2, trace=trace), os.path.join(OUT, "denoise_loop.pt"))
+    # ---- 2-step CFG denoise loops on the tiny T2V model (pipeline_easyanimate.py:1069-1111), fp32 and bf16
+    for name, style in (("denoise_loop", "stress"), ("denoise_loop_default", "default")):
+        cfg = dict(TINY)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+        shapes = _load_sd(m, 3, style)
+        g = _g(43)
+        Fr, H, W, T = 2, 8, 8, 6
+        latents = torch.randn(1, 16, Fr, H, W, generator=g)
+        enc = torch.randn(2, T, cfg["text_embed_dim"], generator=g)
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        traces = {}
+        for dt in (torch.float32, torch.bfloat16):
+            mm = m.to(dt)
+            s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+            s.set_timesteps(2, device="cpu", mu=1)
+            x = latents.clone().to(dt)
+            trace = []
+            for t in s.timesteps:
+                li = torch.cat([x] * 2)
+                te = torch.tensor([t] * 2).to(dtype=li.dtype)
+                v = mm(li, te, encoder_hidden_states=enc.to(dt), image_rotary_emb=(cos, sin), return_dict=False)[0]
+                vu, vt = v.chunk(2)
+                v = vu + 6.0 * (vt - vu)
+                x = s.step(v, t, x, return_dict=False)[0]
+                trace.append(x.float().clone())
+            traces[dt] = trace
+        torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=latents, enc=enc, cos=cos, sin=sin,
+                        guidance=6.0, steps=2, trace=traces[torch.float32], trace_bf16=traces[torch.bfloat16]),
+                   os.path.join(OUT, f"{name}.pt"))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -81,10 +81,14 @@ def test_transformer_vs_golden(name):
     assert mse32 <= max(3 * floor, 1e-4)
 
 
-def test_denoise_loop_vs_golden():
-    """2 Flow steps with CFG (pipeline_easyanimate.py:1069-1111) through product transformer + scheduler."""
+@pytest.mark.parametrize("name", ["denoise_loop", "denoise_loop_default"])
+def test_denoise_loop_vs_golden(name):
+    """2 Flow steps with CFG 6 (pipeline_easyanimate.py:1069-1111) through product transformer + scheduler.
+    With 2 steps (d_sigma = 0.5) and CFG 6 the velocity's bf16 noise is amplified ~11x: the reference's OWN
+    bf16 path sits at MSE 2e-4..4e-4 from its fp32 path (the floor stored in the fixture), so the bar is
+    max(1e-4, 1.5 x floor).  At the 50-step schedule the same per-forward error integrates to < 1e-4."""
     from easyanimate_amd import FlowMatchEulerDiscreteScheduler
-    g = _load("denoise_loop.pt")
+    g = _load(name + ".pt")
     m = _product_model(g["cfg"], g["shapes"], g["seed"], g["style"])
     s = FlowMatchEulerDiscreteScheduler(shift=1.0)
     s.set_timesteps(g["steps"], device=DEV, mu=1)
@@ -96,8 +100,8 @@ def test_denoise_loop_vs_golden():
             te = torch.stack([t] * 2).to(li.dtype)
             v = m(li, te, encoder_hidden_states=enc, image_rotary_emb=(g["cos"], g["sin"]), return_dict=False)[0]
             x = s.step(v, t, x, return_dict=False, guidance_scale=g["guidance"])[0]
-            mse, rel, _ = _metrics(f"loop latents step {i}", x.float(), g["trace"][i])
-            assert mse < 1e-4
+            mse, rel, floor = _metrics(f"{name} latents step {i}", x.float(), g["trace"][i], g["trace_bf16"][i])
+            assert mse <= max(1e-4, 1.5 * floor)
     assert s.step_index == g["steps"]
 
 
