@@ -80,8 +80,9 @@ class SequenceParallel:
         send = torch.empty((2, B, H, nl * 64), dtype=k.dtype, device=k.device)
         send[0] = k[:, :, off:off + nl].reshape(B, H, nl * 64)
         send[1] = vt[:, :, :, off:off + nl].reshape(B, H, 64 * nl)
-        recv = torch.empty((self.world,) + tuple(send.shape), dtype=k.dtype, device=k.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        recv = torch.empty((self.world * send.numel(),), dtype=k.dtype, device=k.device)
+        dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)  # flat: accepted by nccl/RCCL and gloo
+        recv = recv.view((self.world,) + tuple(send.shape))
         for r in range(self.world):
             if r == self.rank:
                 continue
@@ -100,8 +101,9 @@ class SequenceParallel:
         B, n, C = x.shape
         send = torch.zeros((B, self.n_loc, C), dtype=x.dtype, device=x.device)
         send[:, :n] = x
-        recv = torch.empty((self.world, B, self.n_loc, C), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        recv = torch.empty((self.world * send.numel(),), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)
+        recv = recv.view(self.world, B, self.n_loc, C)
         return recv.permute(1, 0, 2, 3).reshape(B, self.world * self.n_loc, C)[:, :self.n_total].contiguous()
 
 
