@@ -33,6 +33,14 @@ PROTOTYPES = {
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_unpatchify": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ea_cfg_euler_step": [_P, _P, _L, _F, _F, _I, _I, _P],
+    "ea_conv3d_cl_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ea_im2col3d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ea_groupnorm_stats_bf16": [_P, _P, _P, _I, _L, _I, _I, _I, _F, _P],
+    "ea_groupnorm_apply_bf16": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P],
+    "ea_softmax_rows_bf16": [_P, _P, _L, _I, _F, _P],
+    "ea_softmax_rows_f32in": [_P, _P, _L, _I, _F, _P],
+    "ea_ncdhw_to_ndhwc": [_P, _P, _I, _I, _L, _I, _P],
+    "ea_ndhwc_to_ncdhw": [_P, _P, _I, _I, _L, _I, _I, _P],
 }
 
 _lib = None

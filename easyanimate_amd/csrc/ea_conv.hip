@@ -1,0 +1,292 @@
+// Causal 3-D convolution of the MAGVIT VAE as an im2col-free implicit GEMM on channels-last activations.
+// reference: easyanimate/vae/ldm/modules/vaemodules/common.py:84-179 (CausalConv3d), downsamplers.py:24-94,
+// upsamplers.py:21-37,123-153, ResidualBlock3D common.py:298-323.
+//
+//   y[to,ho,wo,:] = bias + sum_{dt,dh,dw} W[:, (dt,dh,dw), :] . x[clamp(to*st+dt-(kt-1), 0), ho*ss+dh-pad, wo*ss+dw-pad, :]
+//
+// GEMM view: M = T_out*H_out*W_out output voxels, N = C_out, K = taps*C_in (tap-major, channel-minor).  With
+// NDHWC activations one A-tile row (one voxel, 64 channels of one tap) is 128 contiguous bytes -- exactly one
+// LDS-DMA row -- so the A tile is *gathered by address*: each lane points its global_load_lds at the voxel the
+// tap selects, or at a page of zeros for the spatial zero padding.  Temporal causality = clamping the frame
+// index at 0 (replicate padding of the first frame; the reference's chunk caches reproduce exactly this, SURVEY
+// 8c property 1).  Nearest x2 spatial up-sampling of the input (upsamplers.py:35,143) is `>> 1` in the address.
+// The epilogue can add a residual (ResidualBlock3D) and can write every output frame t >= 1 twice (frames
+// 2t-1, 2t): the temporal nearest x2 of SpatialTemporalUpsampler3D (upsamplers.py:146-152) costs no extra pass.
+//
+// Tile/MFMA/LDS structure is that of ea_gemm.hip (128 x 128 x 64, 4 waves, LDS-DMA + source swizzle, C^T MFMA).
+#include "ea_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int CONV_LDS = 2 * STAGE_BYTES;
+
+struct ConvArgs {
+    const unsigned short* x;
+    const unsigned short* w;
+    const float* bias;
+    const unsigned short* res;
+    unsigned short* y;
+    const unsigned short* zeros;  // >= 128 bytes of zeros
+    int T_in, H_in, W_in, C_in, C_out;
+    int T_out, H_out, W_out;
+    int kt, kh, kw, st, ss, pad, ups, tdup;
+    int tiles_m, tiles_n;
+    int64_t M;
+};
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+
+__global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // per-XCD bands of M-tiles, all N-tiles of an M-tile adjacent: neighbouring voxels (shared halos) and the
+    // whole weight set stay in one XCD's L2
+    int tm, tn;
+    {
+        const int rpx = (p.tiles_m + 7) / 8;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int m_lo = xcd * rpx;
+        int rows = p.tiles_m - m_lo;
+        rows = rows < rpx ? rows : rpx;
+        if (rows <= 0 || idx >= rows * p.tiles_n) return;
+        tm = m_lo + idx / p.tiles_n;
+        tn = idx % p.tiles_n;
+    }
+    const int64_t row0 = (int64_t)tm * BM;
+    const int col0 = tn * BN;
+
+    // ---- the 4 A-rows (output voxels) this lane fetches per K-tile, and its W-row pointers
+    int vt[4], vh[4], vw[4];
+    bool vvalid[4];
+    int csw[4];
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = (wave * 4 + i) * 64 + lane;
+        const int r = L >> 3, c = L & 7;
+        csw[i] = (c ^ ((r >> 1) & 7)) * 8;
+        int64_t m = row0 + r;
+        vvalid[i] = m < p.M;
+        m = vvalid[i] ? m : p.M - 1;
+        vw[i] = (int)(m % p.W_out);
+        const int64_t q = m / p.W_out;
+        vh[i] = (int)(q % p.H_out);
+        vt[i] = (int)(q / p.H_out);
+        int rw = col0 + r;
+        rw = rw < p.C_out ? rw : p.C_out - 1;
+        wsrc[i] = p.w + (int64_t)rw * ((int64_t)p.kt * p.kh * p.kw * p.C_in) + csw[i];
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_off[2], w_off[2], a_sw[2], w_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + l31;
+        const int rw = wn * 64 + i * 32 + swap23(l31);
+        a_off[i] = ra * 128;
+        a_sw[i] = (ra >> 1) & 7;
+        w_off[i] = rw * 128;
+        w_sw[i] = (rw >> 1) & 7;
+    }
+
+    const int cblocks = p.C_in / BK;
+    const int ntaps = p.kt * p.kh * p.kw;
+    const int nk = ntaps * cblocks;
+    const int H_eff = p.ups ? p.H_in * 2 : p.H_in;
+    const int W_eff = p.ups ? p.W_in * 2 : p.W_in;
+
+    auto issue = [&](int t, int stage) {
+        const int tap = t / cblocks, cb = t - tap * cblocks;
+        const int dw = tap % p.kw;
+        const int dh = (tap / p.kw) % p.kh;
+        const int dt = tap / (p.kw * p.kh);
+        char* sa = smem + stage * STAGE_BYTES + wave * 4096;
+        char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ti = vt[i] * p.st + dt - (p.kt - 1);
+            ti = ti < 0 ? 0 : ti;  // causal replicate padding
+            int hh = vh[i] * p.ss + dh - p.pad;
+            int ww = vw[i] * p.ss + dw - p.pad;
+            const bool ok = hh >= 0 && hh < H_eff && ww >= 0 && ww < W_eff;
+            if (p.ups) {
+                hh >>= 1;
+                ww >>= 1;
+            }
+            const unsigned short* src =
+                ok ? p.x + (((int64_t)ti * p.H_in + hh) * p.W_in + ww) * p.C_in + cb * BK + csw[i] : p.zeros + csw[i];
+            glds16(src, sa + i * 1024);
+            glds16(wsrc[i] + (int64_t)t * BK, sw + i * 1024);
+        }
+    };
+
+    issue(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+        const char* sa = smem + (t & 1) * STAGE_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ks * 2 + hi;
+            bf16x8 af[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + ((ch ^ a_sw[i]) << 4));
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + w_off[i] + ((ch ^ w_sw[i]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns voxel m, channels n0..n0+7
+    const int64_t frame = (int64_t)p.H_out * p.W_out;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = row0 + wm * 64 + i * 32 + l31;
+        if (m >= p.M) continue;
+        int64_t m_dst0 = m, m_dst1 = -1;
+        if (p.tdup) {
+            const int64_t to = m / frame, rem = m - to * frame;
+            if (to >= 1) {
+                m_dst0 = (2 * to - 1) * frame + rem;
+                m_dst1 = (2 * to) * frame + rem;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int n0 = col0 + wn * 64 + j * 32 + g * 16 + hi * 8;
+                if (n0 >= p.C_out) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += b0[e];
+                        v[4 + e] += b1[e];
+                    }
+                }
+                if (p.res) {
+                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + m * p.C_out + n0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(rr[e]);
+                }
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
+                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
+            }
+        }
+    }
+}
+
+// Explicit im2col for the few convolutions whose C_in is not a multiple of 64 (conv_in 3->128, decoder conv_in
+// 16->512, 1x1x1 quant convs): cols[m, tap*C_in + c], zero-padded to k_pad; the product is then ea_gemm_bf16.
+__global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ cols, int T_in,
+                                int H_in, int W_in, int C_in, int H_out, int W_out, int kt, int kh, int kw, int st,
+                                int ss, int pad, int k_pad, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % k_pad);
+    const int64_t m = idx / k_pad;
+    unsigned short v = 0;
+    if (k < kt * kh * kw * C_in) {
+        const int c = k % C_in, tap = k / C_in;
+        const int dw = tap % kw, dh = (tap / kw) % kh, dt = tap / (kw * kh);
+        const int wo = (int)(m % W_out);
+        const int64_t q = m / W_out;
+        const int ho = (int)(q % H_out), to = (int)(q / H_out);
+        int ti = to * st + dt - (kt - 1);
+        ti = ti < 0 ? 0 : ti;
+        const int hh = ho * ss + dh - pad, ww = wo * ss + dw - pad;
+        if (hh >= 0 && hh < H_in && ww >= 0 && ww < W_in) v = x[(((int64_t)ti * H_in + hh) * W_in + ww) * C_in + c];
+    }
+    cols[idx] = v;
+}
+
+}  // namespace
+
+static int conv_out_dim(int in, int k, int s, int pad_lo, int pad_hi) { return (in + pad_lo + pad_hi - k) / s + 1; }
+
+extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
+                                 const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
+                                 int kw, int st, int ss, int pad, int ups, int tdup, void* stream) {
+    EA_REQUIRE(x && w && y && zeros, "ea_conv3d_cl_bf16: null tensor");
+    EA_REQUIRE(C_in > 0 && C_in % BK == 0, "ea_conv3d_cl_bf16: C_in=%d must be a multiple of 64 (use ea_im2col3d_bf16 + ea_gemm_bf16)", C_in);
+    EA_REQUIRE(C_out > 0 && C_out % 8 == 0, "ea_conv3d_cl_bf16: C_out must be a multiple of 8");
+    EA_REQUIRE((kt == 3 && kh == 3 && kw == 3) || (kt == 1 && kh == 1 && kw == 1), "ea_conv3d_cl_bf16: kernel must be 3x3x3 or 1x1x1");
+    EA_REQUIRE((st == 1 || st == 2) && (ss == 1 || ss == 2) && (pad == 0 || pad == 1), "ea_conv3d_cl_bf16: bad stride/pad");
+    EA_REQUIRE(!(ups && ss != 1), "ea_conv3d_cl_bf16: upsample addressing needs spatial stride 1");
+    EA_REQUIRE(!(kh == 1 && pad != 0), "ea_conv3d_cl_bf16: 1x1x1 kernels take pad 0");
+    EA_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)res | (uintptr_t)bias | (uintptr_t)zeros) & 15) == 0,
+               "ea_conv3d_cl_bf16: pointers must be 16-byte aligned");
+    ConvArgs p;
+    p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y; p.zeros = zeros;
+    p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.C_in = C_in; p.C_out = C_out;
+    p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.ss = ss; p.pad = pad; p.ups = ups; p.tdup = tdup;
+    const int He = ups ? 2 * H_in : H_in, We = ups ? 2 * W_in : W_in;
+    // temporal: kt-1 replicated leading frames; spatial: `pad` zeros low, and for the strided (pad 0) convs one
+    // zero row/column high (downsamplers.py:44-46 F.pad(x,(0,1,0,1)))
+    p.T_out = conv_out_dim(T_in, kt, st, kt - 1, 0);
+    const int pad_hi = (kh == 1) ? 0 : (pad ? pad : 1);
+    p.H_out = conv_out_dim(He, kh, ss, pad, pad_hi);
+    p.W_out = conv_out_dim(We, kw, ss, pad, pad_hi);
+    p.M = (int64_t)p.T_out * p.H_out * p.W_out;
+    EA_REQUIRE(p.M > 0 && p.M < (1ll << 40), "ea_conv3d_cl_bf16: bad output size");
+    p.tiles_m = (int)((p.M + BM - 1) / BM);
+    p.tiles_n = (C_out + BN - 1) / BN;
+    const int64_t grid = (int64_t)8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    EA_REQUIRE(grid < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)grid), dim3(256), CONV_LDS, (hipStream_t)stream, p);
+    return ea_check_launch("ea_conv3d_cl_bf16");
+}
+
+extern "C" int ea_im2col3d_bf16(const ea_bf16* x, ea_bf16* cols, int T_in, int H_in, int W_in, int C_in, int kt, int kh,
+                                int kw, int st, int ss, int pad, int k_pad, void* stream) {
+    EA_REQUIRE(x && cols, "ea_im2col3d_bf16: null tensor");
+    EA_REQUIRE(k_pad >= kt * kh * kw * C_in && k_pad % 8 == 0, "ea_im2col3d_bf16: k_pad too small");
+    const int T_out = conv_out_dim(T_in, kt, st, kt - 1, 0);
+    const int pad_hi = (kh == 1) ? 0 : (pad ? pad : 1);
+    const int H_out = conv_out_dim(H_in, kh, ss, pad, pad_hi), W_out = conv_out_dim(W_in, kw, ss, pad, pad_hi);
+    const int64_t total = (int64_t)T_out * H_out * W_out * k_pad;
+    EA_REQUIRE(total > 0 && (total + 255) / 256 < (1ll << 31), "ea_im2col3d_bf16: bad size");
+    hipLaunchKernelGGL(im2col3d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, cols,
+                       T_in, H_in, W_in, C_in, H_out, W_out, kt, kh, kw, st, ss, pad, k_pad, total);
+    return ea_check_launch("ea_im2col3d_bf16");
+}

@@ -15,6 +15,7 @@ from . import _lib
 EPI_BIAS = 0
 EPI_BIAS_GELU_TANH = 1
 EPI_BIAS_GATE_RES = 2
+EPI_F32_OUT = 3
 
 _BF16 = torch.bfloat16
 _F32 = torch.float32
@@ -161,8 +162,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     N = W.shape[0]
     assert W.shape[1] == K and W.is_contiguous() and A.stride(2) == 1
     if out is None:
-        out = torch.empty((B, M, N), dtype=_BF16, device=A.device)
+        out = torch.empty((B, M, N), dtype=_F32 if epilogue == EPI_F32_OUT else _BF16, device=A.device)
     assert out.shape == (B, M, N) and out.stride(2) == 1
+    assert out.dtype == (_F32 if epilogue == EPI_F32_OUT else _BF16)
     if bias is not None:
         _chk(bias, _F32, "bias")
     ldres = rbs = gbs = 0
@@ -244,3 +246,108 @@ def cfg_euler_step(v: torch.Tensor, latents: torch.Tensor, guidance: float, dsig
     assert v.numel() == (2 * n if do_cfg else n)
     _lib.call("ea_cfg_euler_step", _p(v), _p(latents), n, float(guidance), float(dsigma), int(do_cfg),
               int(latents.dtype == _BF16), _stream())
+
+
+# ---------------------------------------------------------------------------------------------------
+# VAE ops: channels-last activations [T, H, W, C] bf16 (one sample)
+# ---------------------------------------------------------------------------------------------------
+_zero_pages = {}
+
+
+def _zeros_page(device) -> torch.Tensor:
+    z = _zero_pages.get(str(device))
+    if z is None:
+        z = torch.zeros(256, dtype=_BF16, device=device)
+        _zero_pages[str(device)] = z
+    return z
+
+
+def conv_out_shape(T, H, W, k: int, st: int, ss: int, pad: int, ups: bool = False):
+    He, We = (2 * H, 2 * W) if ups else (H, W)
+    To = (T + (k - 1) - k) // st + 1
+    pad_hi = 0 if k == 1 else (pad if pad else 1)
+    Ho = (He + pad + pad_hi - k) // ss + 1
+    Wo = (We + pad + pad_hi - k) // ss + 1
+    return To, Ho, Wo
+
+
+def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], k: int, st: int = 1, ss: int = 1,
+              pad: int = 1, ups: bool = False, tdup: bool = False, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 [T,H,W,Cin] (Cin % 64 == 0), w_packed bf16 [Cout, k^3*Cin] -> bf16 [T',H',W',Cout]."""
+    _dev(x, w_packed, bias, res)
+    _chk(x, _BF16, "x"); _chk(w_packed, _BF16, "w")
+    assert x.is_contiguous() and w_packed.is_contiguous() and x.dim() == 4
+    T, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    assert w_packed.shape[1] == k * k * k * Cin
+    To, Ho, Wo = conv_out_shape(T, H, W, k, st, ss, pad, ups)
+    Ty = 2 * To - 1 if (tdup and To > 1) else To
+    y = torch.empty((Ty, Ho, Wo, Cout), dtype=_BF16, device=x.device)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == (To, Ho, Wo, Cout) and res.dtype == _BF16
+    _timed("conv3d", lambda: _lib.call("ea_conv3d_cl_bf16", _p(x), _p(w_packed), _p(bias), _p(res), _p(y),
+                                       _p(_zeros_page(x.device)), T, H, W, Cin, Cout, k, k, k, st, ss, pad, int(ups),
+                                       int(tdup and To > 1), _stream()))
+    return y
+
+
+def im2col3d(x: torch.Tensor, k: int, st: int, ss: int, pad: int, k_pad: int):
+    """x bf16 [T,H,W,Cin] -> (cols bf16 [M, k_pad], (T',H',W'))."""
+    _dev(x)
+    _chk(x, _BF16, "x")
+    assert x.is_contiguous()
+    T, H, W, Cin = x.shape
+    To, Ho, Wo = conv_out_shape(T, H, W, k, st, ss, pad)
+    cols = torch.empty((To * Ho * Wo, k_pad), dtype=_BF16, device=x.device)
+    _lib.call("ea_im2col3d_bf16", _p(x), _p(cols), T, H, W, Cin, k, k, k, st, ss, pad, k_pad, _stream())
+    return cols, (To, Ho, Wo)
+
+
+def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                   act: bool = True) -> torch.Tensor:
+    """Per-frame GroupNorm (+SiLU) of x bf16 [T, H, W, C] (or [T, HW, C])."""
+    _dev(x, gamma, beta)
+    _chk(x, _BF16, "x"); _chk(gamma, _F32, "gamma"); _chk(beta, _F32, "beta")
+    assert x.is_contiguous()
+    T, C = x.shape[0], x.shape[-1]
+    hw = x.numel() // (T * C)
+    nblk = max(1, min(256, hw // 2048))
+    partial = torch.empty((T, nblk, C // 4, 2), dtype=_F32, device=x.device)
+    stats = torch.empty((T, groups, 2), dtype=_F32, device=x.device)
+    _lib.call("ea_groupnorm_stats_bf16", _p(x), _p(partial), _p(stats), T, hw, C, groups, nblk, float(eps), _stream())
+    y = torch.empty_like(x)
+    _lib.call("ea_groupnorm_apply_bf16", _p(x), _p(y), _p(stats), _p(gamma), _p(beta), T, hw, C, groups, int(act), _stream())
+    return y
+
+
+def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(x * scale) per row; x bf16 or fp32 [rows, cols] -> bf16."""
+    _dev(x, out)
+    assert x.is_contiguous() and x.dim() == 2 and x.dtype in (_BF16, _F32)
+    if out is None:
+        out = torch.empty(x.shape, dtype=_BF16, device=x.device)
+    name = "ea_softmax_rows_f32in" if x.dtype == _F32 else "ea_softmax_rows_bf16"
+    _lib.call(name, _p(x), _p(out), x.shape[0], x.shape[1], float(scale), _stream())
+    return out
+
+
+def ncdhw_to_ndhwc(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
+    """x [C,T,H,W] fp32/bf16 -> bf16 [T,H,W,c_pad]."""
+    _dev(x)
+    assert x.is_contiguous() and x.dim() == 4 and x.dtype in (_BF16, _F32)
+    C, T, H, W = x.shape
+    cp = c_pad or C
+    y = torch.empty((T, H, W, cp), dtype=_BF16, device=x.device)
+    _lib.call("ea_ncdhw_to_ndhwc", _p(x), _p(y), C, cp, T * H * W, int(x.dtype == _BF16), _stream())
+    return y
+
+
+def ndhwc_to_ncdhw(x: torch.Tensor, channels: int, out_dtype, post: int = 0) -> torch.Tensor:
+    """x bf16 [T,H,W,Cs] -> [channels,T,H,W] in out_dtype (first `channels` channels)."""
+    _dev(x)
+    _chk(x, _BF16, "x")
+    assert x.is_contiguous() and x.dim() == 4
+    T, H, W, Cs = x.shape
+    y = torch.empty((channels, T, H, W), dtype=out_dtype, device=x.device)
+    _lib.call("ea_ndhwc_to_ncdhw", _p(x), _p(y), channels, Cs, T * H * W, int(out_dtype == _BF16), post, _stream())
+    return y

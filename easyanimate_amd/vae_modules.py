@@ -1,0 +1,360 @@
+"""Leaf modules of the MAGVIT causal 3-D VAE -- same class names, constructor arguments and parameter names as
+/root/reference/easyanimate/vae/ldm/modules/vaemodules/{common,down_blocks,up_blocks,mid_blocks,downsamplers,
+upsamplers,attention}.py (the classes the V5/V5.1 config instantiates).
+
+Internal activation layout is channels-last, one sample: bf16 [T, H, W, C].  The whole clip is processed at once
+with causal (replicated-first-frame) temporal addressing inside the convolution kernel; under the V5 settings
+(per-frame GroupNorm, nearest temporal up-sampling) this equals the reference's chunked/cached evaluation
+(padding_flag 3/4, common.py:97-141) -- SURVEY.md 8c property 1 -- and with 288 GB of HBM no chunking is needed.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._params import derived, f32
+
+
+def _pack_conv_weight(w: torch.Tensor, k_pad: Optional[int] = None, n_pad: Optional[int] = None) -> torch.Tensor:
+    """[Cout, Cin, kt, kh, kw] -> bf16 [Cout(_pad), kt*kh*kw*Cin (_pad)], tap-major / channel-minor."""
+    co = w.shape[0]
+    p = w.permute(0, 2, 3, 4, 1).reshape(co, -1).to(torch.bfloat16)
+    if k_pad is not None and k_pad != p.shape[1]:
+        p = torch.nn.functional.pad(p, (0, k_pad - p.shape[1]))
+    if n_pad is not None and n_pad != co:
+        p = torch.nn.functional.pad(p, (0, 0, 0, n_pad - co))
+    return p.contiguous()
+
+
+def _pad_bias(b: Optional[torch.Tensor], n_pad: int) -> Optional[torch.Tensor]:
+    if b is None:
+        return None
+    b = b.float()
+    if b.shape[0] != n_pad:
+        b = torch.nn.functional.pad(b, (0, n_pad - b.shape[0]))
+    return b.contiguous()
+
+
+def conv_cl(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None, ups: bool = False,
+            tdup: bool = False) -> torch.Tensor:
+    """Apply a (Causal)Conv3d module's parameters to a channels-last clip x [T,H,W,Cin] -> [T',H',W',Cout_pad8]."""
+    co, ci, kt, kh, kw = conv.weight.shape
+    assert kt == kh == kw and kt in (1, 3)
+    st, sh, sw = conv.stride
+    assert sh == sw
+    pad = conv.padding[1] if kt == 3 else 0
+    n_pad = ops.round_up(co, 8)
+    if x.shape[-1] != ci:
+        raise ValueError(f"conv expects {ci} input channels, got {x.shape[-1]}")
+    if ci % 64 == 0:
+        w = derived(conv.weight, f"cl{n_pad}", lambda t: _pack_conv_weight(t, None, n_pad))
+        b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None
+        return ops.conv3d_cl(x, w, b, kt, st, sh, pad, ups=ups, tdup=tdup, res=res)
+    # small C_in: explicit im2col + GEMM
+    assert res is None and not ups and not tdup
+    k = kt * kh * kw * ci
+    k_pad = ops.round_up(k, 64)
+    w = derived(conv.weight, f"cl{n_pad}k{k_pad}", lambda t: _pack_conv_weight(t, k_pad, n_pad))
+    b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None
+    cols, (To, Ho, Wo) = ops.im2col3d(x, kt, st, sh, pad, k_pad)
+    y = ops.gemm(cols, w, b, ops.EPI_BIAS)
+    return y.view(To, Ho, Wo, n_pad)
+
+
+class CausalConv3d(nn.Conv3d):
+    """reference: vaemodules/common.py:31-179.  Parameters as nn.Conv3d ([Cout,Cin,kt,kh,kw]); temporal padding is
+    causal (kt-1 replicated leading frames), spatial padding `padding` (0 for the strided down-samplers)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size=3, stride=1, padding=1, dilation=1, **kwargs):
+        kernel_size = kernel_size if isinstance(kernel_size, tuple) else (kernel_size,) * 3
+        stride = stride if isinstance(stride, tuple) else (stride,) * 3
+        dilation = dilation if isinstance(dilation, tuple) else (dilation,) * 3
+        if dilation != (1, 1, 1):
+            raise NotImplementedError("dilation != 1")
+        if not isinstance(padding, int):
+            raise NotImplementedError("padding must be an int (V5 configs use 0 or 1)")
+        self.t_stride = stride[0]
+        self.temporal_padding = kernel_size[0] - 1
+        self.padding_flag = 0
+        self.prev_features = None
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation,
+                         padding=(0, padding, padding), **kwargs)
+
+    def _clear_conv_cache(self):
+        self.prev_features = None
+
+    def forward(self, x: torch.Tensor, res: Optional[torch.Tensor] = None, ups: bool = False, tdup: bool = False):
+        return conv_cl(self, x, res=res, ups=ups, tdup=tdup)
+
+
+def _gn(norm: nn.GroupNorm, x: torch.Tensor, act: bool) -> torch.Tensor:
+    return ops.groupnorm_silu(x, f32(norm.weight), f32(norm.bias), norm.num_groups, norm.eps, act=act)
+
+
+class ResidualBlock3D(nn.Module):
+    """reference: vaemodules/common.py:254-323 (per-frame GroupNorm, i.e. set_3dgroupnorm / spatial_group_norm)."""
+
+    def __init__(self, in_channels: int, out_channels: int, non_linearity: str = "silu", norm_num_groups: int = 32,
+                 norm_eps: float = 1e-6, dropout: float = 0.0, output_scale_factor: float = 1.0):
+        super().__init__()
+        if non_linearity not in ("silu", "swish") or output_scale_factor != 1.0:
+            raise NotImplementedError("only SiLU / output_scale_factor 1 (V5 config)")
+        self.output_scale_factor = output_scale_factor
+        self.norm1 = nn.GroupNorm(num_groups=norm_num_groups, num_channels=in_channels, eps=norm_eps, affine=True)
+        self.conv1 = CausalConv3d(in_channels, out_channels, kernel_size=3)
+        self.norm2 = nn.GroupNorm(num_groups=norm_num_groups, num_channels=out_channels, eps=norm_eps, affine=True)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = CausalConv3d(out_channels, out_channels, kernel_size=3)
+        if in_channels != out_channels:
+            self.shortcut = nn.Conv3d(in_channels, out_channels, kernel_size=1)
+        else:
+            self.shortcut = nn.Identity()
+        self.set_3dgroupnorm = True
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        shortcut = x if isinstance(self.shortcut, nn.Identity) else conv_cl(self.shortcut, x)
+        h = _gn(self.norm1, x, act=True)
+        h = self.conv1(h)
+        h = _gn(self.norm2, h, act=True)
+        return self.conv2(h, res=shortcut)  # (x + shortcut) / 1.0 fused in the conv epilogue
+
+
+# ---- samplers -------------------------------------------------------------------------------------
+class SpatialDownsampler3D(nn.Module):
+    """downsamplers.py:24-47: F.pad(x,(0,1,0,1)) + CausalConv3d(k3, stride (1,2,2), padding 0)."""
+
+    def __init__(self, in_channels: int, out_channels):
+        super().__init__()
+        self.conv = CausalConv3d(in_channels, out_channels or in_channels, kernel_size=3, stride=(1, 2, 2), padding=0)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class SpatialTemporalDownsampler3D(nn.Module):
+    """downsamplers.py:72-94: stride (2,2,2)."""
+
+    def __init__(self, in_channels: int, out_channels):
+        super().__init__()
+        self.conv = CausalConv3d(in_channels, out_channels or in_channels, kernel_size=3, stride=(2, 2, 2), padding=0)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class SpatialUpsampler3D(nn.Module):
+    """upsamplers.py:21-37: nearest x2 (H,W) then conv -- the up-sampling is folded into the conv's addressing."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = CausalConv3d(in_channels, out_channels or in_channels, kernel_size=3)
+
+    def forward(self, x):
+        return self.conv(x, ups=True)
+
+
+class SpatialTemporalUpsampler3D(nn.Module):
+    """upsamplers.py:123-153: nearest x2 (H,W), conv, then temporal nearest x2 of every frame but the first
+    (set_3dgroupnorm => mode "nearest"); the duplication is a second store in the conv epilogue."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = CausalConv3d(in_channels, out_channels or in_channels, kernel_size=3)
+        self.padding_flag = 0
+        self.set_3dgroupnorm = True
+
+    def forward(self, x):
+        return self.conv(x, ups=True, tdup=True)
+
+
+# ---- blocks ----------------------------------------------------------------------------------------
+def _res_stack(in_channels, out_channels, num_layers, norm_num_groups, norm_eps, dropout):
+    return nn.ModuleList([ResidualBlock3D(in_channels if i == 0 else out_channels, out_channels,
+                                          norm_num_groups=norm_num_groups, norm_eps=norm_eps, dropout=dropout)
+                          for i in range(num_layers)])
+
+
+class SpatialDownBlock3D(nn.Module):
+    """down_blocks.py:156-211"""
+
+    def __init__(self, in_channels, out_channels, num_layers=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-6,
+                 dropout=0.0, output_scale_factor=1.0, add_gc_block=False, add_downsample=True):
+        super().__init__()
+        if add_gc_block:
+            raise NotImplementedError("GlobalContextBlock is unused by the V5 config")
+        self.convs = _res_stack(in_channels, out_channels, num_layers, norm_num_groups, norm_eps, dropout)
+        self.gc_block = None
+        self.downsampler = SpatialDownsampler3D(out_channels, out_channels) if add_downsample else None
+        self.spatial_downsample_factor = 2 if add_downsample else 1
+        self.temporal_downsample_factor = 1
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        return self.downsampler(x) if self.downsampler is not None else x
+
+
+class SpatialTemporalDownBlock3D(nn.Module):
+    """down_blocks.py:272-327"""
+
+    def __init__(self, in_channels, out_channels, num_layers=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-6,
+                 dropout=0.0, output_scale_factor=1.0, add_gc_block=False, add_downsample=True):
+        super().__init__()
+        if add_gc_block:
+            raise NotImplementedError("GlobalContextBlock is unused by the V5 config")
+        self.convs = _res_stack(in_channels, out_channels, num_layers, norm_num_groups, norm_eps, dropout)
+        self.gc_block = None
+        self.downsampler = SpatialTemporalDownsampler3D(out_channels, out_channels) if add_downsample else None
+        self.spatial_downsample_factor = 2 if add_downsample else 1
+        self.temporal_downsample_factor = 2 if add_downsample else 1
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        return self.downsampler(x) if self.downsampler is not None else x
+
+
+class SpatialUpBlock3D(nn.Module):
+    """up_blocks.py:96-147"""
+
+    def __init__(self, in_channels, out_channels, num_layers=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-6,
+                 dropout=0.0, output_scale_factor=1.0, add_gc_block=False, add_upsample=True):
+        super().__init__()
+        if add_gc_block:
+            raise NotImplementedError("GlobalContextBlock is unused by the V5 config")
+        self.upsampler = SpatialUpsampler3D(in_channels, in_channels) if add_upsample else None
+        self.gc_block = None
+        self.convs = _res_stack(in_channels, out_channels, num_layers, norm_num_groups, norm_eps, dropout)
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        return self.upsampler(x) if self.upsampler is not None else x
+
+
+class SpatialTemporalUpBlock3D(nn.Module):
+    """up_blocks.py:344-395"""
+
+    def __init__(self, in_channels, out_channels, num_layers=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-6,
+                 dropout=0.0, output_scale_factor=1.0, add_gc_block=False, add_upsample=True):
+        super().__init__()
+        if add_gc_block:
+            raise NotImplementedError("GlobalContextBlock is unused by the V5 config")
+        self.convs = _res_stack(in_channels, out_channels, num_layers, norm_num_groups, norm_eps, dropout)
+        self.gc_block = None
+        self.upsampler = SpatialTemporalUpsampler3D(out_channels, out_channels) if add_upsample else None
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        return self.upsampler(x) if self.upsampler is not None else x
+
+
+_DOWN = {"SpatialDownBlock3D": SpatialDownBlock3D, "SpatialTemporalDownBlock3D": SpatialTemporalDownBlock3D}
+_UP = {"SpatialUpBlock3D": SpatialUpBlock3D, "SpatialTemporalUpBlock3D": SpatialTemporalUpBlock3D}
+
+
+def get_down_block(down_block_type, **kw):
+    if down_block_type not in _DOWN:
+        raise NotImplementedError(f"{down_block_type}: only the V5 block types {sorted(_DOWN)} are built")
+    kw.pop("num_attention_heads", None)
+    return _DOWN[down_block_type](**kw)
+
+
+def get_up_block(up_block_type, **kw):
+    if up_block_type not in _UP:
+        raise NotImplementedError(f"{up_block_type}: only the V5 block types {sorted(_UP)} are built")
+    kw.pop("num_attention_heads", None)
+    return _UP[up_block_type](**kw)
+
+
+# ---- mid block ---------------------------------------------------------------------------------------
+class SpatialAttention(nn.Module):
+    """Single-head per-frame attention of the mid block (vaemodules/attention.py:12-423 `Attention` with
+    residual_connection=True + attention_processors.py:76-139).  Keys: group_norm, to_q, to_k, to_v, to_out.
+    head_dim = C (512): logits = Q K^T via MFMA GEMM into fp32, row softmax, P V via GEMM."""
+
+    def __init__(self, query_dim: int, nheads: int = 1, head_dim: int = 64, bias: bool = True, upcast_softmax: bool = True,
+                 norm_num_groups: int = 32, eps: float = 1e-6, rescale_output_factor: float = 1.0,
+                 residual_connection: bool = True, **unused):
+        super().__init__()
+        if nheads != 1 or rescale_output_factor != 1.0 or not residual_connection:
+            raise NotImplementedError("only the V5 mid-block configuration (1 head, residual, no rescale)")
+        self.inner_dim = head_dim * nheads
+        self.nheads = nheads
+        self.scale = head_dim ** -0.5
+        self.group_norm = nn.GroupNorm(num_channels=query_dim, num_groups=norm_num_groups, eps=eps, affine=True)
+        self.to_q = nn.Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_k = nn.Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_v = nn.Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_out = nn.Linear(self.inner_dim, query_dim, bias=True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from ._params import bf16_weight
+        T, H, W, C = x.shape
+        n = H * W
+        xr = x.view(T, n, C)
+        xn = _gn(self.group_norm, xr, act=False)
+        q = ops.gemm(xn, bf16_weight(self.to_q.weight), f32(self.to_q.bias), ops.EPI_BIAS)
+        k = ops.gemm(xn, bf16_weight(self.to_k.weight), f32(self.to_k.bias), ops.EPI_BIAS)
+        wv = bf16_weight(self.to_v.weight)
+        # softmax rows sum to 1, so the value bias passes straight through attention: fold it into the out bias
+        wo = bf16_weight(self.to_out.weight)
+        b_eff = f32(self.to_out.bias)
+        if self.to_v.bias is not None:  # b_eff = W_o b_v + b_o  (GEMV kernel)
+            b_eff = ops.linear_small_m(f32(self.to_v.bias).view(1, -1), wo, b_eff).view(-1)
+        ones = derived(self.to_out.bias, "ones", lambda t: torch.ones(1, t.shape[0], dtype=torch.float32, device=t.device))
+        out = torch.empty_like(xr)
+        logits = torch.empty((n, n), dtype=torch.float32, device=x.device)
+        for f in range(T):  # one frame at a time: [n, n] fp32 logits (1 GiB at 1024^2) stay a reusable buffer
+            vt = ops.gemm(wv, xn[f], None, ops.EPI_BIAS)                      # V^T [C, n]
+            ops.gemm(q[f], k[f], None, ops.EPI_F32_OUT, out=logits)           # Q K^T
+            p = ops.softmax_rows(logits, self.scale)
+            o = ops.gemm(p, vt, None, ops.EPI_BIAS)                            # P V  [n, C]
+            ops.gemm(o, wo, b_eff, ops.EPI_BIAS_GATE_RES, out=out[f], res=xr[f], gate=ones)
+        return out.view(T, H, W, C)
+
+
+class MidBlock3D(nn.Module):
+    """mid_blocks.py:38-196 with attention_type="spatial": convs[0], then (attention, conv) pairs."""
+
+    def __init__(self, in_channels: int, num_layers: int = 1, act_fn: str = "silu", norm_num_groups: int = 32,
+                 norm_eps: float = 1e-6, dropout: float = 0.0, add_attention: bool = True, attention_type: str = "3d",
+                 attention_head_dim: int = 1, output_scale_factor: float = 1.0):
+        super().__init__()
+        if add_attention and attention_type != "spatial":
+            raise NotImplementedError("only mid_block_attention_type='spatial' (V5 config)")
+        self.attention_type = attention_type
+        self.convs = nn.ModuleList([ResidualBlock3D(in_channels, in_channels, norm_num_groups=norm_num_groups,
+                                                    norm_eps=norm_eps, dropout=dropout)])
+        self.attentions = nn.ModuleList([])
+        for _ in range(num_layers - 1):
+            if add_attention:
+                self.attentions.append(SpatialAttention(in_channels, nheads=in_channels // attention_head_dim,
+                                                        head_dim=attention_head_dim, bias=True, upcast_softmax=True,
+                                                        norm_num_groups=norm_num_groups, eps=norm_eps,
+                                                        rescale_output_factor=output_scale_factor, residual_connection=True))
+            else:
+                self.attentions.append(None)
+            self.convs.append(ResidualBlock3D(in_channels, in_channels, norm_num_groups=norm_num_groups,
+                                              norm_eps=norm_eps, dropout=dropout))
+
+    def forward(self, x):
+        x = self.convs[0](x)
+        for attn, resnet in zip(self.attentions, self.convs[1:]):
+            if attn is not None:
+                x = attn(x)
+            x = resnet(x)
+        return x
+
+
+def get_mid_block(mid_block_type, in_channels, num_layers, act_fn, norm_num_groups=32, norm_eps=1e-6, dropout=0.0,
+                  add_attention=True, attention_type="3d", num_attention_heads=1, output_scale_factor=1.0):
+    if mid_block_type != "MidBlock3D":
+        raise ValueError(f"Unknown mid block type: {mid_block_type}")
+    return MidBlock3D(in_channels=in_channels, num_layers=num_layers, act_fn=act_fn, norm_num_groups=norm_num_groups,
+                      norm_eps=norm_eps, dropout=dropout, add_attention=add_attention, attention_type=attention_type,
+                      attention_head_dim=in_channels // num_attention_heads, output_scale_factor=output_scale_factor)

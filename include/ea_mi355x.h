@@ -36,6 +36,7 @@ typedef uint16_t ea_bf16;
 #define EA_EPI_BIAS 0           /* C = A.W^T + bias                                              */
 #define EA_EPI_BIAS_GELU_TANH 1 /* C = gelu_tanh(A.W^T + bias)       (diffusers FeedForward.net.0) */
 #define EA_EPI_BIAS_GATE_RES 2  /* C = res + gate[b,:] * (A.W^T + bias)  (attention.py:1140,1161)  */
+#define EA_EPI_F32_OUT 3        /* C (fp32, ldc/c_batch_stride in floats) = A.W^T + bias: attention logits */
 
 const char* ea_last_error_string(void);
 int ea_version(void);
@@ -134,6 +135,58 @@ int ea_unpatchify(const ea_bf16* tokens, void* out, int batch, int channels, int
  * v: [2, n] (uncond, text) when do_cfg else [1, n]; model-dtype in/out selected by is_bf16. */
 int ea_cfg_euler_step(const void* v, void* latents, int64_t n, float guidance, float dsigma, int do_cfg,
                       int is_bf16, void* stream);
+
+/* ---- VAE (AutoencoderKLMagvit), channels-last (NDHWC) activations of ONE sample -------------------- */
+
+/* Causal 3-D convolution as an im2col-free implicit GEMM (vaemodules/common.py:84-179 CausalConv3d; the
+ * strided down-samplers downsamplers.py:24-94; the up-samplers upsamplers.py:21-37,123-153; the residual add of
+ * ResidualBlock3D common.py:322).
+ *   x : bf16 [T_in, H_in, W_in, C_in]      C_in % 64 == 0
+ *   w : bf16 [C_out, kt*kh*kw*C_in]        (the [C_out,C_in,kt,kh,kw] parameter permuted to tap-major)
+ *   y : bf16 [T_out, H_out, W_out, C_out]  C_out % 8 == 0
+ * Temporal padding = kt-1 replicated leading frames (identical to the reference's chunk caches, SURVEY 8c
+ * property 1); spatial padding `pad` zeros on the low side and, for the pad-0 strided convs, one zero
+ * row/column on the high side (F.pad(x,(0,1,0,1))).  st / ss = temporal / spatial stride in {1,2}.
+ * ups = 1: the input is read through a nearest x2 spatial up-sampling (never materialised).
+ * tdup = 1: output frame t >= 1 is written to frames 2t-1 and 2t of y (y then has 2*T_out-1 frames): the
+ *           temporal nearest x2 of SpatialTemporalUpsampler3D under spatial_group_norm.
+ * res (optional, same shape as the un-duplicated output): y = conv + bias + res.
+ * zeros: any device buffer holding >= 128 zero bytes (source of the spatial zero padding). */
+int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
+                      const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
+                      int kw, int st, int ss, int pad, int ups, int tdup, void* stream);
+
+/* Explicit im2col for the few convolutions with C_in % 64 != 0 (conv_in 3->128, decoder conv_in 16->512, the
+ * 1x1x1 quant convs autoencoder_magvit.py:181-182): cols bf16 [T_out*H_out*W_out, k_pad],
+ * cols[m, tap*C_in + c], zero padded; the product is ea_gemm_bf16. */
+int ea_im2col3d_bf16(const ea_bf16* x, ea_bf16* cols, int T_in, int H_in, int W_in, int C_in, int kt, int kh,
+                     int kw, int st, int ss, int pad, int k_pad, void* stream);
+
+/* Per-frame GroupNorm statistics (common.py:301-305 under spatial_group_norm; omnigen_enc_dec.py:258-262):
+ * x bf16 [T, hw, C] -> stats fp32 [T, groups, 2] = (mean, rstd).  Deterministic two-level reduction:
+ * partial is an fp32 workspace of T*nblk*(C/4)*2 floats.  (C/groups) % 4 == 0. */
+int ea_groupnorm_stats_bf16(const ea_bf16* x, float* partial, float* stats, int T, int64_t hw, int C, int groups,
+                            int nblk, float eps, void* stream);
+
+/* y = act((x - mean) * rstd * gamma + beta); act: 0 none, 1 SiLU (common.py:306,318). */
+int ea_groupnorm_apply_bf16(const ea_bf16* x, ea_bf16* y, const float* stats, const float* gamma,
+                            const float* beta, int T, int64_t hw, int C, int groups, int act, void* stream);
+
+/* y = softmax(x * scale) along rows; bf16 [rows, cols], cols % 8 == 0, cols <= 32768.  Used with two
+ * ea_gemm_bf16 calls for the single-head (head_dim 512) spatial attention of the VAE mid block
+ * (vaemodules/attention.py:391-423, attention_processors.py:76-139). */
+int ea_softmax_rows_bf16(const ea_bf16* x, ea_bf16* y, int64_t rows, int cols, float scale, void* stream);
+/* same with fp32 logits in (written by ea_gemm_bf16 with EA_EPI_F32_OUT), bf16 probabilities out */
+int ea_softmax_rows_f32in(const float* x, ea_bf16* y, int64_t rows, int cols, float scale, void* stream);
+
+/* Layout changes between the reference's NCDHW tensors and the kernels' NDHWC (one sample).
+ * to NDHWC: src [C, voxels] fp32/bf16 -> dst bf16 [voxels, C_pad] (extra channels zero).
+ * to NCDHW: src bf16 [voxels, C_src] -> dst [C, voxels] fp32/bf16 (first C channels); post = 1 applies
+ * clamp(-1,1) -> x/2+0.5 -> clamp(0,1) (pipeline_easyanimate.py:731,739). */
+int ea_ncdhw_to_ndhwc(const void* src, ea_bf16* dst, int C, int C_pad, int64_t voxels, int src_is_bf16,
+                      void* stream);
+int ea_ndhwc_to_ncdhw(const ea_bf16* src, void* dst, int C, int C_src, int64_t voxels, int dst_is_bf16, int post,
+                      void* stream);
 
 #ifdef __cplusplus
 }

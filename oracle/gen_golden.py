@@ -24,6 +24,14 @@ TINY = dict(num_attention_heads=2, attention_head_dim=64, in_channels=16, out_ch
             norm_eps=1e-5, time_position_encoding_type="3d_rope", enable_text_attention_mask=True)
 
 
+TINY_VAE = dict(in_channels=3, out_channels=3, block_out_channels=[64, 64, 128, 128],
+                down_block_types=("SpatialDownBlock3D", "SpatialTemporalDownBlock3D", "SpatialTemporalDownBlock3D", "SpatialTemporalDownBlock3D"),
+                up_block_types=("SpatialUpBlock3D", "SpatialTemporalUpBlock3D", "SpatialTemporalUpBlock3D", "SpatialTemporalUpBlock3D"),
+                mid_block_attention_type="spatial", latent_channels=16, norm_num_groups=16, spatial_group_norm=True,
+                cache_mag_vae=True, slice_mag_vae=False, cache_compression_vae=False, slice_compression_vae=False,
+                mini_batch_encoder=4, mini_batch_decoder=1, layers_per_block=2)
+
+
 def _load_sd(module, seed, style):
     shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
     sd = synth_state_dict(shapes, seed, style)
@@ -124,6 +132,21 @@ def main():
         torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=latents, enc=enc, cos=cos, sin=sin,
                         guidance=6.0, steps=2, trace=traces[torch.float32], trace_bf16=traces[torch.bfloat16]),
                    os.path.join(OUT, f"{name}.pt"))
+    # ---- tiny MAGVIT VAE in the reference's real (chunked, cached) inference mode: encode + decode
+    vkw = dict(TINY_VAE)
+    vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()
+    shapes = _load_sd(vae, 2, "default")
+    g = _g(9)
+    video = torch.rand(1, 3, 9, 64, 64, generator=g) * 2 - 1
+    zlat = torch.randn(1, 16, 3, 8, 8, generator=g)
+    moments = vae.encode(video)[0].parameters
+    dec = vae.decode(zlat)[0]
+    vb = vae.to(torch.bfloat16)
+    moments_b = vb.encode(video.bfloat16())[0].parameters.float()
+    dec_b = vb.decode(zlat.bfloat16())[0].float()
+    torch.save(dict(cfg=vkw, shapes=shapes, seed=2, style="default", video=video, z=zlat, moments=moments, dec=dec,
+                    moments_bf16=moments_b, dec_bf16=dec_b), os.path.join(OUT, "vae_tiny.pt"))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

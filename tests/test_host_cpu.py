@@ -88,3 +88,25 @@ def test_synthetic_weights_are_order_independent():
     s2 = synth_state_dict(dict(reversed(list(shapes.items()))), 1)
     assert all(torch.equal(s1[k], s2[k]) for k in shapes)
     assert abs(s1["x.norm.weight"].mean().item() - 1) < 0.1
+
+
+def test_vae_state_dict_keys_and_config_surface():
+    from easyanimate_amd import AutoencoderKLMagvit, name_to_autoencoder_magvit
+    g = _load("vae_tiny.pt")
+    v = name_to_autoencoder_magvit["AutoencoderKLMagvit"].from_config(g["cfg"])
+    assert isinstance(v, AutoencoderKLMagvit)
+    assert {k: tuple(t.shape) for k, t in v.state_dict().items()} == g["shapes"]
+    assert v.config.scaling_factor == 0.1825 and v.config.latent_channels == 16 and list(v.config.block_out_channels) == [64, 64, 128, 128]
+    assert v.quant_conv.weight.ndim == 5 and v.cache_mag_vae and v.mini_batch_encoder == 4 and v.mini_batch_decoder == 1
+    with pytest.raises(NotImplementedError):
+        AutoencoderKLMagvit.from_config(dict(g["cfg"], spatial_group_norm=False))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        v.decode(torch.zeros(1, 16, 1, 8, 8))
+
+
+def test_pipeline_latent_shapes():
+    from easyanimate_amd.pipeline import EasyAnimatePipeline
+    p = EasyAnimatePipeline(vae=None, transformer=None, scheduler=None)
+    assert p.latent_shape(1, 16, 49, 1024, 1024) == (1, 16, 13, 128, 128)
+    assert p.latent_shape(1, 16, 1, 256, 256) == (1, 16, 1, 32, 32)
+    assert p.latent_shape(1, 16, 25, 384, 672) == (1, 16, 7, 48, 84)

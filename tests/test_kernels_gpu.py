@@ -102,6 +102,8 @@ GEMM_SHAPES = [
     (1, 512, 3072, 12288),
     (2, 64, 64, 3584),      # narrow N (proj_out-like), K = 56*64
     (1, 5, 8, 64),
+    (1, 8300, 320, 128),    # tiles_m >= 64: per-XCD row bands with a short last band
+    (2, 8192, 256, 64),
 ]
 
 

@@ -105,3 +105,28 @@ def test_restatement_vs_live_reference_block():
     h2, e2 = R.dit_block(sd, "", h, e, temb, rope, 2, 1e-6)
     _close(h2, ho, 2e-6, "live block hidden")
     _close(e2, eo, 2e-6, "live block encoder")
+
+
+def test_restatement_vae_vs_golden_chunked_reference():
+    """The monolithic causal restatement equals the reference run in its real chunked/cached mode (flags 3/4)."""
+    from oracle import restatement_vae as RV
+    g = _load("vae_tiny.pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    with torch.no_grad():
+        m = RV.vae_encode_moments(sd, g["video"], g["cfg"]["norm_num_groups"])
+        d = RV.vae_decode(sd, g["z"], g["cfg"]["norm_num_groups"])
+    assert m.shape == g["moments"].shape == (1, 32, 3, 8, 8) and d.shape == g["dec"].shape == (1, 3, 9, 64, 64)
+    _close(m, g["moments"], 1e-5, "vae moments")
+    _close(d, g["dec"], 1e-5, "vae decode")
+
+
+def test_vae_frame_bookkeeping():
+    """1 -> 1 -> 1 ; 9 -> 3 -> 9 ; 13 -> 4 -> 13 frames (SURVEY 8c property 2), on the restatement."""
+    from oracle import restatement_vae as RV
+    g = _load("vae_tiny.pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    for f, fl in ((1, 1), (5, 2), (13, 4)):
+        with torch.no_grad():
+            m = RV.vae_encode_moments(sd, torch.zeros(1, 3, f, 32, 32), 16)
+            d = RV.vae_decode(sd, torch.zeros(1, 16, fl, 4, 4), 16)
+        assert m.shape == (1, 32, fl, 4, 4) and d.shape == (1, 3, f, 32, 32)

@@ -1,0 +1,196 @@
+"""GPU parity of the VAE kernels (vs plain PyTorch on the same bf16-rounded inputs) and of the product
+AutoencoderKLMagvit (vs golden vectors from the reference's chunked mode and the oracle restatement)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rep(name, got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    err = (got - ref).abs().max().item()
+    rel = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    print(f"[parity] {name}: max_abs={err:.3e} rel_l2={rel:.3e} ref_absmax={ref.abs().max().item():.3e}")
+    return err, rel
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+CONV_CASES = [
+    # T, H, W, Cin, Cout, k, st, ss, pad, ups, tdup, res
+    (3, 10, 12, 64, 64, 3, 1, 1, 1, False, False, False),
+    (4, 9, 7, 128, 72, 3, 1, 1, 1, False, False, True),    # ragged M / N tails + residual
+    (5, 16, 12, 64, 128, 3, 1, 2, 0, False, False, False),  # SpatialDownsampler3D
+    (5, 16, 12, 64, 64, 3, 2, 2, 0, False, False, False),   # SpatialTemporalDownsampler3D
+    (9, 8, 8, 128, 64, 3, 2, 2, 0, False, False, False),
+    (3, 6, 5, 64, 64, 3, 1, 1, 1, True, False, False),     # SpatialUpsampler3D (nearest x2 folded)
+    (3, 6, 5, 64, 64, 3, 1, 1, 1, True, True, False),      # SpatialTemporalUpsampler3D (temporal dup)
+    (1, 6, 6, 64, 64, 3, 1, 1, 1, True, True, False),      # single frame: no temporal dup
+    (4, 5, 6, 128, 256, 1, 1, 1, 0, False, False, False),  # 1x1x1 shortcut
+    (2, 40, 40, 256, 256, 3, 1, 1, 1, False, False, True),
+]
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,k,st,ss,pad,ups,tdup,res", CONV_CASES)
+def test_conv3d_cl(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res):
+    from easyanimate_amd import ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(1, Ci, T, H, W, generator=g))
+    w = _bf(torch.randn(Co, Ci, k, k, k, generator=g) / (Ci * k ** 3) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    # reference (fp64): causal replicate pad in time, nearest x2, asymmetric pad for the strided convs
+    xr = x.double()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=(1, 2, 2), mode="nearest")
+    if k == 3 and pad == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    xr = F.pad(xr, (0, 0, 0, 0, k - 1, 0), mode="replicate")
+    ref = F.conv3d(xr, w.double(), b.double(), stride=(st, ss, ss), padding=(0, pad, pad))
+    r = None
+    if res:
+        r = _bf(torch.randn(ref.shape, generator=g))
+        ref = ref + r.double()
+    if tdup and ref.shape[2] > 1:
+        ref = torch.cat([ref[:, :, :1], F.interpolate(ref[:, :, 1:], scale_factor=(2, 1, 1), mode="nearest")], 2)
+    xcl = x[0].permute(1, 2, 3, 0).contiguous().to(DEV)
+    rcl = None if r is None else r[0].permute(1, 2, 3, 0).contiguous().to(DEV)
+    y = ops.conv3d_cl(xcl, _pack_conv_weight(w).to(DEV), b.to(DEV), k, st, ss, pad, ups=ups, tdup=tdup, res=rcl)
+    got = y.permute(3, 0, 1, 2)[None]
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err, rel = _rep(f"conv3d_cl T{T} {H}x{W} {Ci}->{Co} k{k} s{st}{ss} ups{int(ups)} tdup{int(tdup)}", got, ref)
+    assert rel < 4e-3
+
+
+def test_small_cin_conv_via_im2col():
+    from easyanimate_amd.vae_modules import CausalConv3d
+    g = torch.Generator().manual_seed(4)
+    for ci, co in ((3, 64), (16, 128), (64, 3)):
+        conv = CausalConv3d(ci, co, kernel_size=3)
+        with torch.no_grad():
+            conv.weight.copy_(_bf(torch.randn(conv.weight.shape, generator=g) / (27 * ci) ** 0.5).float())
+            conv.bias.copy_(torch.randn(co, generator=g))
+        x = _bf(torch.randn(1, ci, 4, 9, 10, generator=g))
+        ref = F.conv3d(F.pad(x.double(), (0, 0, 0, 0, 2, 0), mode="replicate"), conv.weight.double(), conv.bias.double(), padding=(0, 1, 1))
+        conv = conv.to(DEV)
+        y = conv(x[0].permute(1, 2, 3, 0).contiguous().to(DEV))
+        got = y[..., :co].permute(3, 0, 1, 2)[None]
+        err, rel = _rep(f"conv {ci}->{co}", got, ref)
+        assert rel < 4e-3
+        if y.shape[-1] != co:
+            assert y[..., co:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("T,HW,C,G", [(3, 100, 64, 16), (2, 5000, 128, 32), (1, 4096, 512, 32), (4, 333, 256, 32)])
+def test_groupnorm_silu(T, HW, C, G):
+    from easyanimate_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(T, HW, C, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    for act in (True, False):
+        y = ops.groupnorm_silu(x, gamma, beta, G, 1e-6, act=act)
+        ref = F.group_norm(x.double().transpose(1, 2), G, gamma.double(), beta.double(), 1e-6).transpose(1, 2)
+        if act:
+            ref = F.silu(ref)
+        err, rel = _rep(f"groupnorm T{T} HW{HW} C{C} act{int(act)}", y, ref)
+        assert rel < 4e-3
+    y2 = ops.groupnorm_silu(x, gamma, beta, G, 1e-6, act=True)
+    assert torch.equal(y2, ops.groupnorm_silu(x, gamma, beta, G, 1e-6, act=True))  # deterministic (no atomics)
+
+
+def test_softmax_rows_and_f32_gemm():
+    from easyanimate_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for cols in (64, 1000 - 1000 % 8, 4096, 16384):
+        x = (torch.randn(37, cols, generator=g) * 4).to(DEV)
+        for xin in (x, x.to(torch.bfloat16)):
+            y = ops.softmax_rows(xin.contiguous(), 0.37)
+            ref = torch.softmax(xin.double() * 0.37, -1)
+            err, rel = _rep(f"softmax {cols} {xin.dtype}", y, ref)
+            assert rel < 5e-3
+    A = _bf(torch.randn(200, 128, generator=g)).to(DEV)
+    W = _bf(torch.randn(72, 128, generator=g)).to(DEV)
+    out = ops.gemm(A, W, None, ops.EPI_F32_OUT)
+    assert out.dtype == torch.float32
+    err, rel = _rep("gemm f32 out", out, A.double() @ W.double().t())
+    assert rel < 1e-5
+
+
+def test_layout_kernels():
+    from easyanimate_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 4, 5, 6, generator=g).to(DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        cl = ops.ncdhw_to_ndhwc(x.to(dt), 8)
+        assert torch.equal(cl[..., :3], x.to(dt).to(torch.bfloat16).permute(1, 2, 3, 0)) and cl[..., 3:].abs().max() == 0
+        back = ops.ndhwc_to_ncdhw(cl, 3, dt)
+        assert torch.equal(back, x.to(dt).to(torch.bfloat16).to(dt))
+    cl = ops.ncdhw_to_ndhwc(x * 2, 8)
+    post = ops.ndhwc_to_ncdhw(cl, 3, torch.float32, post=1)
+    ref = ((x * 2).to(torch.bfloat16).float().clamp(-1, 1) / 2 + 0.5).clamp(0, 1)
+    assert torch.allclose(post, ref, atol=1e-6)
+
+
+def _metrics(name, got, ref32, refb):
+    got, r, b = got.double().cpu(), ref32.double(), refb.double()
+    mse = ((got - r) ** 2).mean().item()
+    floor = ((b - r) ** 2).mean().item()
+    rel = ((got - r).norm() / r.norm()).item()
+    print(f"[parity] {name}: new-bf16 vs ref-fp32 MSE={mse:.3e} rel_l2={rel:.3e} | ref-bf16 floor MSE={floor:.3e} | new vs ref-bf16 MSE={((got - b) ** 2).mean().item():.3e}")
+    return mse, floor, rel
+
+
+def test_vae_vs_golden_chunked_reference():
+    from easyanimate_amd import AutoencoderKLMagvit
+    from easyanimate_amd.synthetic import synth_state_dict
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
+    vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    with torch.no_grad():
+        post = vae.encode(g["video"].to(DEV).bfloat16())[0]
+        dec = vae.decode(g["z"].to(DEV).bfloat16())[0]
+    assert post.mode().shape == (1, 16, 3, 8, 8) and dec.shape == (1, 3, 9, 64, 64)
+    mse_e, floor_e, rel_e = _metrics("vae encode moments", post.parameters.float(), g["moments"], g["moments_bf16"])
+    mse_d, floor_d, rel_d = _metrics("vae decode", dec.float(), g["dec"], g["dec_bf16"])
+    assert mse_e <= max(1e-4, 2 * floor_e) and mse_d <= max(1e-4, 2 * floor_d)
+    # fp32 in -> fp32 out
+    with torch.no_grad():
+        dec32 = vae.decode(g["z"].to(DEV), return_dict=True).sample
+    assert dec32.dtype == torch.float32
+    # post-processing fused in the layout kernel == decode_latents arithmetic
+    with torch.no_grad():
+        pp = vae.decode(g["z"].to(DEV), postprocess=True)[0]
+    assert torch.allclose(pp, (dec32.clamp(-1, 1) / 2 + 0.5).clamp(0, 1), atol=1e-6)
+
+
+def test_vae_frame_bookkeeping_gpu():
+    from easyanimate_amd import AutoencoderKLMagvit
+    from easyanimate_amd.synthetic import synth_state_dict
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
+    vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    from oracle import restatement_vae as RV
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    for f, fl in ((1, 1), (5, 2), (13, 4)):
+        gen = torch.Generator().manual_seed(f)
+        vid = torch.rand(1, 3, f, 64, 64, generator=gen) * 2 - 1
+        z = torch.randn(1, 16, fl, 8, 8, generator=gen)
+        with torch.no_grad():
+            m = vae.encode(vid.to(DEV).bfloat16())[0].parameters
+            d = vae.decode(z.to(DEV).bfloat16())[0]
+            mr = RV.vae_encode_moments(sd, vid, 16)
+            dr = RV.vae_decode(sd, z, 16)
+        assert m.shape == mr.shape and d.shape == dr.shape
+        _, rel_m = _rep(f"vae enc {f}f", m.float(), mr)
+        _, rel_d = _rep(f"vae dec {fl}->{f}f", d.float(), dr)
+        assert rel_m < 4e-2 and rel_d < 4e-2
