@@ -34,6 +34,17 @@ class SequenceParallel:
         self.n_total = 0
         self.n_loc = 0
 
+    def _all_gather_flat(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        """recv[world*n] <- concat over ranks of send[n].  RCCL ("nccl") gathers device buffers directly over xGMI.
+        The gloo backend (used only by the CPU / single-GPU tests) cannot gather device tensors into one buffer, so
+        device tensors are staged through host memory there."""
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            r = torch.empty(recv.shape, dtype=recv.dtype, device="cpu")
+            dist.all_gather_into_tensor(r, send.cpu(), group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+
     # ---- token partition ----------------------------------------------------------------------
     def plan(self, n_total: int) -> None:
         self.n_total = n_total
@@ -81,7 +92,7 @@ class SequenceParallel:
         send[0] = k[:, :, off:off + nl].reshape(B, H, nl * 64)
         send[1] = vt[:, :, :, off:off + nl].reshape(B, H, 64 * nl)
         recv = torch.empty((self.world * send.numel(),), dtype=k.dtype, device=k.device)
-        dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)  # flat: accepted by nccl/RCCL and gloo
+        self._all_gather_flat(recv, send.view(-1))  # flat buffers: accepted by nccl/RCCL and gloo
         recv = recv.view((self.world,) + tuple(send.shape))
         for r in range(self.world):
             if r == self.rank:
@@ -102,7 +113,7 @@ class SequenceParallel:
         send = torch.zeros((B, self.n_loc, C), dtype=x.dtype, device=x.device)
         send[:, :n] = x
         recv = torch.empty((self.world * send.numel(),), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)
+        self._all_gather_flat(recv, send.view(-1))
         recv = recv.view(self.world, B, self.n_loc, C)
         return recv.permute(1, 0, 2, 3).reshape(B, self.world * self.n_loc, C)[:, :self.n_total].contiguous()
 

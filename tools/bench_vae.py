@@ -1,0 +1,126 @@
+"""VAE-only benchmark (BASELINE.json config 4): AutoencoderKLMagvit encode + decode of 49 x 1024 x 1024 RGB on one
+MI355X, bf16, random-init full-width weights.  Prints one JSON line with MPix/s (MPix = F*H*W/1e6 of the pixel
+video) for decode and encode, the algorithmic FLOPs (decode 7.50e14, encode 4.77e14 at this shape) and
+the implied MFMA fraction.
+
+    python tools/bench_vae.py [--frames 49 --size 1024 --iters 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+PEAK = 2500.0
+
+
+def conv_flops(vae, frames, size):
+    """2*k^3*Cin*Cout per output voxel for every conv + linears/attention of the mid blocks (SURVEY 8d formula)."""
+    import torch.nn as nn
+    from easyanimate_amd import ops
+    from easyanimate_amd.vae_modules import SpatialAttention
+    total = {"enc": 0.0, "dec": 0.0}
+    # walk the graph symbolically with shapes only
+    def conv(c, T, H, W, ups=False, tdup=False):
+        co, ci, k = c.weight.shape[0], c.weight.shape[1], c.weight.shape[2]
+        st, ss = c.stride[0], c.stride[1]
+        pad = c.padding[1] if k == 3 else 0
+        To, Ho, Wo = ops.conv_out_shape(T, H, W, k, st, ss, pad, ups)
+        fl = 2.0 * k ** 3 * ci * co * To * Ho * Wo
+        if tdup and To > 1:
+            To = 2 * To - 1
+        return fl, (To, Ho, Wo)
+    def res(r, shp):
+        fl = 0.0
+        if not isinstance(r.shortcut, nn.Identity):
+            f, _ = conv(r.shortcut, *shp); fl += f
+        f, s1 = conv(r.conv1, *shp); fl += f
+        f, s2 = conv(r.conv2, *s1); fl += f
+        return fl, s2
+    def mid(m, shp):
+        fl, s = res(m.convs[0], shp)
+        for a, r in zip(m.attentions, m.convs[1:]):
+            if a is not None:
+                T, H, W = s
+                n, C = H * W, a.inner_dim
+                fl += T * (8.0 * n * C * C + 4.0 * n * n * C)
+            f, s = res(r, s); fl += f
+        return fl, s
+    T, H, W = frames, size, size
+    f, s = conv(vae.encoder.conv_in, T, H, W); total["enc"] += f
+    for b in vae.encoder.down_blocks:
+        for r in b.convs:
+            f, s = res(r, s); total["enc"] += f
+        if b.downsampler is not None:
+            f, s = conv(b.downsampler.conv, *s); total["enc"] += f
+    f, s = mid(vae.encoder.mid_block, s); total["enc"] += f
+    f, s = conv(vae.encoder.conv_out, *s); total["enc"] += f
+    f, _ = conv(vae.quant_conv, *s); total["enc"] += f
+    lat = s
+    f, s = conv(vae.post_quant_conv, *lat); total["dec"] += f
+    f, s = conv(vae.decoder.conv_in, *s); total["dec"] += f
+    f, s = mid(vae.decoder.mid_block, s); total["dec"] += f
+    for b in vae.decoder.up_blocks:
+        for r in b.convs:
+            f, s = res(r, s); total["dec"] += f
+        if b.upsampler is not None:
+            f, s = conv(b.upsampler.conv, *s, ups=True, tdup=hasattr(b.upsampler, "padding_flag")); total["dec"] += f
+    f, s = conv(vae.decoder.conv_out, *s); total["dec"] += f
+    return total, lat, s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=49)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--small", action="store_true", help="reduced widths (debug)")
+    a = ap.parse_args()
+    from easyanimate_amd import AutoencoderKLMagvit
+    boc = [64, 64, 128, 128] if a.small else [128, 256, 512, 512]
+    with torch.device("meta"):
+        vae = AutoencoderKLMagvit(
+            in_channels=3, out_channels=3, block_out_channels=boc,
+            down_block_types=("SpatialDownBlock3D", "SpatialTemporalDownBlock3D", "SpatialTemporalDownBlock3D", "SpatialTemporalDownBlock3D"),
+            up_block_types=("SpatialUpBlock3D", "SpatialTemporalUpBlock3D", "SpatialTemporalUpBlock3D", "SpatialTemporalUpBlock3D"),
+            mid_block_attention_type="spatial", latent_channels=16, norm_num_groups=32 if not a.small else 16,
+            spatial_group_norm=True, cache_mag_vae=True, slice_mag_vae=False, mini_batch_encoder=4, mini_batch_decoder=1)
+    vae = vae.to(torch.bfloat16).to_empty(device="cuda")
+    torch.cuda.manual_seed(2)
+    with torch.no_grad():
+        for n, p in vae.named_parameters():
+            if p.dim() >= 2:
+                b = 1.0 / (p[0].numel() ** 0.5)
+                p.uniform_(-b, b)
+            elif "norm" in n and n.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.uniform_(-0.02, 0.02)
+    fl, lat, out = conv_flops(vae, a.frames, a.size)
+    mpix = a.frames * a.size * a.size / 1e6
+    z = torch.randn(1, 16, *lat, device="cuda").to(torch.bfloat16) / 0.1825
+    video = (torch.rand(1, 3, a.frames, a.size, a.size, device="cuda") * 2 - 1).to(torch.bfloat16)
+    res = {}
+    with torch.no_grad():
+        for name, fn in (("decode", lambda: vae.decode(z)[0]), ("encode", lambda: vae.encode(video)[0].mode())):
+            y = fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.iters):
+                y = fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / a.iters
+            key = "dec" if name == "decode" else "enc"
+            res[name] = {"seconds": dt, "MPix_per_s": mpix / dt, "algorithmic_flop": fl[key],
+                         "TFLOPs": fl[key] / dt / 1e12, "mfma_frac": fl[key] / dt / 1e12 / PEAK,
+                         "finite": bool(torch.isfinite(y.float()).all().item()), "out_shape": list(y.shape)}
+            del y
+    print(json.dumps({"metric": "VAE MPix/s (AutoencoderKLMagvit, bf16, 1 GPU)", "frames": a.frames, "size": a.size, "MPix": mpix,
+                      "latent_shape": list(lat), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, **res}))
+
+
+if __name__ == "__main__":
+    main()
