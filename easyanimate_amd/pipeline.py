@@ -33,6 +33,15 @@ def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timeste
     return scheduler.timesteps, num_inference_steps
 
 
+def get_image_to_video_latent(image: torch.Tensor, video_length: int):
+    """reference: easyanimate/utils/utils.py:128-157 (single start image, already a [3,H,W] tensor in [0,1]):
+    the image tiled over all frames, mask 0 on frame 0 and 255 elsewhere."""
+    input_video = torch.tile(image[None, :, None], [1, 1, video_length, 1, 1]).to(torch.float32)
+    mask = torch.zeros_like(input_video[:, :1])
+    mask[:, :, 1:] = 255
+    return input_video, mask
+
+
 def resize_mask(mask, latent, process_first_frame_only=True):
     """reference: pipeline_easyanimate_inpaint.py:116-149 (trilinear resize, first frame separately)."""
     import torch.nn.functional as F
@@ -128,11 +137,10 @@ class EasyAnimatePipeline:
                                        temporal_size=latent_frames, use_real=True)
 
     def decode_latents(self, latents):
-        """reference: :722-742"""
-        latents = 1 / self.vae.config.scaling_factor * latents
-        video = self.vae.decode(latents)[0]
-        video = video.clamp(-1, 1)
-        video = (video / 2 + 0.5).clamp(0, 1)
+        """reference: :722-742.  The 1/scaling_factor multiply touches the 0.9 MB latent only; the clamp / rescale
+        / clamp of the 150 M-pixel video is fused into the VAE's final layout kernel (postprocess=True)."""
+        latents = (1 / self.vae.config.scaling_factor) * latents
+        video = self.vae.decode(latents, postprocess=True)[0]
         return video.cpu().float().numpy()
 
     def _embeds(self, prompt_embeds, negative_prompt_embeds, device, dtype):
@@ -218,15 +226,27 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
         lat = self.vae.encode(masked_video.to(device=device, dtype=self.vae.dtype))[0].mode()
         return lat.to(dtype) * self.vae.config.scaling_factor
 
-    def inpaint_conditioning(self, video, mask_video, latents, dtype, device, do_cfg=True):
-        """reference: :1321-1383.  video in [-1,1] [B,3,F,H,W]; mask_video in [0,255]/255 -> [0,1] [B,1,F,H,W]."""
-        mask_condition = mask_video.to(device=device, dtype=torch.float32)
-        masked_video = video.to(device=device, dtype=torch.float32) * (mask_condition < 0.5) + \
-            torch.ones_like(video, device=device, dtype=torch.float32) * -1 * (mask_condition > 0.5)
+    @staticmethod
+    def masked_video_and_mask(video: torch.Tensor, mask_video: torch.Tensor):
+        """Host-side preprocessing exactly as the reference does it on CPU tensors (:1337-1346):
+        video in [0,1] -> init_video in [-1,1] (VaeImageProcessor normalize); mask in [0,255] binarised at 0.5;
+        masked_video = init_video * (mask < 0.5) - (mask > 0.5)."""
+        init_video = video.to(torch.float32) * 2.0 - 1.0
+        mask_condition = (mask_video.to(torch.float32) >= 0.5).to(torch.float32)
+        tile = torch.tile(mask_condition, [1, 3, 1, 1, 1])
+        masked_video = init_video * (tile < 0.5) + torch.ones_like(init_video) * (tile > 0.5) * -1
+        return masked_video, mask_condition
+
+    def inpaint_conditioning(self, video, mask_video, dtype, device, do_cfg=True):
+        """reference: pipeline_easyanimate_inpaint.py:1321-1383 with resize_inpaint_mask_directly=True (V5.1 yaml):
+        inpaint_latents = cat[ resize_mask(1 - mask) * s , VAE.encode(masked_video).mode() * s ]  (1 + 16 channels)."""
+        if not self.transformer.resize_inpaint_mask_directly:
+            raise NotImplementedError("resize_inpaint_mask_directly=False (mask encoded by the VAE) is not built")
+        masked_video, mask_condition = self.masked_video_and_mask(video.cpu(), mask_video.cpu())
         masked_latents = self.prepare_mask_latents(None, masked_video, dtype, device)
-        mask = resize_mask(1 - mask_condition, masked_latents, self.transformer.resize_inpaint_mask_directly is False or True)
-        mask = mask.to(dtype) * self.vae.config.scaling_factor
-        inpaint = torch.cat([mask, masked_latents], dim=1)
+        mask_latents = resize_mask(1 - mask_condition, masked_latents, getattr(self.vae, "cache_mag_vae", True))
+        mask_latents = mask_latents.to(device, dtype) * self.vae.config.scaling_factor
+        inpaint = torch.cat([mask_latents, masked_latents], dim=1).to(dtype)
         return torch.cat([inpaint] * 2) if do_cfg else inpaint
 
     @torch.no_grad()
@@ -248,7 +268,7 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
         latents = self.prepare_latents(1, nc, video_length, height, width, dtype, device, generator, latents)
         rope = self.rotary_embedding(height, width, latents.size(2))
         if video is not None and mask_video is not None:
-            inpaint = self.inpaint_conditioning(video, mask_video, latents, dtype, device, self.do_classifier_free_guidance)
+            inpaint = self.inpaint_conditioning(video, mask_video, dtype, device, self.do_classifier_free_guidance)
         else:
             n_extra = self.transformer.config.in_channels - nc
             inpaint = torch.zeros((2 if self.do_classifier_free_guidance else 1, n_extra) + tuple(latents.shape[2:]),

@@ -147,6 +147,17 @@ def main():
     torch.save(dict(cfg=vkw, shapes=shapes, seed=2, style="default", video=video, z=zlat, moments=moments, dec=dec,
                     moments_bf16=moments_b, dec_bf16=dec_b), os.path.join(OUT, "vae_tiny.pt"))
 
+    # ---- I2V conditioning helpers (pipeline_easyanimate_inpaint.py:116-149, utils/utils.py:128-157)
+    from easyanimate.pipeline import pipeline_easyanimate_inpaint as inp
+    g = _g(21)
+    mask = torch.zeros(1, 1, 9, 32, 48)
+    mask[:, :, 1:] = 1.0
+    lat = torch.zeros(1, 16, 3, 4, 6)
+    rm = {f"first{int(b)}": inp.resize_mask(1 - mask, lat, b) for b in (True, False)}
+    mask2 = (torch.rand(1, 1, 13, 16, 16, generator=g) > 0.5).float()
+    rm["random_first1"] = inp.resize_mask(1 - mask2, torch.zeros(1, 16, 4, 2, 2), True)
+    torch.save(dict(mask=mask, mask2=mask2, resized=rm), os.path.join(OUT, "i2v_resize_mask.pt"))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

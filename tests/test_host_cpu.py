@@ -110,3 +110,21 @@ def test_pipeline_latent_shapes():
     assert p.latent_shape(1, 16, 49, 1024, 1024) == (1, 16, 13, 128, 128)
     assert p.latent_shape(1, 16, 1, 256, 256) == (1, 16, 1, 32, 32)
     assert p.latent_shape(1, 16, 25, 384, 672) == (1, 16, 7, 48, 84)
+
+
+def test_i2v_conditioning_host_logic():
+    """resize_mask equals the reference function's output; masked-video / mask construction follows
+    pipeline_easyanimate_inpaint.py:1337-1346 and utils/utils.py:152-157."""
+    from easyanimate_amd.pipeline import EasyAnimateInpaintPipeline, get_image_to_video_latent, resize_mask
+    g = _load("i2v_resize_mask.pt")
+    lat = torch.zeros(1, 16, 3, 4, 6)
+    for b in (True, False):
+        assert torch.equal(resize_mask(1 - g["mask"], lat, b), g["resized"][f"first{int(b)}"])
+    assert torch.equal(resize_mask(1 - g["mask2"], torch.zeros(1, 16, 4, 2, 2), True), g["resized"]["random_first1"])
+    img = torch.rand(3, 16, 24)
+    video, mask = get_image_to_video_latent(img, 9)
+    assert video.shape == (1, 3, 9, 16, 24) and mask.shape == (1, 1, 9, 16, 24)
+    assert torch.equal(video[0, :, 5], img) and mask[0, 0, 0].max() == 0 and mask[0, 0, 1:].min() == 255
+    mv, mc = EasyAnimateInpaintPipeline.masked_video_and_mask(video, mask)
+    assert torch.equal(mv[0, :, 0], img * 2 - 1) and (mv[0, :, 1:] == -1).all()
+    assert mc[0, 0, 0].max() == 0 and mc[0, 0, 1:].min() == 1
