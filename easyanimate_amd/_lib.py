@@ -63,6 +63,8 @@ def load() -> ctypes.CDLL:
     lib.ea_last_error_string.argtypes = []
     lib.ea_version.restype = c_int
     lib.ea_version.argtypes = []
+    lib.ea_set_option.restype = c_int
+    lib.ea_set_option.argtypes = [ctypes.c_char_p, c_int]
     _lib = lib
     return lib
 
@@ -72,3 +74,8 @@ def call(name: str, *args) -> None:
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.ea_last_error_string().decode()}")
+
+
+def set_option(name: str, value: int) -> None:
+    """ea_set_option: tuning / benchmarking switches (e.g. "gemm_tile" 0|128|256)."""
+    call("ea_set_option", name.encode(), int(value))

@@ -14,6 +14,7 @@
 //     accumulator registers: 16-byte bf16 stores, 16-byte residual loads, vector bias/gate loads.
 //   * blockIdx is remapped so that the 8 XCDs (private L2s) each walk a contiguous band of M-tiles.
 #include "ea_common.h"
+#include <string.h>
 
 namespace {
 
@@ -43,26 +44,19 @@ __device__ __forceinline__ int swap23(int m) {  // swap bits 2 and 3
     return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int hi = lane >> 5, l31 = lane & 31;
 
-    // ---- XCD-aware, grouped tile mapping.  Block b runs on XCD b%8 (private 4 MiB L2).  Each XCD owns a
-    // contiguous band of M-tile rows and walks it in groups of 8 rows x all N-tiles, column-major inside a
-    // group, so the ~64 workgroups resident on an XCD at any time cover an 8 x 8 patch of tiles: per K-step they
-    // pull 8 A-tiles + 8 W-tiles through that L2 instead of ~3 + 24 (round-1 PMC: 10-20x HBM over-fetch).
-    int tm, tn;
+// ---- XCD-aware, grouped tile mapping.  Block b runs on XCD b%8 (private 4 MiB L2).  Each XCD owns a
+// contiguous band of M-tile rows and walks it in groups of 8 rows x all N-tiles, column-major inside a
+// group, so the workgroups resident on an XCD at any time cover an 8 x {8 (128^2 tiles) | 4 (256^2 tiles)} patch
+// of tiles: per K-step they pull 8 A-tiles + a few W-tiles through that L2 instead of ~3 + 24 (round-1 PMC:
+// 10-20x HBM over-fetch with the plain N-fastest order).
+__device__ __forceinline__ bool tile_of_block(const GemmArgs& p, int& tm, int& tn) {
     if (p.rows_per_xcd > 0) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         const int m_lo = xcd * p.rows_per_xcd;
         int rows = p.tiles_m - m_lo;
         rows = rows < p.rows_per_xcd ? rows : p.rows_per_xcd;
-        if (rows <= 0 || idx >= rows * p.tiles_n) return;
+        if (rows <= 0 || idx >= rows * p.tiles_n) return false;
         const int width = 8 * p.tiles_n;
         const int first = (idx / width) * 8;
         const int local = idx % width;
@@ -73,6 +67,65 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         tm = blockIdx.x / p.tiles_n;
         tn = blockIdx.x % p.tiles_n;
     }
+    return true;
+}
+
+// ---- epilogue for one lane-owned strip: output row m, columns n0..n0+7 (fp32 math, one bf16 rounding)
+template <int EPI>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int b, int m, int n0, float (&v)[8]) {
+    if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+        }
+    }
+    if (EPI == EA_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+    }
+    if (EPI == EA_EPI_BIAS_GATE_RES) {
+        const float* gb = p.gate + b * p.gbs;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + n0);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gb + n0 + 4);
+        const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + b * p.rbs + (int64_t)m * p.ldres + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = bf16_bits_to_f32(rr[e]) + g0[e] * v[e];
+            v[4 + e] = bf16_bits_to_f32(rr[4 + e]) + g1[e] * v[4 + e];
+        }
+    }
+    if (EPI == EA_EPI_F32_OUT) {
+        float* Cf = reinterpret_cast<float*>(p.C) + b * p.cbs + (int64_t)m * p.ldc + n0;
+        f32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o0[e] = v[e];
+            o1[e] = v[4 + e];
+        }
+        *reinterpret_cast<f32x4*>(Cf) = o0;
+        *reinterpret_cast<f32x4*>(Cf + 4) = o1;
+    } else {
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+        *reinterpret_cast<u16x8*>(p.C + b * p.cbs + (int64_t)m * p.ldc + n0) = o;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    int tm, tn;
+    if (!tile_of_block(p, tm, tn)) return;
     const int b = blockIdx.y;
     const int row0 = tm * BM, col0 = tn * BN;
 
@@ -151,9 +204,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: lane owns row m, columns n0..n0+7 per (j, g)
-    unsigned short* Cb = p.C + b * p.cbs;
-    const unsigned short* Rb = EPI == EA_EPI_BIAS_GATE_RES ? p.res + b * p.rbs : nullptr;
-    const float* gb = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = row0 + wm * 64 + i * 32 + l31;
@@ -167,49 +217,196 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
-                if (p.bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] += b0[e];
-                        v[4 + e] += b1[e];
-                    }
-                }
-                if (EPI == EA_EPI_BIAS_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
-                }
-                if (EPI == EA_EPI_BIAS_GATE_RES) {
-                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + n0);
-                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gb + n0 + 4);
-                    const u16x8 rr = *reinterpret_cast<const u16x8*>(Rb + (int64_t)m * p.ldres + n0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = bf16_bits_to_f32(rr[e]) + g0[e] * v[e];
-                        v[4 + e] = bf16_bits_to_f32(rr[4 + e]) + g1[e] * v[4 + e];
-                    }
-                }
-                if (EPI == EA_EPI_F32_OUT) {
-                    float* Cf = reinterpret_cast<float*>(p.C) + b * p.cbs + (int64_t)m * p.ldc + n0;
-                    f32x4 o0, o1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o0[e] = v[e];
-                        o1[e] = v[4 + e];
-                    }
-                    *reinterpret_cast<f32x4*>(Cf) = o0;
-                    *reinterpret_cast<f32x4*>(Cf + 4) = o1;
-                } else {
-                    u16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                    *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + n0) = o;
-                }
+                epilogue8<EPI>(p, b, m, n0, v);
             }
         }
     }
 }
+
+
+// =================================================================================================
+// 256 x 256 x 64 "ping-pong" kernel for the large DiT linears (M >= a few thousand rows).
+//
+//   * workgroup = 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = 4 x 2 MFMA tiles (128 accumulator
+//     registers); one workgroup per CU (128 KiB LDS: A and W tiles of 256 rows x 128 B, two stages each).
+//   * a K-tile is four phases (one 16-deep k-step each): L-part {6 ds_read_b128 (4 A + 2 W fragments), a share of
+//     the next tile's LDS-DMA} | s_barrier | M-part {8 MFMAs at s_setprio 1} | s_barrier.  The two wave groups
+//     (wr = 0 / 1; each SIMD hosts one wave of either group) run staggered by one barrier, so on every SIMD one
+//     wave's MFMAs cover the other wave's LDS reads and DMA issue (CDNA4 guide, T3/T4/T5).
+//   * tile t+1 is DMA'd during phases 0 (A) and 1 (W) of tile t into the other stage and waited for (vmcnt(0),
+//     1000-1500 cycles later) in phase 3 before that phase's first barrier; phase 3 also retires its own ds_reads
+//     before that barrier, which is what frees the stage for the DMA issued two barriers later.
+//   * same operand roles / row swizzles / epilogue as the 128^2 kernel (C^T tiles, swap-2/3 W rows, 16-byte stores).
+constexpr int OPER2 = 256 * 128;   // one operand tile, 32 KiB
+constexpr int GEMM2_LDS = 4 * OPER2;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    int tm, tn;
+    if (!tile_of_block(p, tm, tn)) return;
+    const int b = blockIdx.y;
+    const int row0 = tm * 256, col0 = tn * 256;
+    const unsigned short* Ab = p.A + b * p.abs_;
+
+    // ---- per-lane DMA sources: 4 x 1 KiB pieces per wave per operand tile (piece q = rows 8q..8q+7)
+    const unsigned short* asrc[4];
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ ((r >> 1) & 7);
+        int ra = row0 + r;
+        ra = ra < p.M ? ra : p.M - 1;
+        int rw = col0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
+        wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
+    }
+    char* const dma_a = smem + wave * 4096;               // + stage*OPER2 + i*1024
+    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addresses: row*128 + ((chunk ^ ((row>>1)&7)) << 4), chunk = 2*ks + hi
+    const int a_row = wr * 128 + l31;
+    const int w_row = wc * 64 + swap23(l31);
+    const int a_sw = (l31 >> 1) & 7, w_sw = (swap23(l31) >> 1) & 7;
+    const char* a_k[4];
+    const char* w_k[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a_k[ks] = smem + a_row * 128 + (((ks * 2 + hi) ^ a_sw) << 4);
+        w_k[ks] = smem + 2 * OPER2 + w_row * 128 + (((ks * 2 + hi) ^ w_sw) << 4);
+    }
+
+    const int nk = p.K / BK;
+
+#define EA_G2_PHASE(S, KS, HAS_NEXT)                                                                       \
+    {                                                                                                      \
+        bf16x8 af[4], wf[2];                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+            wf[j] = *reinterpret_cast<const bf16x8*>(w_k[KS] + (S) * OPER2 + j * 4096);                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            af[i] = *reinterpret_cast<const bf16x8*>(a_k[KS] + (S) * OPER2 + i * 4096);                    \
+        if ((KS) == 0 && (HAS_NEXT)) {                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+                asrc[i] += BK;                                                                             \
+                glds16(asrc[i], dma_a + ((S) ^ 1) * OPER2 + i * 1024);                                     \
+            }                                                                                              \
+        }                                                                                                  \
+        if ((KS) == 1 && (HAS_NEXT)) {                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+                wsrc[i] += BK;                                                                             \
+                glds16(wsrc[i], dma_w + ((S) ^ 1) * OPER2 + i * 1024);                                     \
+            }                                                                                              \
+        }                                                                                                  \
+        if ((KS) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);     \
+        __builtin_amdgcn_s_setprio(0);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+#define EA_G2_TILE(S, HAS_NEXT)      \
+    EA_G2_PHASE(S, 0, HAS_NEXT)      \
+    EA_G2_PHASE(S, 1, HAS_NEXT)      \
+    EA_G2_PHASE(S, 2, HAS_NEXT)      \
+    EA_G2_PHASE(S, 3, HAS_NEXT)
+
+    // ---- prologue: tile 0 -> stage 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        glds16(asrc[i], dma_a + i * 1024);
+        glds16(wsrc[i], dma_w + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t < nk; t += 2) {
+        const bool n0_ = t + 1 < nk;
+        EA_G2_TILE(0, n0_)
+        if (n0_) {
+            const bool n1_ = t + 2 < nk;
+            EA_G2_TILE(1, n1_)
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+#undef EA_G2_TILE
+#undef EA_G2_PHASE
+
+    // ---- epilogue: lane owns row m, columns n0..n0+7 per (j, g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = row0 + wr * 128 + i * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int n0 = col0 + wc * 64 + j * 32 + g * 16 + hi * 8;
+                if (n0 >= p.N) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
+                epilogue8<EPI>(p, b, m, n0, v);
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
+    GemmArgs p = p0;
+    const int bm = tile, threads = tile == 256 ? 512 : 256;
+    const int lds = tile == 256 ? GEMM2_LDS : GEMM_LDS;
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = (p.N + bm - 1) / bm;
+    // small problems: plain N-fastest order over all XCDs; large M: per-XCD row bands (see tile_of_block)
+    p.rows_per_xcd = p.tiles_m >= 64 ? (p.tiles_m + 7) / 8 : 0;
+    dim3 grid(p.rows_per_xcd ? 8 * p.rows_per_xcd * p.tiles_n : p.tiles_m * p.tiles_n, batch);
+    static bool attr_done[2] = {false, false};
+    if (tile == 256) {
+        if (!attr_done[1]) {
+            hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_done[1] = true;
+        }
+        hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
+    } else {
+        if (!attr_done[0]) {
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_done[0] = true;
+        }
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
+    }
+    return EA_OK;
+}
+
+int g_gemm_tile = 0;   // 0 = auto, 128 / 256 = forced (ea_set_option("gemm_tile", ...), benchmarking only)
 
 }  // namespace
 
@@ -233,33 +430,27 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
     p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.abs_ = a_batch_stride; p.ldc = ldc; p.cbs = c_batch_stride;
     p.ldres = ldres; p.rbs = res_batch_stride; p.gbs = gate_batch_stride;
-    p.tiles_m = (M + BM - 1) / BM;
-    p.tiles_n = (N + BN - 1) / BN;
-    // small problems: plain N-fastest order over all XCDs; large M: per-XCD row bands (see kernel)
-    p.rows_per_xcd = p.tiles_m >= 64 ? (p.tiles_m + 7) / 8 : 0;
-    dim3 grid(p.rows_per_xcd ? 8 * p.rows_per_xcd * p.tiles_n : p.tiles_m * p.tiles_n, batch);
+    // 256^2 ping-pong kernel when there are enough 256-row tiles to fill the 256 CUs a few times over
+    int tile = g_gemm_tile;
+    if (tile != 128 && tile != 256)
+        tile = ((int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch >= 512 && N % 256 == 0) ? 256 : 128;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        attr_done = true;
-    }
     switch (epilogue) {
-        case EA_EPI_BIAS:
-            hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, dim3(256), GEMM_LDS, st, p);
-            break;
-        case EA_EPI_BIAS_GELU_TANH:
-            hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, dim3(256), GEMM_LDS, st, p);
-            break;
-        case EA_EPI_F32_OUT:
-            hipLaunchKernelGGL(gemm_bf16_kernel<3>, grid, dim3(256), GEMM_LDS, st, p);
-            break;
-        default:
-            hipLaunchKernelGGL(gemm_bf16_kernel<2>, grid, dim3(256), GEMM_LDS, st, p);
-            break;
+        case EA_EPI_BIAS: launch_gemm<0>(p, batch, tile, st); break;
+        case EA_EPI_BIAS_GELU_TANH: launch_gemm<1>(p, batch, tile, st); break;
+        case EA_EPI_F32_OUT: launch_gemm<3>(p, batch, tile, st); break;
+        default: launch_gemm<2>(p, batch, tile, st); break;
     }
     return ea_check_launch("ea_gemm_bf16");
+}
+
+extern "C" int ea_set_option(const char* name, int value) {
+    EA_REQUIRE(name, "ea_set_option: null name");
+    if (!strcmp(name, "gemm_tile")) {
+        EA_REQUIRE(value == 0 || value == 128 || value == 256, "ea_set_option: gemm_tile must be 0, 128 or 256");
+        g_gemm_tile = value;
+        return EA_OK;
+    }
+    ea_set_error("ea_set_option: unknown option '%s'", name);
+    return EA_ERR_ARG;
 }

@@ -40,6 +40,9 @@ typedef uint16_t ea_bf16;
 
 const char* ea_last_error_string(void);
 int ea_version(void);
+/* Tuning / benchmarking switches (process-wide; results never depend on them):
+ *   "gemm_tile": 0 = automatic (default), 128 / 256 = force that block tile in ea_gemm_bf16. */
+int ea_set_option(const char* name, int value);
 
 /* ---- normalisation ------------------------------------------------------------------------- */
 

@@ -133,6 +133,51 @@ def test_gemm(B, M, N, K, epi):
     assert err < 0.06 * max(1.0, ref.abs().max().item() / 4)
 
 
+GEMM256_SHAPES = [
+    # B, M, N, K   (forced 256^2 ping-pong tile; odd/even K-tile counts, M and N tails, strided batches)
+    (1, 256, 256, 64),
+    (1, 256, 256, 128),
+    (1, 512, 512, 192),
+    (2, 700, 768, 3072),
+    (1, 16500, 320, 320),    # tiles_m >= 64 (per-XCD bands), N tail (320 = 256 + 64)
+    (2, 1000, 3072, 1024),
+    (1, 2048, 12288, 256),
+]
+
+
+@pytest.mark.parametrize("B,M,N,K", GEMM256_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_tile256(B, M, N, K, epi):
+    from easyanimate_amd import _lib
+    _lib.set_option("gemm_tile", 256)
+    try:
+        test_gemm(B, M, N, K, epi)
+    finally:
+        _lib.set_option("gemm_tile", 0)
+
+
+def test_gemm_tile256_matches_tile128_bitwise_inputs_many_runs():
+    """Race screen for the hand-placed vmcnt / barrier schedule: the 256^2 kernel must give the identical result on
+    repeated launches, and agree with the 128^2 kernel to fp32-accumulation-order noise, at a DiT-sized problem."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 8192, 3072, 3072
+    A = _bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    _lib.set_option("gemm_tile", 128)
+    y128 = ops.gemm(A, W, bias, 0)
+    _lib.set_option("gemm_tile", 256)
+    try:
+        y0 = ops.gemm(A, W, bias, 0)
+        for _ in range(5):
+            assert torch.equal(ops.gemm(A, W, bias, 0), y0)
+    finally:
+        _lib.set_option("gemm_tile", 0)
+    assert torch.equal(y0, y128)  # same k order and fp32 accumulation chain per output element
+
+
 def test_gemm_identity_transpose_detect():
     """A = I with asymmetric W: catches swapped row/col in the C write (guide rule 16)."""
     ops = _ops()

@@ -28,6 +28,14 @@ def timeit(fn, warm=2, iters=5):
 
 
 def bench_gemm():
+    from easyanimate_amd import _lib
+    for tile in (128, 256, 128, 256):
+        _lib.set_option("gemm_tile", tile)
+        _bench_gemm(tile)
+    _lib.set_option("gemm_tile", 0)
+
+
+def _bench_gemm(tile):
     for (M, N, K, epi) in [(106496 + 512, 3072, 3072, 0), (106496, 12288, 3072, 1), (106496, 3072, 12288, 2), (8192, 8192, 8192, 0), (4096, 4096, 4096, 0), (512, 3072, 3072, 0)]:
         A = (torch.randn(M, K, device=DEV) ).to(torch.bfloat16)
         W = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
@@ -39,7 +47,7 @@ def bench_gemm():
         else:
             fn = lambda: ops.gemm(A, W, bias, epi, out=out)
         ms = timeit(fn)
-        print(json.dumps({"kernel": "gemm", "M": M, "N": N, "K": K, "epi": epi, "ms": ms, "TFLOPs": 2.0 * M * N * K / ms / 1e9}), flush=True)
+        print(json.dumps({"kernel": "gemm", "tile": tile, "M": M, "N": N, "K": K, "epi": epi, "ms": ms, "TFLOPs": 2.0 * M * N * K / ms / 1e9}), flush=True)
         del A, W, out
 
 
