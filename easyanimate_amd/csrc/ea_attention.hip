@@ -334,7 +334,15 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     }
 }
 
+#include "ea_attention_v2.inc"
+
 }  // namespace
+
+int ea_attn_variant_set(int v) {
+    if (v != 1 && v != 2) return -1;
+    g_attn_variant = v;
+    return 0;
+}
 
 extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q_out, ea_bf16* k_out,
                                    ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
@@ -365,7 +373,11 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
     EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd_bf16: grid too large");
     const float scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt,
-                       out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
+    if (g_attn_variant == 1)
+        hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt,
+                           out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
+    else
+        hipLaunchKernelGGL(attention_fwd_v2_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k,
+                           vt, out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
     return ea_check_launch("ea_attention_fwd_bf16");
 }

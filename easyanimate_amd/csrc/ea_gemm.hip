@@ -444,11 +444,17 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
     return ea_check_launch("ea_gemm_bf16");
 }
 
+int ea_attn_variant_set(int v);
+
 extern "C" int ea_set_option(const char* name, int value) {
     EA_REQUIRE(name, "ea_set_option: null name");
     if (!strcmp(name, "gemm_tile")) {
         EA_REQUIRE(value == 0 || value == 128 || value == 256, "ea_set_option: gemm_tile must be 0, 128 or 256");
         g_gemm_tile = value;
+        return EA_OK;
+    }
+    if (!strcmp(name, "attn_variant")) {
+        EA_REQUIRE(ea_attn_variant_set(value) == 0, "ea_set_option: attn_variant must be 1 or 2");
         return EA_OK;
     }
     ea_set_error("ea_set_option: unknown option '%s'", name);

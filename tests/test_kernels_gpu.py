@@ -285,6 +285,58 @@ def test_attention_forced_rescale_and_padding_garbage():
     assert rel < 8e-3 and err < 0.05
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_variants_rescale_paths(variant):
+    """Both kernels (v1: per-block rescale; v2: software-pipelined, deferred rescale with the pending P.V flushed in the
+    rare branch) against an fp64 reference on inputs that force the rescale branch at chosen blocks (CDNA4 guide,
+    rule 26): spikes in even / odd 32-key blocks, in the first tile, in the ragged last tile, growth below and above
+    the defer threshold, and a steady ramp whose cumulated growth crosses the threshold many times."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    _lib.set_option("attn_variant", variant)
+    try:
+        B, H, S = 1, 3, 1000   # 15 full tiles + a 40-key tail
+        q, k, vt, v = _attn_inputs(B, H, S, 23)
+        # head 0: spikes of different heights at different block parities
+        for (qq, kk, amp) in [(3, 40, 1.2), (3, 70, 2.5), (3, 650, 7.0), (17, 31, 4.0), (200, 96, 3.0), (200, 999, 9.0),
+                              (777, 960, 5.0), (64, 0, 6.0), (65, 130, 0.6)]:
+            k[:, 0, kk] = q[:, 0, qq] * amp
+        # head 1: scores ramp up along the key axis for every query: k_j = (j/S) * 3 * mean-direction
+        d = _bf(torch.ones(64)).to(DEV)
+        q[:, 1, :S] = (q[:, 1, :S].float() * 0.3 + d.float() * 2.0).to(torch.bfloat16)
+        ramp = (torch.arange(S, device=DEV).float() / S)[None, :, None]
+        k[:, 1, :S] = (k[:, 1, :S].float() * 0.3 + d.float()[None, None, :] * 3.0 * ramp).to(torch.bfloat16)
+        # head 2: plain random
+        out = ops.attention(q, k, vt, S, 0.125)
+        ref = _attn_ref(q, k, v, S)
+        for h in range(H):
+            err, rel = _report(f"attention v{variant} rescale-paths head{h}", out[:, :, h * 64:(h + 1) * 64],
+                               ref[:, :, h * 64:(h + 1) * 64])
+            assert rel < 8e-3 and err < 0.05, (h, err, rel)
+        assert torch.isfinite(out.float()).all()
+    finally:
+        _lib.set_option("attn_variant", 2)
+
+
+def test_attention_v2_matches_v1_large():
+    """The two kernels agree on a long sequence (836 tiles worth of pipeline steady state is covered by the model
+    tests; here 130 tiles, ragged tail, 16 heads so every XCD slot is used)."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    B, H, S = 1, 16, 8300
+    q, k, vt, v = _attn_inputs(B, H, S, 29, scale_q=1.5)
+    _lib.set_option("attn_variant", 1)
+    o1 = ops.attention(q, k, vt, S, 0.125)
+    _lib.set_option("attn_variant", 2)
+    o2 = ops.attention(q, k, vt, S, 0.125)
+    o2b = ops.attention(q, k, vt, S, 0.125)
+    assert torch.equal(o2, o2b)
+    ref = _attn_ref(q, k, v, S)
+    e1, r1 = _report("attention v1 S8300", o1, ref)
+    e2, r2 = _report("attention v2 S8300", o2, ref)
+    assert r2 < 8e-3 and e2 < 0.05 and r2 < 1.5 * r1 + 1e-4
+
+
 def test_attention_query_range():
     """Sequence-parallel use: only rows [q_begin, q_end) are produced, the rest of `out` is untouched."""
     ops = _ops()

@@ -52,6 +52,14 @@ def _bench_gemm(tile):
 
 
 def bench_attn():
+    from easyanimate_amd import _lib
+    for var in (1, 2, 1, 2):
+        _lib.set_option("attn_variant", var)
+        _bench_attn(var)
+    _lib.set_option("attn_variant", 2)
+
+
+def _bench_attn(var):
     for (B, H, S) in [(2, 48, 13568), (1, 48, 53504), (2, 8, 53504)]:
         s_pad = ops.round_up(S, 256)
         q = torch.randn(B, H, s_pad, 64, device=DEV).to(torch.bfloat16)
@@ -60,7 +68,7 @@ def bench_attn():
         out = torch.empty(B, S, H * 64, dtype=torch.bfloat16, device=DEV)
         fn = lambda: ops.attention(q, k, vt, S, 0.125, out=out)
         ms = timeit(fn, warm=1, iters=3)
-        print(json.dumps({"kernel": "attention", "B": B, "H": H, "S": S, "ms": ms, "TFLOPs": 4.0 * B * H * S * S * 64 / ms / 1e9}), flush=True)
+        print(json.dumps({"kernel": "attention", "variant": var, "B": B, "H": H, "S": S, "ms": ms, "TFLOPs": 4.0 * B * H * S * S * 64 / ms / 1e9}), flush=True)
         del q, k, vt, out
 
 
