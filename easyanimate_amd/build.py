@@ -16,6 +16,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libea_mi355x.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# per-file extras: the one-wave-per-SIMD attention kernel keeps its MFMA accumulators in arch VGPRs (they are read by
+# the softmax VALU code every block); without this hipcc parks them in AGPRs and copies ~340 registers per tile.
+EXTRA_FLAGS = {"ea_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _sources():
@@ -30,12 +33,13 @@ def _digest() -> str:
             h.update(f.encode())
             h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
 def _compile(src: str, objdir: str) -> str:
     obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-    cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -335,11 +335,12 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
 }
 
 #include "ea_attention_v2.inc"
+#include "ea_attention_v3.inc"
 
 }  // namespace
 
 int ea_attn_variant_set(int v) {
-    if (v != 1 && v != 2) return -1;
+    if (v < 1 || v > 3) return -1;
     g_attn_variant = v;
     return 0;
 }
@@ -368,7 +369,8 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
     EA_REQUIRE(s_pad % ATT_QB == 0 && s_pad >= seq, "ea_attention_fwd_bf16: s_pad must be a multiple of 256 and >= seq");
     EA_REQUIRE(q_begin >= 0 && q_begin <= q_end && q_end <= seq, "ea_attention_fwd_bf16: bad query range");
     if (q_end == q_begin) return EA_OK;
-    const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
+    const int qblk = g_attn_variant == 3 ? ATT3_QB : ATT_QB;
+    const int nqb = (q_end - q_begin + qblk - 1) / qblk;
     const int bh = batch * heads;
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
     EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd_bf16: grid too large");
@@ -376,6 +378,9 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
     if (g_attn_variant == 1)
         hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt,
                            out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
+    else if (g_attn_variant == 3)
+        hipLaunchKernelGGL(attention_fwd_v3_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k,
+                           vt, out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
     else
         hipLaunchKernelGGL(attention_fwd_v2_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k,
                            vt, out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);

@@ -454,7 +454,7 @@ extern "C" int ea_set_option(const char* name, int value) {
         return EA_OK;
     }
     if (!strcmp(name, "attn_variant")) {
-        EA_REQUIRE(ea_attn_variant_set(value) == 0, "ea_set_option: attn_variant must be 1 or 2");
+        EA_REQUIRE(ea_attn_variant_set(value) == 0, "ea_set_option: attn_variant must be 1, 2 or 3");
         return EA_OK;
     }
     ea_set_error("ea_set_option: unknown option '%s'", name);

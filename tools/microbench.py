@@ -53,7 +53,7 @@ def _bench_gemm(tile):
 
 def bench_attn():
     from easyanimate_amd import _lib
-    for var in (1, 2, 1, 2):
+    for var in (2, 3, 2, 3):
         _lib.set_option("attn_variant", var)
         _bench_attn(var)
     _lib.set_option("attn_variant", 2)
