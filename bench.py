@@ -158,17 +158,22 @@ def main():
         elapsed = tmax.item()
     finite = bool(torch.isfinite(latents.float()).all().item())
 
-    # ---- roofline of the dominant kernel (attention forward): algorithmic FLOPs per launch / HIP-event duration
+    # ---- roofline of the dominant kernel (attention forward): algorithmic FLOPs per block / HIP-event duration.
+    # Multi-GPU: a rank runs its batch slice (CFG axis) and its query shard (sequence axis) as two or three key-range
+    # launches per block (local keys while the K/V all-gather is in flight, then the remote keys): they are summed.
     durs = kt.durations_ms()
+    n_blocks = L * K
     if world > 1:
-        n_q = max(d_ for d_ in [model.sequence_parallel.shard_range()[1] - model.sequence_parallel.shard_range()[0]])
-        # two launches per block per rank (text rows + own video rows): use the video launches (every 2nd event)
-        durs = durs[1::2]
-        q_rows = n_q
+        sp = model.sequence_parallel
+        b_loc = 1 if sp.axis.cfg_degree == 2 else B
+        lo, hi = sp.shard_range()
+        q_rows = 256 + (hi - lo)
+        par = (f"cfg{sp.axis.cfg_degree} x sp{sp.size}: CFG pair split over rank halves, video-token sequence parallel "
+               f"inside a half, asynchronous K/V all-gather under the local-key attention pass")
     else:
-        q_rows = S
-    att_ms = sum(durs) / max(len(durs), 1)
-    att_flop = 4.0 * q_rows * S * 64 * B * H
+        b_loc, q_rows, par = B, S, "single GPU"
+    att_ms = sum(durs) / max(n_blocks, 1)
+    att_flop = 4.0 * q_rows * S * 64 * b_loc * H
     achieved = att_flop / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
     flop_step = B * L * (24.0 * S * d * d + 4.0 * S * S * d)
     traffic = None
@@ -193,12 +198,13 @@ def main():
         "dtype": "bf16",
         "data": "synthetic (random-init weights of the declared 12B architecture, N(0,1) latents + text embeddings)",
         "config": {"workload": cfg["desc"], "video_tokens": N_tok, "seq_len": S, "cfg_batch": 2,
-                   "parallelism": "single GPU" if world == 1 else f"sp{world} (video-token sequence parallel, K/V all-gather)",
+                   "parallelism": par,
                    "flop_per_step": flop_step, "step_mfma_frac": flop_step * K / elapsed / (PEAK_BF16_TFLOPS * 1e12 * world),
                    "finite_output": finite},
-        "roofline": {"bound": "mfma", "kernel": "attention_fwd_kernel (ea_attention_fwd_bf16)", "achieved": achieved,
-                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                     "flop_per_launch": att_flop, "avg_launch_ms": att_ms, "launches_timed": len(durs)},
+        "roofline": {"bound": "mfma", "kernel": "attention_fwd_v2_kernel (ea_attention_fwd_bf16 / _range_bf16)",
+                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                     "traffic": traffic, "flop_per_launch": att_flop, "avg_launch_ms": att_ms,
+                     "launches_timed": len(durs), "launches_per_block": len(durs) / max(n_blocks, 1)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dt, flop_sample, sample = cpu_baseline()

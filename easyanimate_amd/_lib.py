@@ -30,6 +30,7 @@ PROTOTYPES = {
     "ea_gemm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _I, _P],
     "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "ea_attention_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P],
+    "ea_attention_fwd_range_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_unpatchify": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ea_cfg_euler_step": [_P, _P, _L, _F, _F, _I, _I, _P],
@@ -63,6 +64,8 @@ def load() -> ctypes.CDLL:
     lib.ea_last_error_string.argtypes = []
     lib.ea_version.restype = c_int
     lib.ea_version.argtypes = []
+    lib.ea_attention_state_bytes.restype = c_int64
+    lib.ea_attention_state_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.ea_set_option.restype = c_int
     lib.ea_set_option.argtypes = [ctypes.c_char_p, c_int]
     _lib = lib

@@ -361,28 +361,66 @@ extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride,
     return ea_check_launch("ea_qknorm_rope_bf16");
 }
 
-extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
-                                     int64_t out_batch_stride, int batch, int heads, int seq, int s_pad, int q_begin,
-                                     int q_end, float scale, void* stream) {
-    EA_REQUIRE(q && k && vt && out, "ea_attention_fwd_bf16: null tensor");
-    EA_REQUIRE(batch > 0 && heads > 0 && seq > 0, "ea_attention_fwd_bf16: bad sizes");
-    EA_REQUIRE(s_pad % ATT_QB == 0 && s_pad >= seq, "ea_attention_fwd_bf16: s_pad must be a multiple of 256 and >= seq");
-    EA_REQUIRE(q_begin >= 0 && q_begin <= q_end && q_end <= seq, "ea_attention_fwd_bf16: bad query range");
+static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                            int64_t out_batch_stride, int batch, int heads, int s_pad, int q_begin, int q_end,
+                            int kv_begin, int kv_end, float scale, float* state, int flags, void* stream) {
+    EA_REQUIRE(q && k && vt && (out || (flags & 2)), "ea_attention_fwd: null tensor");
+    EA_REQUIRE(batch > 0 && heads > 0 && kv_end > kv_begin && kv_begin >= 0, "ea_attention_fwd: bad sizes");
+    EA_REQUIRE(s_pad % ATT_QB == 0 && s_pad >= kv_end, "ea_attention_fwd: s_pad must be a multiple of 256 and >= the key range");
+    EA_REQUIRE(q_begin >= 0 && q_begin <= q_end && q_end <= s_pad, "ea_attention_fwd: bad query range");
+    EA_REQUIRE(kv_begin % ATT_KV == 0, "ea_attention_fwd: kv_begin must be a multiple of 64");
+    EA_REQUIRE((flags & ~3) == 0 && (flags == 0 || state), "ea_attention_fwd: bad flags / missing state buffer");
     if (q_end == q_begin) return EA_OK;
-    const int qblk = g_attn_variant == 3 ? ATT3_QB : ATT_QB;
+    const bool plain = flags == 0 && kv_begin == 0;
+    const int variant = plain ? g_attn_variant : 2;   // key ranges / resumable state: the v2 kernel only
+    const int qblk = variant == 3 ? ATT3_QB : ATT_QB;
     const int nqb = (q_end - q_begin + qblk - 1) / qblk;
     const int bh = batch * heads;
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
-    EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd_bf16: grid too large");
+    EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd: grid too large");
     const float scale_log2e = scale * 1.4426950408889634f;
-    if (g_attn_variant == 1)
-        hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt,
-                           out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
-    else if (g_attn_variant == 3)
-        hipLaunchKernelGGL(attention_fwd_v3_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k,
-                           vt, out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* o16 = (unsigned short*)out;
+    f32x4* st4 = reinterpret_cast<f32x4*>(state);
+    if (variant == 1)
+        hipLaunchKernelGGL(attention_fwd_kernel, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh, kv_end,
+                           s_pad, q_begin, q_end, nqb, scale_log2e);
+    else if (variant == 3)
+        hipLaunchKernelGGL(attention_fwd_v3_kernel, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
+                           kv_end, s_pad, q_begin, q_end, nqb, scale_log2e);
+    else if (flags == 0)
+        hipLaunchKernelGGL(attention_fwd_v2_kernel<0>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
+                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
+    else if (flags == 1)
+        hipLaunchKernelGGL(attention_fwd_v2_kernel<1>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
+                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
+    else if (flags == 2)
+        hipLaunchKernelGGL(attention_fwd_v2_kernel<2>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
+                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
     else
-        hipLaunchKernelGGL(attention_fwd_v2_kernel, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k,
-                           vt, out, out_batch_stride, heads, bh, seq, s_pad, q_begin, q_end, nqb, scale_log2e);
-    return ea_check_launch("ea_attention_fwd_bf16");
+        hipLaunchKernelGGL(attention_fwd_v2_kernel<3>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
+                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
+    return ea_check_launch("ea_attention_fwd");
+}
+
+extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                     int64_t out_batch_stride, int batch, int heads, int seq, int s_pad, int q_begin,
+                                     int q_end, float scale, void* stream) {
+    EA_REQUIRE(q_end <= seq, "ea_attention_fwd_bf16: bad query range");
+    return attention_launch(q, k, vt, out, out_batch_stride, batch, heads, s_pad, q_begin, q_end, 0, seq, scale, nullptr, 0,
+                            stream);
+}
+
+extern "C" int64_t ea_attention_state_bytes(int batch, int heads, int q_begin, int q_end) {
+    const int64_t nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
+    return (int64_t)batch * heads * nqb * ATT_STATE_F4 * 256 * 16;
+}
+
+extern "C" int ea_attention_fwd_range_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                           int64_t out_batch_stride, int batch, int heads, int s_pad, int q_begin,
+                                           int q_end, int kv_begin, int kv_end, float scale, float* state, int flags,
+                                           void* stream) {
+    return attention_launch(q, k, vt, out, out_batch_stride, batch, heads, s_pad, q_begin, q_end, kv_begin, kv_end, scale,
+                            state, flags, stream);
 }

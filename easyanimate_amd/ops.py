@@ -213,6 +213,32 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scal
     return out
 
 
+def attention_state(B: int, H: int, q_begin: int, q_end: int, device) -> torch.Tensor:
+    """fp32 scratch for the resumable attention (ea_attention_state_bytes)."""
+    n = _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)
+    return torch.empty(n // 4, dtype=_F32, device=device)
+
+
+def attention_range(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float, q_begin: int, q_end: int,
+                    kv_begin: int, kv_end: int, state: Optional[torch.Tensor] = None, load_state: bool = False,
+                    store_state: bool = False, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Attention over the key range [kv_begin, kv_end) for query rows [q_begin, q_end); `state` carries the
+    online-softmax state between calls.  out: bf16 [B, >= q_end, H*64] (written unless store_state)."""
+    _dev(q, k, vt, out, state)
+    B, H, s_pad, dh = q.shape
+    assert dh == 64 and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    flags = (1 if load_state else 0) | (2 if store_state else 0)
+    if flags:
+        assert state is not None and state.dtype == _F32 and state.is_contiguous()
+        assert state.numel() * 4 >= _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)
+    if not store_state:
+        assert out is not None and out.stride(2) == 1 and out.stride(1) == H * 64 and out.shape[1] >= q_end
+    _timed("attention", lambda: _lib.call("ea_attention_fwd_range_bf16", _p(q), _p(k), _p(vt), _p(out),
+                                          out.stride(0) if out is not None else 0, B, H, s_pad, q_begin, q_end, kv_begin,
+                                          kv_end, float(scale), _p(state), flags, _stream()))
+    return out
+
+
 def patchify(latents: torch.Tensor, extra: Optional[torch.Tensor], k_pad: int) -> torch.Tensor:
     """latents [B,C,F,H,W] (+ extra [B,C2,F,H,W]) -> bf16 [B, F*(H/2)*(W/2), k_pad]."""
     _dev(latents, extra)

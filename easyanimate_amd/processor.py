@@ -26,12 +26,25 @@ def _workspace(B: int, H: int, s_pad: int, device) -> dict:
     key = (B, H, s_pad, str(device))
     ws = _ws.get(key)
     if ws is None:
-        _ws.clear()  # one live shape at a time keeps the footprint bounded
+        for k in [k for k in _ws if k[0] != "state"]:  # one live shape at a time keeps the footprint bounded
+            del _ws[k]
         ws = dict(q=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
                   k=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
                   vt=torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=device))
         _ws[key] = ws
     return ws
+
+
+def _attention_state(B: int, H: int, q_end: int, device) -> torch.Tensor:
+    """fp32 scratch of the resumable attention, one live shape at a time."""
+    key = ("state", B, H, q_end, str(device))
+    st = _ws.get(key)
+    if st is None:
+        for k in [k for k in _ws if k[0] == "state"]:
+            del _ws[k]
+        st = ops.attention_state(B, H, 0, q_end, device)
+        _ws[key] = st
+    return st
 
 
 def rope_to_device(image_rotary_emb, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -93,12 +106,13 @@ class EasyAnimateAttnProcessor2_0:
             ops.gemm(e, bf16_weight(lt.weight), f32(lt.bias), ops.EPI_BIAS, out=qkv_t[:, :, i * d:(i + 1) * d])
 
         # ---- qk LayerNorm + RoPE + head-major scatter; text rows first, then video (torch.cat at :277-279)
+        lay = None
         if sp is not None:
-            S, q_begin, q_end, seq_off_v, s_pad = sp.layout(T, N)
+            lay = sp.layout(T, N)   # per-rank rows: [text | own shard | remote shards | pad]
+            S, s_pad, v_off = lay.q_end, lay.s_pad, lay.v_off
         else:
             S = T + N
-            s_pad = ops.round_up(S, 256)
-            q_begin, q_end, seq_off_v = 0, S, T
+            s_pad, v_off = ops.round_up(S, 256), T
         ws = _workspace(B, H, s_pad, dev)
         cos = sin = None
         if image_rotary_emb is not None:
@@ -108,20 +122,29 @@ class EasyAnimateAttnProcessor2_0:
         ops.qknorm_rope(qkv_t, ws["q"], ws["k"], ws["vt"], f32(tattn.norm_q.weight), f32(tattn.norm_q.bias),
                         f32(tattn.norm_k.weight), f32(tattn.norm_k.bias), None, None, 0, tattn.norm_q.eps)
         ops.qknorm_rope(qkv_v, ws["q"], ws["k"], ws["vt"], f32(attn.norm_q.weight), f32(attn.norm_q.bias),
-                        f32(attn.norm_k.weight), f32(attn.norm_k.bias), cos, sin, seq_off_v, attn.norm_q.eps)
-        if sp is not None:
-            sp.exchange_kv(ws, T, N)
+                        f32(attn.norm_k.weight), f32(attn.norm_k.bias), cos, sin, v_off, attn.norm_q.eps)
 
-        # ---- joint attention (processor.py:287-291)
+        # ---- joint attention (processor.py:287-291): queries = text rows + this rank's video rows
         o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
-        if sp is not None:
-            # replicated text queries (bit-identical on every rank) + this rank's video queries
-            ops.attention(ws["q"], ws["k"], ws["vt"], S, 1.0 / 8.0, out=o, q_begin=0, q_end=T)
-        ops.attention(ws["q"], ws["k"], ws["vt"], S, 1.0 / 8.0, out=o, q_begin=q_begin, q_end=q_end)
-        if sp is not None:
-            o_t, o_v = sp.split_output(o, T, N)
+        if lay is not None and lay.remote_end > lay.remote_begin:
+            # sequence-parallel: attend the local keys while the K / V^T all-gather is in flight, then resume the
+            # online-softmax state over the remote keys (ea_attention_fwd_range_bf16)
+            pending = sp.exchange_start(ws, v_off)
+            state = _attention_state(B, H, S, dev)
+            for i, (lo, hi) in enumerate(lay.local_ranges):
+                ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, lo, hi, state=state, load_state=i > 0,
+                                    store_state=True)
+            sp.exchange_finish(pending, ws, v_off)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, lay.remote_begin, lay.remote_end,
+                                state=state, load_state=True, out=o)
+        elif v_off != T:
+            # single sequence rank with unaligned text: rows [T, v_off) are padding between the two key ranges
+            state = _attention_state(B, H, S, dev)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, 0, T, state=state, store_state=True)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, v_off, S, state=state, load_state=True, out=o)
         else:
-            o_t, o_v = o[:, :T], o[:, T:]
+            ops.attention(ws["q"], ws["k"], ws["vt"], S, 1.0 / 8.0, out=o)
+        o_t, o_v = o[:, :T], o[:, v_off:]
 
         # ---- output projections (:293-311), optionally with the gated residual fused (attention.py:1140-1141)
         lo_v, lo_t = attn.to_out[0], tattn.to_out[0]

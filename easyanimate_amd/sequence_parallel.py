@@ -1,22 +1,41 @@
-"""Sequence parallelism over the video-token axis (new capability; the reference has no multi-GPU inference,
-SURVEY.md 5.7 / 8e).  One process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).
+"""Multi-GPU sampling: CFG parallelism x sequence parallelism over the video-token axis (new capability; the
+reference has no multi-GPU inference).  One process per GPU, `torch.distributed` (backend "nccl"
+== RCCL over xGMI).  All weights and the T text tokens are replicated.
 
-Design A of SURVEY 5.7: every rank owns a contiguous shard of the N video tokens (shard stride n_loc, a multiple
-of 64; only the last ranks may be short), the T text tokens and all weights are replicated.  All per-token work
-(norms, QKV/out/FFN GEMMs, RoPE, residuals) is local.  The only exchange per block is an all-gather of the
-K and V^T shards; each rank then attends its own queries (its video rows + the replicated text rows) over the
-full key/value set.  One more all-gather returns the velocity prediction to every rank so that all ranks run the
-identical scheduler step.
+Two orthogonal axes, chosen per forward call:
 
-Global row layout of the attention buffers:  [ text 0..T | rank0 video | rank1 video | ... | pad ]  -- padding
-only ever sits at the end (rows >= T+N), where ea_attention_fwd_bf16 masks it.
+* **CFG axis** (only when the call carries the CFG pair, batch == 2, and the world size is even): ranks
+  [0, P/2) run the first batch element, ranks [P/2, P) the second.  Nothing is exchanged between the halves until the
+  final velocity prediction -- at P = 2 a denoise step has no per-block communication at all, and at P = 8 every
+  per-block exchange moves 2.3x fewer bytes than an 8-way sequence split of both batch elements would.
+* **Sequence axis** (the remaining P' = P or P/2 ranks of a half): rank r owns a contiguous shard of the N video
+  tokens (shard stride n_loc, a multiple of 64; only the last rank may be short).  All per-token work (norms,
+  QKV / out / FFN GEMMs, RoPE, residuals) is local.  The one exchange per block is an all-gather of the K rows /
+  V^T columns of the shards.  It is *asynchronous*: while it is in flight the rank already attends its queries over
+  its LOCAL keys (text + own shard) with `ea_attention_fwd_range_bf16(..., flags=store state)`; when the remote
+  shards have landed a second launch resumes from that state over the REMOTE keys.  Softmax does not care about the
+  key order, so each rank keeps a private row layout
 
-This module contains communication and indexing only (no arithmetic); it works on any device, so the exchange
-is covered by gloo/CPU tests (tests/test_sequence_parallel_cpu.py).
+        [ text 0..T | (gap to a multiple of 64) | own shard | remote shards in rank order | pad ]
+
+  in which the query range and the remote key range are contiguous (the local keys are one range, or two when T is not
+  a multiple of 64); padding inside a short last shard is never part of a key range (a range may end anywhere, it only
+  has to start on a multiple of 64).
+
+One more all-gather (whole world) returns the velocity prediction of both batch elements / all shards to every rank,
+so that all ranks run the identical scheduler step.
+
+The text stream is replicated, not synchronised: its attention rows are accumulated in a rank-dependent key order, so
+the replicas agree to fp32-accumulation-order noise, not bit for bit (the values every rank feeds back are rounded to
+bf16 each block; measured drift is at the bf16 noise floor of the model).
+
+This module contains communication and indexing only (no arithmetic); it works on any device, so the exchange is
+covered by gloo/CPU tests (tests/test_sequence_parallel_cpu.py).
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -26,29 +45,73 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-class SequenceParallel:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, comm_stream=None):
+@dataclass
+class Layout:
+    """Row layout of this rank's attention buffers for one block (see module docstring)."""
+    T: int             # text rows [0, T)
+    v_off: int         # first row of the own shard = round_up(T, 64): key ranges must start on a multiple of 64
+    n_own: int         # valid rows of the own shard
+    n_loc: int         # shard stride
+    s_pad: int         # rows of the q / k / v^T workspaces
+    q_end: int         # queries are rows [0, q_end) (text, [alignment gap,] own shard)
+    local_ranges: List[Tuple[int, int]]  # local keys: [0, T + n_own) or, if T % 64 != 0, [0, T) and [v_off, v_off + n_own)
+    remote_begin: int  # remote keys [remote_begin, remote_end)   (empty when the sequence axis has one rank)
+    remote_end: int
+
+
+class _Axis:
+    """One partition of the world: `groups` sequence-parallel groups of `size` consecutive ranks each."""
+
+    def __init__(self, world: int, rank: int, cfg_degree: int, group):
+        self.cfg_degree = cfg_degree
+        self.size = world // cfg_degree
+        self.cfg_rank = rank // self.size
+        self.rank = rank % self.size
         self.group = group
+
+
+class SequenceParallel:
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, cfg_parallel: bool = True):
+        self.world_group = group
         self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.world_rank = dist.get_rank(group)
+        # flat axis: every rank is a sequence shard of every batch element
+        self._flat = _Axis(self.world, self.world_rank, 1, group)
+        self._cfg = None
+        if cfg_parallel and self.world % 2 == 0:
+            half = self.world // 2
+            base = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
+            mine = None
+            for c in range(2):  # every rank creates every sub-group (collective call)
+                g = dist.new_group([base[c * half + i] for i in range(half)])
+                if self.world_rank // half == c:
+                    mine = g
+            self._cfg = _Axis(self.world, self.world_rank, 2, mine)
+        self.axis = self._flat
         self.n_total = 0
         self.n_loc = 0
 
-    def _all_gather_flat(self, recv: torch.Tensor, send: torch.Tensor) -> None:
-        """recv[world*n] <- concat over ranks of send[n].  RCCL ("nccl") gathers device buffers directly over xGMI.
-        The gloo backend (used only by the CPU / single-GPU tests) cannot gather device tensors into one buffer, so
-        device tensors are staged through host memory there."""
-        if send.is_cuda and dist.get_backend(self.group) == "gloo":
-            r = torch.empty(recv.shape, dtype=recv.dtype, device="cpu")
-            dist.all_gather_into_tensor(r, send.cpu(), group=self.group)
-            recv.copy_(r)
-        else:
-            dist.all_gather_into_tensor(recv, send, group=self.group)
+    # ---- per-call mode ------------------------------------------------------------------------
+    def begin(self, batch: int) -> Tuple[int, int]:
+        """Pick the partition for a forward call with `batch` elements; returns this rank's batch slice."""
+        if self._cfg is not None and batch == 2:
+            self.axis = self._cfg
+            return self.axis.cfg_rank, self.axis.cfg_rank + 1
+        self.axis = self._flat
+        return 0, batch
+
+    @property
+    def rank(self) -> int:
+        return self.axis.rank
+
+    @property
+    def size(self) -> int:
+        return self.axis.size
 
     # ---- token partition ----------------------------------------------------------------------
     def plan(self, n_total: int) -> None:
         self.n_total = n_total
-        self.n_loc = _round_up((n_total + self.world - 1) // self.world, 64)
+        self.n_loc = _round_up((n_total + self.size - 1) // self.size, 64)
 
     def shard_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
         r = self.rank if rank is None else rank
@@ -57,11 +120,11 @@ class SequenceParallel:
         return lo, hi
 
     def shard_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """[B, N, C] -> this rank's [B, n_valid, C] (contiguous)."""
+        """[B, N, C] -> this rank's [B, n_own, C] (contiguous)."""
         self.plan(x.shape[1])
+        if self.shard_range(self.size - 1)[1] - self.shard_range(self.size - 1)[0] <= 0:
+            raise ValueError(f"sequence parallel: the last rank would own no tokens (N={x.shape[1]}, P={self.size})")
         lo, hi = self.shard_range()
-        if hi <= lo:
-            raise ValueError(f"sequence parallel: rank {self.rank} would own no tokens (N={x.shape[1]}, P={self.world})")
         return x[:, lo:hi].contiguous()
 
     def shard_rope(self, rope, device):
@@ -71,55 +134,90 @@ class SequenceParallel:
                 sin[lo:hi].to(device=device, dtype=torch.float32).contiguous())
 
     # ---- attention layout ---------------------------------------------------------------------
-    def layout(self, T: int, n_valid: int):
-        """-> (S_global, q_begin, q_end, seq_off_video, s_pad) for this rank's video queries."""
+    def layout(self, T: int, n_own: int) -> Layout:
         lo, hi = self.shard_range()
-        assert hi - lo == n_valid, "hidden-state shard does not match the plan"
-        S = T + self.n_total
-        s_pad = _round_up(T + self.world * self.n_loc, 256)
-        return S, T + lo, T + hi, T + lo, s_pad
+        assert hi - lo == n_own, "hidden-state shard does not match the plan"
+        nl, P = self.n_loc, self.size
+        v_off = _round_up(T, 64)
+        s_pad = _round_up(v_off + P * nl, 256)
+        last = self.shard_range(P - 1)
+        n_last = last[1] - last[0]
+        remote_valid = 0 if P == 1 else ((P - 1) * nl if self.rank == P - 1 else (P - 2) * nl + n_last)
+        local = [(0, T + n_own)] if v_off == T else [(0, T), (v_off, v_off + n_own)]
+        return Layout(T=T, v_off=v_off, n_own=n_own, n_loc=nl, s_pad=s_pad, q_end=v_off + n_own, local_ranges=local,
+                      remote_begin=v_off + nl, remote_end=v_off + nl + remote_valid)
 
-    def exchange_kv(self, ws: dict, T: int, n_valid: int) -> None:
-        """All-gather the K rows / V^T columns of every rank's video shard into the full-sequence buffers.
-        ws["k"]: [B,H,s_pad,64], ws["vt"]: [B,H,64,s_pad]; this rank has already written its own shard."""
-        if self.world == 1:
-            return
+    def slot(self, src_rank: int) -> int:
+        """Row-slot (in units of n_loc after the text rows) of rank src_rank's shard in THIS rank's buffers."""
+        if src_rank == self.rank:
+            return 0
+        return 1 + (src_rank if src_rank < self.rank else src_rank - 1)
+
+    def _gloo_device_staging(self, t: torch.Tensor) -> bool:
+        return t.is_cuda and dist.get_backend(self.axis.group) == "gloo"
+
+    def exchange_start(self, ws: dict, v_off: int):
+        """Start the all-gather of every rank's own K rows / V^T columns (rows [v_off, v_off+n_loc) of its buffers).
+        Returns a handle for exchange_finish.  With RCCL the collective runs on the process group's stream, behind
+        everything already queued on the current stream, and the caller keeps launching compute."""
+        if self.size == 1:
+            return None
         k, vt = ws["k"], ws["vt"]
         B, H = k.shape[0], k.shape[1]
         nl = self.n_loc
-        off = T + self.rank * nl
         send = torch.empty((2, B, H, nl * 64), dtype=k.dtype, device=k.device)
-        send[0] = k[:, :, off:off + nl].reshape(B, H, nl * 64)
-        send[1] = vt[:, :, :, off:off + nl].reshape(B, H, 64 * nl)
-        recv = torch.empty((self.world * send.numel(),), dtype=k.dtype, device=k.device)
-        self._all_gather_flat(recv, send.view(-1))  # flat buffers: accepted by nccl/RCCL and gloo
-        recv = recv.view((self.world,) + tuple(send.shape))
-        for r in range(self.world):
+        send[0] = k[:, :, v_off:v_off + nl].reshape(B, H, nl * 64)
+        send[1] = vt[:, :, :, v_off:v_off + nl].reshape(B, H, 64 * nl)
+        if self._gloo_device_staging(send):
+            # gloo (CPU / shared-GPU tests only) cannot gather device tensors into one buffer: stage through the host
+            r = torch.empty((self.size * send.numel(),), dtype=send.dtype, device="cpu")
+            dist.all_gather_into_tensor(r, send.view(-1).cpu(), group=self.axis.group)
+            return (None, r.to(send.device), send)
+        recv = torch.empty((self.size * send.numel(),), dtype=k.dtype, device=k.device)
+        work = dist.all_gather_into_tensor(recv, send.view(-1), group=self.axis.group, async_op=True)
+        return (work, recv, send)
+
+    def exchange_finish(self, handle, ws: dict, v_off: int) -> None:
+        """Wait for the all-gather (a stream-level wait with RCCL) and scatter the remote shards into their slots."""
+        if handle is None:
+            return
+        work, recv, send = handle
+        if work is not None:
+            work.wait()
+        k, vt = ws["k"], ws["vt"]
+        B, H = k.shape[0], k.shape[1]
+        nl = self.n_loc
+        recv = recv.view((self.size,) + tuple(send.shape))
+        for r in range(self.size):
             if r == self.rank:
                 continue
-            o = T + r * nl
+            o = v_off + self.slot(r) * nl
             k[:, :, o:o + nl] = recv[r, 0].reshape(B, H, nl, 64)
             vt[:, :, :, o:o + nl] = recv[r, 1].reshape(B, H, 64, nl)
 
-    def split_output(self, o: torch.Tensor, T: int, n_valid: int):
-        lo, hi = self.shard_range()
-        return o[:, :T], o[:, T + lo:T + hi]
-
+    # ---- final prediction ---------------------------------------------------------------------
     def gather_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """[B, n_valid, C] shards -> [B, N, C] on every rank."""
+        """This rank's [b_loc, n_own, C] -> the full [batch, N, C] on every rank (one world-wide all-gather)."""
         if self.world == 1:
             return x
-        B, n, C = x.shape
-        send = torch.zeros((B, self.n_loc, C), dtype=x.dtype, device=x.device)
+        b, n, C = x.shape
+        send = torch.zeros((b, self.n_loc, C), dtype=x.dtype, device=x.device)
         send[:, :n] = x
-        recv = torch.empty((self.world * send.numel(),), dtype=x.dtype, device=x.device)
-        self._all_gather_flat(recv, send.view(-1))
-        recv = recv.view(self.world, B, self.n_loc, C)
-        return recv.permute(1, 0, 2, 3).reshape(B, self.world * self.n_loc, C)[:, :self.n_total].contiguous()
+        if send.is_cuda and dist.get_backend(self.world_group) == "gloo":
+            r = torch.empty((self.world * send.numel(),), dtype=x.dtype, device="cpu")
+            dist.all_gather_into_tensor(r, send.view(-1).cpu(), group=self.world_group)
+            recv = r.to(x.device)
+        else:
+            recv = torch.empty((self.world * send.numel(),), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(recv, send.view(-1), group=self.world_group)
+        # world rank = cfg_rank * size + seq_rank
+        recv = recv.view(self.axis.cfg_degree, self.size, b, self.n_loc, C)
+        out = recv.permute(0, 2, 1, 3, 4).reshape(self.axis.cfg_degree * b, self.size * self.n_loc, C)
+        return out[:, :self.n_total].contiguous()
 
 
-def enable(transformer, group: Optional[dist.ProcessGroup] = None) -> SequenceParallel:
-    """Attach sequence parallelism to an EasyAnimateTransformer3DModel (all ranks hold identical weights)."""
-    sp = SequenceParallel(group)
+def enable(transformer, group: Optional[dist.ProcessGroup] = None, cfg_parallel: bool = True) -> SequenceParallel:
+    """Attach multi-GPU sampling to an EasyAnimateTransformer3DModel (all ranks hold identical weights)."""
+    sp = SequenceParallel(group, cfg_parallel=cfg_parallel)
     transformer.sequence_parallel = sp if sp.world > 1 else None
     return sp

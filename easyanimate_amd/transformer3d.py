@@ -214,6 +214,15 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
         in_dtype = hidden_states.dtype
         p = self.patch_size
         sp = self.sequence_parallel
+        if sp is not None:
+            # multi-GPU: this rank's batch slice (CFG axis) -- the token shard (sequence axis) is cut after patchify
+            b0, b1 = sp.begin(batch_size)
+            if (b0, b1) != (0, batch_size):
+                cut = lambda x: None if x is None else x[b0:b1]
+                hidden_states, encoder_hidden_states = cut(hidden_states), cut(encoder_hidden_states)
+                timestep = timestep if timestep.numel() == 1 else timestep.reshape(-1)[b0:b1]
+                encoder_hidden_states_t5, inpaint_latents, control_latents = cut(encoder_hidden_states_t5), cut(inpaint_latents), cut(control_latents)
+                batch_size = b1 - b0
 
         # 1. time embedding
         temb = self.time_embed(timestep, batch_size, bf16_round=in_dtype != torch.float32)

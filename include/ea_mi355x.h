@@ -118,6 +118,20 @@ int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt,
                           int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
                           int q_begin, int q_end, float scale, void* stream);
 
+/* The same attention, resumable over key ranges: keys [kv_begin, kv_end) only (kv_begin % 64 == 0, kv_end
+ * arbitrary), with the online-softmax state (un-normalised O, running max, partial row sums; fp32) carried in a
+ * caller-owned `state` buffer of ea_attention_state_bytes(batch, heads, q_begin, q_end) bytes:
+ *   flags bit 0: start from `state` instead of the empty state;  bit 1: write `state` instead of `out`.
+ * A sequence-parallel rank runs {its local keys, flags 2} while the all-gather of the remote K / V^T shards is in
+ * flight and then {remote keys, flags 1}: softmax is invariant to the key order, so the result is the full
+ * attention (new capability: the reference has no multi-GPU inference).  Both calls must use
+ * the same batch / heads / q_begin / q_end.  q_end <= s_pad. */
+int64_t ea_attention_state_bytes(int batch, int heads, int q_begin, int q_end);
+int ea_attention_fwd_range_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                int64_t out_batch_stride, int batch, int heads, int s_pad, int q_begin,
+                                int q_end, int kv_begin, int kv_end, float scale, float* state, int flags,
+                                void* stream);
+
 /* ---- latent-space elementwise ---------------------------------------------------------------- */
 
 /* Patchify gather for the 2x2/stride-2 Conv2d patch embedding (transformer3d.py:1523-1531):

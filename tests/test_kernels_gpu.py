@@ -339,6 +339,31 @@ def test_attention_v2_matches_v1_large():
     _lib.set_option("attn_variant", 2)
 
 
+@pytest.mark.parametrize("splits", [(0, 320, 1000), (0, 64, 128, 1000), (0, 960, 1000), (0, 256, 576, 999)])
+def test_attention_resumable_key_ranges(splits):
+    """ea_attention_fwd_range_bf16: chaining key ranges through the fp32 state equals the one-shot attention (the
+    sequence-parallel overlap path).  Ranges are visited OUT of order (softmax is order invariant); ragged last range."""
+    ops = _ops()
+    B, H = 2, 3
+    S = splits[-1]
+    q, k, vt, v = _attn_inputs(B, H, S, 31, scale_q=1.5)
+    k[:, 1, 700] = q[:, 1, 5] * 6     # a spike inside a late range
+    ref = _attn_ref(q, k, v, S)
+    qb, qe = 64, 900                   # a query sub-range, as a rank would own
+    out = torch.full((B, S, H * 64), 3.0, dtype=torch.bfloat16, device=DEV)
+    st = ops.attention_state(B, H, qb, qe, DEV)
+    ranges = list(zip(splits[:-1], splits[1:]))
+    order = ranges[1:] + ranges[:1]    # start with the second range, finish with the first
+    for i, (lo, hi) in enumerate(order):
+        ops.attention_range(q, k, vt, 0.125, qb, qe, lo, hi, state=st, load_state=i > 0,
+                            store_state=i < len(order) - 1, out=out)
+    err, rel = _report(f"attention ranges {splits}", out[:, qb:qe], ref[:, qb:qe])
+    assert rel < 8e-3 and err < 0.05
+    assert (out[:, :qb] == 3.0).all() and (out[:, qe:] == 3.0).all()
+    one = ops.attention(q, k, vt, S, 0.125, q_begin=qb, q_end=qe)
+    assert (out[:, qb:qe].float() - one[:, qb:qe].float()).abs().max().item() < 0.02
+
+
 def test_attention_query_range():
     """Sequence-parallel use: only rows [q_begin, q_end) are produced, the rest of `out` is untouched."""
     ops = _ops()

@@ -1,6 +1,7 @@
-"""The PRODUCT sequence-parallel path (HIP kernels + SequenceParallel layer) on the GPU box: 2 ranks that share
-cuda:0, gloo rendezvous (RCCL refuses two ranks on one device; the collective itself is covered by the driver's
-multi-GPU bench).  The sharded transformer forward must equal the single-rank forward."""
+"""The PRODUCT multi-GPU path (HIP kernels + SequenceParallel layer) on the 1-GPU box: 2-4 ranks that share cuda:0,
+gloo rendezvous (RCCL refuses two ranks on one device; the collective itself is covered by the driver's multi-GPU
+bench).  The sharded transformer forward -- CFG split, sequence split with the resumable two-range attention, and
+both -- must equal the single-rank forward."""
 import os
 import socket
 
@@ -21,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, cfg_parallel, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -40,26 +41,30 @@ def _worker(rank, world, port, ret):
         rope = get_3d_rotary_pos_embed(64, ((0, 8), (30, 38)), (16, 12), 5)
         with torch.no_grad():
             ref = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
-            sp = sequence_parallel.enable(m)
+            sp = sequence_parallel.enable(m, cfg_parallel=cfg_parallel)
             assert m.sequence_parallel is sp and sp.world == world
             out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
             out2 = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]  # workspace reuse
         err = (out.float() - ref.float()).abs().max().item()
-        ret[rank] = (err, ref.float().abs().max().item(), torch.equal(out, out2), sp.shard_range())
+        ret[rank] = (err, ref.float().abs().max().item(), torch.equal(out, out2), sp.shard_range(), sp.size)
     finally:
         dist.destroy_process_group()
 
 
-def test_sp_transformer_equals_single_rank():
-    world = 2
+@pytest.mark.parametrize("world,cfg_parallel", [(2, True), (2, False), (4, True), (3, True)])
+def test_sp_transformer_equals_single_rank(world, cfg_parallel):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), cfg_parallel, ret), nprocs=world, join=True)
     assert len(ret) == world
-    print("[parity] sp2 vs single:", dict(ret))
+    print(f"[parity] world {world} cfg_parallel {cfg_parallel} vs single:", dict(ret))
+    seq = world // 2 if (cfg_parallel and world % 2 == 0) else world
+    n_loc = {1: 960, 2: 512, 3: 320}[seq]
     for r in range(world):
-        err, scale, same, rng = ret[r]
-        # identical kernels on identical rows; only the attention q-block decomposition differs (fp32 online-softmax
-        # order is per-row, so results are expected bit-equal or within one bf16 ulp)
+        err, scale, same, rng, size = ret[r]
+        # identical kernels on identical rows; the attention accumulates the keys in a rank-dependent order (fp32),
+        # and the replicated text stream is not synchronised: agreement to bf16 rounding noise
         assert err <= 2e-2 * max(1.0, scale) and same
-    assert ret[0][3] == (0, 512) and ret[1][3] == (512, 960)
+        assert size == seq
+        sr = r % seq
+        assert rng == (min(sr * n_loc, 960), min((sr + 1) * n_loc, 960))
