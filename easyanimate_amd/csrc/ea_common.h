@@ -43,12 +43,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// tanh-approximate GELU exactly as torch: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))
+// tanh-approximate GELU as torch defines it, 0.5*x*(1+tanh(u)) with u = sqrt(2/pi)*(x+0.044715x^3), evaluated as
+// x * sigmoid(2u) = x / (1 + 2^(-2u*log2(e))): 5 plain VALU + v_exp_f32 + v_rcp_f32 (the GEMM epilogue runs it on
+// 128 values per thread with no MFMA work left to hide it under).
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1)
-    float e = __expf(2.0f * u);
-    float t = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + t);
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;   // -2*sqrt(2/pi)*log2(e)
+    const float c1 = c0 * 0.044715f;
+    const float a = x * __builtin_fmaf(x * x, c1, c0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }

@@ -237,6 +237,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 //     1000-1500 cycles later) in phase 3 before that phase's first barrier; phase 3 also retires its own ds_reads
 //     before that barrier, which is what frees the stage for the DMA issued two barriers later.
 //   * same operand roles / row swizzles / epilogue as the 128^2 kernel (C^T tiles, swap-2/3 W rows, 16-byte stores).
+#ifdef EA_GEMM_TIMESTAMPS
+__device__ unsigned long long* g_gemm_ts = nullptr;   // diagnostic builds: per-workgroup s_memtime stamps
+#endif
 constexpr int OPER2 = 256 * 128;   // one operand tile, 32 KiB
 constexpr int GEMM2_LDS = 4 * OPER2;
 
@@ -249,6 +252,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     const int wr = wave >> 2, wc = wave & 3;
     const int hi = lane >> 5, l31 = lane & 31;
 
+#ifdef EA_GEMM_TIMESTAMPS
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
     int tm, tn;
     if (!tile_of_block(p, tm, tn)) return;
     const int b = blockIdx.y;
@@ -343,6 +349,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#ifdef EA_GEMM_TIMESTAMPS
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
     if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
@@ -356,27 +365,120 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+#ifdef EA_GEMM_TIMESTAMPS
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
 #undef EA_G2_TILE
 #undef EA_G2_PHASE
 
-    // ---- epilogue: lane owns row m, columns n0..n0+7 per (j, g)
+    // ---- epilogue.  bf16 outputs go through LDS (free now: every wave is past its last operand read) so that HBM
+    // sees whole 128-byte rows: in accumulator layout a store instruction covers 32 rows x 32 B (partial lines, and
+    // for the gated-residual epilogue the same pattern on the residual loads); staged, it covers 8 rows x 128 B.
+    // Each wave owns a private 16 KiB image of its 128 x 64 output tile (rows of 128 B, 16-byte chunks XOR-swizzled
+    // with (row>>1)&7 like the operand tiles), so no workgroup barrier is needed.
+    if (EPI == EA_EPI_F32_OUT) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = row0 + wr * 128 + i * 32 + l31;
-        if (m >= p.M) continue;
+        for (int i = 0; i < 4; ++i) {
+            const int m = row0 + wr * 128 + i * 32 + l31;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int n0 = col0 + wc * 64 + j * 32 + g * 16 + hi * 8;
+                    if (n0 >= p.N) continue;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
+                    epilogue8<EPI>(p, b, m, n0, v);
+                }
+            }
+        }
+        return;
+    }
+    char* const img = smem + wave * 16384;
+    const int mrow0 = row0 + wr * 128, ncol0 = col0 + wc * 64;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    if (EPI == EA_EPI_BIAS_GATE_RES) {
+        // residual tile -> LDS image by LDS-DMA (source-side swizzle, rows clamped at the M tail)
+        const unsigned short* Rb = p.res + b * p.rbs;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = q * 8 + r8;
+            int m = mrow0 + r;
+            m = m < p.M ? m : p.M - 1;
+            int n = ncol0 + ((c8 ^ ((r >> 1) & 7)) << 3);
+            n = n < p.N ? n : 0;                                   // N tail: any in-bounds address, never used
+            glds16(Rb + (int64_t)m * p.ldres + n, img + q * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        const float* gb = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs : nullptr;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const int n0 = col0 + wc * 64 + j * 32 + g * 16 + hi * 8;
-                if (n0 >= p.N) continue;
-                float v[8];
+                const int ch = j * 4 + g * 2 + hi;          // 16-byte chunk of the wave's 64 columns
+                const int n0 = ncol0 + ch * 8;
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, g0 = b0, g1 = b0;
+                if (n0 >= p.N) continue;                           // N tail (N % 8 == 0): whole chunk outside
+                if (p.bias) {
+                    b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+                }
+                if (EPI == EA_EPI_BIAS_GATE_RES) {
+                    g0 = *reinterpret_cast<const f32x4*>(gb + n0);
+                    g1 = *reinterpret_cast<const f32x4*>(gb + n0 + 4);
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
-                epilogue8<EPI>(p, b, m, n0, v);
+                for (int i = 0; i < 4; ++i) {
+                    const int r = i * 32 + l31;
+                    char* cell = img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][g * 8 + e] + b0[e];
+                        v[4 + e] = acc[i][j][g * 8 + 4 + e] + b1[e];
+                    }
+                    if (EPI == EA_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                    }
+                    if (EPI == EA_EPI_BIAS_GATE_RES) {
+                        const u16x8 rr = *reinterpret_cast<const u16x8*>(cell);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = bf16_bits_to_f32(rr[e]) + g0[e] * v[e];
+                            v[4 + e] = bf16_bits_to_f32(rr[4 + e]) + g1[e] * v[4 + e];
+                        }
+                    }
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+                    *reinterpret_cast<u16x8*>(cell) = o;
+                }
             }
         }
     }
+    // the image is wave-private: the wave's own LDS accesses complete in order, no barrier
+    unsigned short* Cb = p.C + b * p.cbs;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = q * 8 + r8;
+        const int m = mrow0 + r;
+        const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
+        if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8) = o;
+    }
+#ifdef EA_GEMM_TIMESTAMPS
+    if (g_gemm_ts && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g_gemm_ts + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 5;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
+        d[4] = 0;
+    }
+#endif
 }
 
 template <int EPI>
@@ -445,6 +547,12 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
 }
 
 int ea_attn_variant_set(int v);
+
+#ifdef EA_GEMM_TIMESTAMPS
+extern "C" int ea_debug_gemm_timestamps(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_ts), &buf, sizeof(void*));
+}
+#endif
 
 extern "C" int ea_set_option(const char* name, int value) {
     EA_REQUIRE(name, "ea_set_option: null name");
