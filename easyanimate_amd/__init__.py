@@ -14,6 +14,8 @@ _LAZY = {
     "FlowMatchEulerDiscreteScheduler": "scheduler",
     "EasyAnimatePipeline": "pipeline",
     "EasyAnimateInpaintPipeline": "pipeline",
+    "TeaCache": "teacache",
+    "get_teacache_coefficients": "teacache",
     "name_to_transformer3d": "registry",
     "name_to_autoencoder_magvit": "registry",
 }

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_unpatchify": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ea_cfg_euler_step": [_P, _P, _L, _F, _F, _I, _I, _P],
+    "ea_teacache_rel_l1_bf16": [_P, _P, _L, _P, _I, _P, _P],
+    "ea_bf16_binary": [_P, _P, _P, _L, _I, _P],
     "ea_conv3d_cl_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_im2col3d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_groupnorm_stats_bf16": [_P, _P, _P, _I, _L, _I, _I, _I, _F, _P],

@@ -141,3 +141,102 @@ extern "C" int ea_cfg_euler_step(const void* v, void* latents, int64_t n, float 
         hipLaunchKernelGGL(cfg_euler_kernel<false>, grid, dim3(256), 0, st, v, latents, n, guidance, dsigma, do_cfg);
     return ea_check_launch("ea_cfg_euler_step");
 }
+
+// ------------------------------------------------------------------------------------------------
+// TeaCache on device (reference: easyanimate/models/transformer3d.py:90-121, 1564-1590, 1635).
+// The reference moves two [B,N,d] tensors to the host every step and reduces them there; here the rel-L1 numerator
+// and denominator are reduced on the device (8 bytes leave the GPU per step) and the residual stays resident.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// sums[0] += sum |bf16(cur - prev)| , sums[1] += sum |prev| over one contiguous chunk per block; the second stage adds
+// the per-block partials in a fixed order (deterministic, bit-identical on every rank for identical data).
+__global__ __launch_bounds__(256) void rel_l1_partial_kernel(const unsigned short* __restrict__ cur,
+                                                             const unsigned short* __restrict__ prev, int64_t n,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[2][4];
+    const int64_t per = ((n / 8 + gridDim.x - 1) / gridDim.x) * 8;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    int64_t hi = lo + per;
+    hi = hi < n ? hi : n;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = lo + (int64_t)threadIdx.x * 8; i + 8 <= hi; i += 256 * 8) {
+        const u16x8 c = *reinterpret_cast<const u16x8*>(cur + i);
+        const u16x8 p = *reinterpret_cast<const u16x8*>(prev + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float pf = bf16_bits_to_f32(p[e]);
+            // torch: (cur - prev) is a bf16 tensor (rounded), abs() of it is exact
+            s1 += fabsf(bf16_bits_to_f32(f32_to_bf16_bits(bf16_bits_to_f32(c[e]) - pf)));
+            s2 += fabsf(pf);
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ void rel_l1_final_kernel(const float* __restrict__ partial, int nblk, double* __restrict__ sums) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < nblk; ++i) {
+            a += (double)partial[2 * i];
+            b += (double)partial[2 * i + 1];
+        }
+        sums[0] = a;
+        sums[1] = b;
+    }
+}
+
+template <int OP>  // 0: out = a - b    1: out = a + b      (bf16 in/out, fp32 arithmetic, one rounding: == torch bf16 ops)
+__global__ __launch_bounds__(256) void bf16_binary_kernel(const unsigned short* __restrict__ a,
+                                                          const unsigned short* __restrict__ b,
+                                                          unsigned short* __restrict__ out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const u16x8 x = reinterpret_cast<const u16x8*>(a)[i];
+        const u16x8 y = reinterpret_cast<const u16x8*>(b)[i];
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xf = bf16_bits_to_f32(x[e]), yf = bf16_bits_to_f32(y[e]);
+            o[e] = f32_to_bf16_bits(OP == 0 ? xf - yf : xf + yf);
+        }
+        reinterpret_cast<u16x8*>(out)[i] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int ea_teacache_rel_l1_bf16(const ea_bf16* cur, const ea_bf16* prev, int64_t n, float* partial, int nblk,
+                                       double* sums, void* stream) {
+    EA_REQUIRE(cur && prev && partial && sums, "ea_teacache_rel_l1_bf16: null tensor");
+    EA_REQUIRE(n > 0 && n % 8 == 0 && nblk > 0 && nblk <= 65535, "ea_teacache_rel_l1_bf16: n must be a positive multiple of 8");
+    EA_REQUIRE(((uintptr_t)cur | (uintptr_t)prev) % 16 == 0, "ea_teacache_rel_l1_bf16: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rel_l1_partial_kernel, dim3(nblk), dim3(256), 0, st, cur, prev, n, partial);
+    hipLaunchKernelGGL(rel_l1_final_kernel, dim3(1), dim3(64), 0, st, partial, nblk, sums);
+    return ea_check_launch("ea_teacache_rel_l1_bf16");
+}
+
+extern "C" int ea_bf16_binary(const ea_bf16* a, const ea_bf16* b, ea_bf16* out, int64_t n, int op, void* stream) {
+    EA_REQUIRE(a && b && out, "ea_bf16_binary: null tensor");
+    EA_REQUIRE(n >= 0 && n % 8 == 0 && (op == 0 || op == 1), "ea_bf16_binary: n must be a multiple of 8, op 0 (sub) or 1 (add)");
+    EA_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0, "ea_bf16_binary: pointers must be 16-byte aligned");
+    if (n == 0) return EA_OK;
+    const int64_t n8 = n / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (op == 0)
+        hipLaunchKernelGGL(bf16_binary_kernel<0>, dim3(blocks), dim3(256), 0, st, a, b, out, n8);
+    else
+        hipLaunchKernelGGL(bf16_binary_kernel<1>, dim3(blocks), dim3(256), 0, st, a, b, out, n8);
+    return ea_check_launch("ea_bf16_binary");
+}

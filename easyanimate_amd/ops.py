@@ -239,6 +239,43 @@ def attention_range(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: f
     return out
 
 
+_tc_ws = {}
+
+
+def teacache_rel_l1_sums(cur: torch.Tensor, prev: torch.Tensor):
+    """-> (fp64 device tensor [sum |bf16(cur-prev)|, sum |prev|], element count)."""
+    _dev(cur, prev)
+    _chk(cur, _BF16, "cur"); _chk(prev, _BF16, "prev")
+    assert cur.shape == prev.shape and cur.is_contiguous() and prev.is_contiguous()
+    n = cur.numel()
+    nblk = max(1, min(2048, n // (8 * 256 * 4)))
+    key = (nblk, str(cur.device))
+    ws = _tc_ws.get(key)
+    if ws is None:
+        ws = (torch.empty(2 * nblk, dtype=_F32, device=cur.device), torch.empty(2, dtype=torch.float64, device=cur.device))
+        _tc_ws[key] = ws
+    sums = torch.empty(2, dtype=torch.float64, device=cur.device)
+    _lib.call("ea_teacache_rel_l1_bf16", _p(cur), _p(prev), n, _p(ws[0]), nblk, _p(sums), _stream())
+    return sums, n
+
+
+def bf16_sub(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _dev(a, b)
+    _chk(a, _BF16, "a"); _chk(b, _BF16, "b")
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty_like(a)
+    _lib.call("ea_bf16_binary", _p(a), _p(b), _p(out), a.numel(), 0, _stream())
+    return out
+
+
+def bf16_add_(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    _dev(x, y)
+    _chk(x, _BF16, "x"); _chk(y, _BF16, "y")
+    assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous()
+    _lib.call("ea_bf16_binary", _p(x), _p(y), _p(x), x.numel(), 1, _stream())
+    return x
+
+
 def patchify(latents: torch.Tensor, extra: Optional[torch.Tensor], k_pad: int) -> torch.Tensor:
     """latents [B,C,F,H,W] (+ extra [B,C2,F,H,W]) -> bf16 [B, F*(H/2)*(W/2), k_pad]."""
     _dev(latents, extra)

@@ -195,6 +195,17 @@ class SequenceParallel:
             k[:, :, o:o + nl] = recv[r, 0].reshape(B, H, nl, 64)
             vt[:, :, :, o:o + nl] = recv[r, 1].reshape(B, H, 64, nl)
 
+    def all_reduce_sums(self, sums: torch.Tensor, n: int):
+        """TeaCache: add the rel-L1 partial sums / element counts of every rank (batch slices and token shards)."""
+        t = torch.cat([sums.to(torch.float64), torch.tensor([float(n)], dtype=torch.float64, device=sums.device)])
+        if t.is_cuda and dist.get_backend(self.world_group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, group=self.world_group)
+            t = h.to(sums.device)
+        else:
+            dist.all_reduce(t, group=self.world_group)
+        return t[:2], int(round(t[2].item()))
+
     # ---- final prediction ---------------------------------------------------------------------
     def gather_tokens(self, x: torch.Tensor) -> torch.Tensor:
         """This rank's [b_loc, n_own, C] -> the full [batch, N, C] on every rank (one world-wide all-gather)."""

@@ -159,8 +159,11 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
     def device(self):
         return next(self.parameters()).device
 
-    def enable_teacache(self, num_steps: int, rel_l1_thresh: float, coefficients=None):
-        raise NotImplementedError("TeaCache is a SURVEY 8(f) 'next' row (device-side rel-L1); benchmarks run with it off")
+    def enable_teacache(self, num_steps: int, rel_l1_thresh: float,
+                        coefficients=[-10.47857366, 8.33844143, -0.78477557, 0.68798618, 0.0136149]):
+        """reference: transformer3d.py:1485-1491."""
+        from .teacache import TeaCache
+        self.teacache = TeaCache(coefficients, num_steps, rel_l1_thresh=rel_l1_thresh)
 
     def _text_proj(self, mod, x: torch.Tensor) -> torch.Tensor:
         x = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
@@ -258,16 +261,32 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
         if rope is not None and sp is not None:
             rope = sp.shard_rope(rope, hs.device)
 
-        # 4. transformer blocks
-        for block in self.transformer_blocks:
-            hs, enc = block(hidden_states=hs, encoder_hidden_states=enc, temb=temb, image_rotary_emb=rope,
-                            num_frames=video_length, height=height // p, width=width // p, sp=sp)
+        # TeaCache (transformer3d.py:1564-1590): skip the blocks while the accumulated, rescaled rel-L1 change of the
+        # first block's modulated input stays under the threshold; a skipped step re-applies the cached residual
+        should_calc = True
+        if self.teacache is not None:
+            if hs.dtype != torch.bfloat16:
+                raise NotImplementedError("TeaCache: the device path keeps bf16 state (the model dtype of every V5.1 config)")
+            modulated_inp = self.transformer_blocks[0].norm1(hs, enc, temb)[0]
+            residual = self.teacache.previous_residual
+            should_calc = self.teacache.should_calc(modulated_inp, sp)
+            if not should_calc:
+                hs = ops.bf16_add_(hs, residual)
 
-        # 5. final norms (transformer3d.py:1673-1680); LayerNorm is per-row, so only the video rows are normalised
-        aff = self.norm_final.elementwise_affine
-        hs = ops.layernorm_modulate(hs, f32(self.norm_final.weight) if aff else None,
-                                    f32(self.norm_final.bias) if aff else None, None, None, self.norm_final.eps)
-        hs = self.norm_out(hs, temb=temb)
+        if should_calc:
+            ori_hs = hs
+            # 4. transformer blocks
+            for block in self.transformer_blocks:
+                hs, enc = block(hidden_states=hs, encoder_hidden_states=enc, temb=temb, image_rotary_emb=rope,
+                                num_frames=video_length, height=height // p, width=width // p, sp=sp)
+
+            # 5. final norms (transformer3d.py:1673-1680); LayerNorm is per-row: only the video rows are normalised
+            aff = self.norm_final.elementwise_affine
+            hs = ops.layernorm_modulate(hs, f32(self.norm_final.weight) if aff else None,
+                                        f32(self.norm_final.bias) if aff else None, None, None, self.norm_final.eps)
+            hs = self.norm_out(hs, temb=temb)
+            if self.teacache is not None:
+                self.teacache.previous_residual = ops.bf16_sub(hs, ori_hs)   # :1635, kept in HBM
         hs = ops.gemm(hs, bf16_weight(self.proj_out.weight), f32(self.proj_out.bias), ops.EPI_BIAS)
         if sp is not None:
             hs = sp.gather_tokens(hs)

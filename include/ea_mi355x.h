@@ -155,6 +155,22 @@ int ea_cfg_euler_step(const void* v, void* latents, int64_t n, float guidance, f
 
 /* ---- VAE (AutoencoderKLMagvit), channels-last (NDHWC) activations of ONE sample -------------------- */
 
+/* ---- TeaCache (transformer3d.py:90-121, 1564-1590, 1635) -------------------------------------- */
+
+/* Numerator and denominator of the reference's rel-L1 distance between consecutive modulated inputs
+ * (TeaCache.compute_rel_l1_distance, transformer3d.py:113-117), reduced on the device:
+ *   sums[0] = sum_i | bf16(cur_i - prev_i) |      sums[1] = sum_i | prev_i |        (fp64, deterministic order)
+ * cur/prev: bf16 [n], n % 8 == 0; partial: fp32 workspace of 2*nblk floats.  The host forms
+ * bf16(bf16(sums[0]/n) / bf16(sums[1]/n)) -- the roundings torch applies to bf16 tensors -- after an 16-byte copy;
+ * under sequence parallelism the two sums are all-reduced first. */
+int ea_teacache_rel_l1_bf16(const ea_bf16* cur, const ea_bf16* prev, int64_t n, float* partial, int nblk,
+                            double* sums, void* stream);
+
+/* out = a - b (op 0) or a + b (op 1), bf16, fp32 arithmetic with one rounding (== the torch bf16 tensor op):
+ * the cached residual `previous_residual = hidden_states - ori_hidden_states` (:1635) and its re-application
+ * `hidden_states += previous_residual` (:1590).  out may alias a or b.  n % 8 == 0. */
+int ea_bf16_binary(const ea_bf16* a, const ea_bf16* b, ea_bf16* out, int64_t n, int op, void* stream);
+
 /* Causal 3-D convolution as an im2col-free implicit GEMM (vaemodules/common.py:84-179 CausalConv3d; the
  * strided down-samplers downsamplers.py:24-94; the up-samplers upsamplers.py:21-37,123-153; the residual add of
  * ResidualBlock3D common.py:322).

@@ -7,6 +7,7 @@ Weights are not stored: they are regenerated from (state-dict name, shape, seed,
 easyanimate_amd.synthetic.synth_tensor, so the fixtures stay small; the shapes recorded here are the
 reference's own state-dict shapes, which also pins the key names of SURVEY Appendix C.
 """
+import copy
 import os
 import sys
 
@@ -132,6 +133,56 @@ def main():
         torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=latents, enc=enc, cos=cos, sin=sin,
                         guidance=6.0, steps=2, trace=traces[torch.float32], trace_bf16=traces[torch.bfloat16]),
                    os.path.join(OUT, f"{name}.pt"))
+    # ---- TeaCache (transformer3d.py:90-121,1564-1636): 8-step CFG loop on the tiny T2V model with the step-skip
+    # heuristic on; records the reference's rel-L1 distances, skip decisions and latents (fp32 and bf16 runs)
+    cfg = dict(TINY)
+    m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+    shapes = _load_sd(m, 3, "stress")
+    g = _g(47)
+    Fr, H, W, T = 2, 8, 8, 6
+    latents = torch.randn(1, 16, Fr, H, W, generator=g)
+    enc = torch.randn(2, T, cfg["text_embed_dim"], generator=g)
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+    cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+    coeff = [-10.47857366, 8.33844143, -0.78477557, 0.68798618, 0.0136149]
+    n_steps = 8
+    tea = {}
+    for thresh in (0.15, 0.3, 0.5):
+        for dt in (torch.float32, torch.bfloat16):
+            mm = copy.deepcopy(m).to(dt)   # (Module.to converts in place: never round-trip the fp32 weights through bf16)
+            mm.enable_teacache(n_steps, thresh, coefficients=coeff)
+            dists, calcs, accs = [], [], []
+            orig = type(mm.teacache).compute_rel_l1_distance
+            calls = {"n": 0}
+            hook = mm.transformer_blocks[1].register_forward_hook(lambda *a: calls.__setitem__("n", calls["n"] + 1))
+
+            def logged(prev, cur, _o=orig, _d=dists):
+                v = _o(prev, cur)
+                _d.append(v)
+                return v
+            mm.teacache.compute_rel_l1_distance = logged
+            s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+            s.set_timesteps(n_steps, device="cpu", mu=1)
+            x = latents.clone().to(dt)
+            trace = []
+            for t in s.timesteps:
+                before = calls["n"]
+                li = torch.cat([x] * 2)
+                te = torch.tensor([t] * 2).to(dtype=li.dtype)
+                v = mm(li, te, encoder_hidden_states=enc.to(dt), image_rotary_emb=(cos, sin), return_dict=False)[0]
+                calcs.append(calls["n"] > before)
+                accs.append(float(mm.teacache.accumulated_rel_l1_distance))
+                vu, vt = v.chunk(2)
+                v = vu + 6.0 * (vt - vu)
+                x = s.step(v, t, x, return_dict=False)[0]
+                trace.append(x.float().clone())
+            hook.remove()
+            mm.teacache = None
+            tea[(thresh, "bf16" if dt == torch.bfloat16 else "fp32")] = dict(dists=dists, calcs=calcs, accs=accs, trace=trace)
+            print("teacache", thresh, dt, "calc:", calcs, "dists:", [round(d, 4) for d in dists], "acc:", [round(a, 4) for a in accs])
+    torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style="stress", latents=latents, enc=enc, cos=cos, sin=sin, guidance=6.0,
+                    steps=n_steps, coefficients=coeff, runs=tea), os.path.join(OUT, "teacache_loop.pt"))
+
     # ---- tiny MAGVIT VAE in the reference's real (chunked, cached) inference mode: encode + decode
     vkw = dict(TINY_VAE)
     vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()

@@ -181,8 +181,48 @@ def dit_block(sd: SD, pre: str, h, e, temb, rope, heads: int, norm_eps: float, r
     return h2, e2
 
 
-def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint_latents=None):
-    """EasyAnimateTransformer3DModel.forward, transformer3d.py:1496-1689 (teacache off, no ref/clip)."""
+class TeaCache:
+    """The step-skip heuristic of transformer3d.py:90-121 and its use at :1564-1590, 1635.
+    rel-L1 distance between consecutive `transformer_blocks[0].norm1` outputs (video stream, whole CFG batch),
+    rescaled by np.poly1d(coefficients) and accumulated; a step is skipped while the sum stays below the threshold.
+    The reference evaluates the distance in the MODEL dtype (bf16 tensors: |cur-prev| is rounded per element, each
+    mean and the quotient are rounded to bf16) before `.item()`; with fp32 tensors nothing is rounded."""
+
+    def __init__(self, coefficients, num_steps: int, rel_l1_thresh: float = 0.0):
+        self.coefficients, self.num_steps, self.rel_l1_thresh = list(coefficients), num_steps, rel_l1_thresh
+        self.cnt = 0
+        self.accumulated = 0.0
+        self.prev_mod = None
+        self.prev_residual = None
+
+    def rescale(self, x: float) -> float:
+        return float(np.poly1d(self.coefficients)(x))
+
+    @staticmethod
+    def rel_l1(prev: torch.Tensor, cur: torch.Tensor) -> float:
+        return ((cur - prev).abs().mean() / prev.abs().mean()).item()
+
+    def should_calc(self, mod: torch.Tensor):
+        """-> (should_calc, rel_l1 or None); advances the step counter exactly as :1569-1584."""
+        dist = None
+        if self.cnt == 0 or self.cnt == self.num_steps - 1:
+            calc = True
+            self.accumulated = 0.0
+        else:
+            dist = self.rel_l1(self.prev_mod, mod)
+            self.accumulated += self.rescale(dist)
+            calc = not (self.accumulated < self.rel_l1_thresh)
+            if calc:
+                self.accumulated = 0.0
+        self.prev_mod = mod
+        self.cnt += 1
+        if self.cnt == self.num_steps:
+            self.cnt, self.prev_mod, self.prev_residual = 0, None, None   # reset(): `accumulated` is kept
+        return calc, dist
+
+
+def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint_latents=None, teacache=None):
+    """EasyAnimateTransformer3DModel.forward, transformer3d.py:1496-1689 (no ref/clip inputs)."""
     heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
     inner = heads * dh
     p = cfg["patch_size"]
@@ -197,16 +237,27 @@ def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint
         e = F.linear(rmsnorm(enc, sd["text_proj.0.weight"]), sd["text_proj.1.weight"], sd["text_proj.1.bias"])
     else:
         e = F.linear(enc, sd["text_proj.weight"], sd["text_proj.bias"])
-    for i in range(cfg["num_layers"]):
-        x, e = dit_block(sd, f"transformer_blocks.{i}.", x, e, temb, rope, heads, cfg["norm_eps"])
-    T = e.shape[1]
-    x = torch.cat([e, x], dim=1)
-    x = F.layer_norm(x, (inner,), sd.get("norm_final.weight"), sd.get("norm_final.bias"), cfg["norm_eps"])
-    x = x[:, T:]
-    mod = F.linear(F.silu(temb), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
-    shift, scale = mod.chunk(2, dim=1)
-    x = F.layer_norm(x, (inner,), sd.get("norm_out.norm.weight"), sd.get("norm_out.norm.bias"), cfg["norm_eps"])
-    x = x * (1 + scale[:, None, :]) + shift[:, None, :]
+    calc = True
+    if teacache is not None:
+        mod_in, _, _, _ = layernorm_zero(sd, "transformer_blocks.0.norm1.", x, e, temb, cfg["norm_eps"])
+        nxt = teacache.prev_residual
+        calc, _ = teacache.should_calc(mod_in)
+        if not calc:
+            x = x + nxt                      # :1590 (the residual recorded by the last computed step)
+    if calc:
+        x_in = x
+        for i in range(cfg["num_layers"]):
+            x, e = dit_block(sd, f"transformer_blocks.{i}.", x, e, temb, rope, heads, cfg["norm_eps"])
+        T = e.shape[1]
+        x = torch.cat([e, x], dim=1)
+        x = F.layer_norm(x, (inner,), sd.get("norm_final.weight"), sd.get("norm_final.bias"), cfg["norm_eps"])
+        x = x[:, T:]
+        mod = F.linear(F.silu(temb), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
+        shift, scale = mod.chunk(2, dim=1)
+        x = F.layer_norm(x, (inner,), sd.get("norm_out.norm.weight"), sd.get("norm_out.norm.bias"), cfg["norm_eps"])
+        x = x * (1 + scale[:, None, :]) + shift[:, None, :]
+        if teacache is not None:
+            teacache.prev_residual = x - x_in            # :1635
     x = F.linear(x, sd["proj_out.weight"], sd["proj_out.bias"])
     out = x.reshape(B, Fr, H // p, W // p, C, p, p).permute(0, 4, 1, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
     return out
@@ -240,14 +291,14 @@ def euler_step(v, x, sigma, sigma_next):
 
 
 def denoise_loop(sd: SD, cfg: dict, latents, enc_neg_pos, rope, num_steps: int, guidance_scale: float,
-                 inpaint_latents=None, shift: float = 1.0, return_all: bool = False):
+                 inpaint_latents=None, shift: float = 1.0, return_all: bool = False, teacache=None):
     """EasyAnimatePipeline.__call__ hot loop, pipeline_easyanimate.py:1069-1111 (CFG on, guidance_rescale 0)."""
     timesteps, sigmas = flow_sigmas(num_steps, shift=shift)
     trace = []
     for i, t in enumerate(timesteps):
         lat_in = torch.cat([latents] * 2)
         t_expand = torch.tensor([t] * lat_in.shape[0]).to(dtype=lat_in.dtype)
-        v = transformer_forward(sd, cfg, lat_in, t_expand, enc_neg_pos, rope, inpaint_latents)
+        v = transformer_forward(sd, cfg, lat_in, t_expand, enc_neg_pos, rope, inpaint_latents, teacache=teacache)
         vu, vt = v.chunk(2)
         v = vu + guidance_scale * (vt - vu)
         latents = euler_step(v, latents, sigmas[i], sigmas[i + 1])

@@ -105,6 +105,61 @@ def test_denoise_loop_vs_golden(name):
     assert s.step_index == g["steps"]
 
 
+@pytest.mark.parametrize("thresh", [0.15, 0.3, 0.5])
+def test_teacache_loop_vs_golden(thresh):
+    """8 Flow steps, CFG 6, TeaCache on (transformer3d.py:1564-1636) through the product transformer with the
+    device-resident cache: the skip DECISIONS must equal the reference's (bf16 run of tests/golden/teacache_loop.pt),
+    the rel-L1 distances agree to bf16 resolution, the latents meet the loop bar against the reference's fp32 run."""
+    from easyanimate_amd import FlowMatchEulerDiscreteScheduler
+    g = _load("teacache_loop.pt")
+    run_b, run_f = g["runs"][(thresh, "bf16")], g["runs"][(thresh, "fp32")]
+    m = _product_model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    m.enable_teacache(g["steps"], thresh, coefficients=g["coefficients"])
+    s = FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(g["steps"], device=DEV, mu=1)
+    x = g["latents"].to(DEV).bfloat16()
+    enc = g["enc"].to(DEV).bfloat16()
+    calcs, dists = [], []
+    with torch.no_grad():
+        for i, t in enumerate(s.timesteps):
+            li = torch.cat([x] * 2)
+            te = torch.stack([t] * 2).to(li.dtype)
+            v = m(li, te, encoder_hidden_states=enc, image_rotary_emb=(g["cos"], g["sin"]), return_dict=False)[0]
+            calcs.append(m.teacache.last_should_calc)
+            if m.teacache.last_rel_l1_distance is not None:
+                dists.append(m.teacache.last_rel_l1_distance)
+            x = s.step(v, t, x, return_dict=False, guidance_scale=g["guidance"])[0]
+            mse, rel, floor = _metrics(f"teacache {thresh} latents step {i}", x.float(), run_f["trace"][i], run_b["trace"][i])
+            assert mse <= max(1e-4, 1.5 * floor)
+    print(f"[parity] teacache {thresh}: decisions {calcs} (reference {run_b['calcs']}); rel-L1 {[round(d, 4) for d in dists]} "
+          f"(reference bf16 {[round(d, 4) for d in run_b['dists']]})")
+    assert calcs == run_b["calcs"]
+    assert len(dists) == len(run_b["dists"]) and all(abs(a - b) <= 0.03 * b for a, b in zip(dists, run_b["dists"]))
+    assert m.teacache.cnt == 0 and m.teacache.previous_residual is not None   # reset() after the last step, :1582-1584, :1635
+
+
+def test_teacache_kernels():
+    """ea_teacache_rel_l1_bf16 / ea_bf16_binary against torch bf16 tensor ops (the reference's arithmetic)."""
+    from easyanimate_amd import ops
+    from easyanimate_amd.teacache import TeaCache
+    gen = torch.Generator().manual_seed(3)
+    for shape in [(2, 96, 128), (1, 4097, 3072), (2, 53248 // 8, 3072)]:
+        prev = torch.randn(shape, generator=gen).bfloat16().to(DEV)
+        cur = (prev.float() + 0.2 * torch.randn(shape, generator=gen).to(DEV)).bfloat16()
+        ref = ((cur - prev).abs().mean() / prev.abs().mean()).item()     # torch bf16 ops on the GPU == the reference's
+        got = TeaCache.compute_rel_l1_distance(prev, cur)
+        sums, n = ops.teacache_rel_l1_sums(cur, prev)
+        exact = (cur - prev).abs().double().sum().item(), prev.abs().double().sum().item()
+        print(f"[parity] rel_l1 {shape}: device {got:.6f} torch-bf16 {ref:.6f}; sums rel err "
+              f"{abs(sums[0].item() - exact[0]) / exact[0]:.2e} {abs(sums[1].item() - exact[1]) / exact[1]:.2e}")
+        assert n == prev.numel()
+        assert abs(sums[0].item() - exact[0]) <= 1e-5 * exact[0] and abs(sums[1].item() - exact[1]) <= 1e-5 * exact[1]
+        assert abs(got - ref) <= 0.008 * ref   # one bf16 ulp of the quotient (torch's own reduction order differs too)
+        assert torch.equal(ops.bf16_sub(cur, prev), cur - prev)
+        y = cur.clone()
+        assert torch.equal(ops.bf16_add_(y, prev), cur + prev)
+
+
 def test_block_full_width_vs_oracle():
     """One 12B-width block (d=3072, 48 heads, ff 12288) on 640 video + 256 text tokens, stress init, against the
     fp32 oracle restatement on CPU; also checks the un-gated attention and FFN branch outputs."""

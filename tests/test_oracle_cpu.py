@@ -130,3 +130,36 @@ def test_vae_frame_bookkeeping():
             m = RV.vae_encode_moments(sd, torch.zeros(1, 3, f, 32, 32), 16)
             d = RV.vae_decode(sd, torch.zeros(1, 16, fl, 4, 4), 16)
         assert m.shape == (1, 32, fl, 4, 4) and d.shape == (1, 3, f, 32, 32)
+
+
+@pytest.mark.parametrize("thresh", [0.15, 0.3, 0.5])
+def test_teacache_restatement_matches_reference(thresh):
+    """oracle.restatement.TeaCache + transformer_forward(teacache=...) reproduce the reference's rel-L1 distances, skip
+    decisions and latents (tests/golden/teacache_loop.pt, generated by running the unchanged reference with
+    enable_teacache through the shim), in fp32 and in the bf16 model dtype whose rounding the heuristic inherits."""
+    g = _load("teacache_loop.pt")
+    sd32 = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        run = g["runs"][(thresh, name)]
+        sd = {k: v.to(dt) for k, v in sd32.items()}
+        tc = R.TeaCache(g["coefficients"], g["steps"], thresh)
+        dists, calcs = [], []
+        orig = tc.should_calc
+
+        def logged(mod, _o=orig):
+            c, d = _o(mod)
+            calcs.append(c)
+            if d is not None:
+                dists.append(d)
+            return c, d
+        tc.should_calc = logged
+        with torch.no_grad():
+            _, trace = R.denoise_loop(sd, g["cfg"], g["latents"].to(dt), g["enc"].to(dt), (g["cos"], g["sin"]), g["steps"],
+                                      g["guidance"], return_all=True, teacache=tc)
+        assert calcs == run["calcs"], (name, calcs, run["calcs"])
+        tol = 1e-6
+        assert len(dists) == len(run["dists"])
+        assert all(abs(a - b) <= tol * max(1.0, abs(b)) for a, b in zip(dists, run["dists"])), (dists, run["dists"])
+        err = max((a.float() - b).abs().max().item() for a, b in zip(trace, run["trace"]))
+        print(f"[parity] teacache thresh {thresh} {name}: decisions equal, max latent err {err:.3e}")
+        assert err < 1e-6   # the restatement is bit-identical to the reference on CPU, skipped steps included

@@ -68,3 +68,52 @@ def test_sp_transformer_equals_single_rank(world, cfg_parallel):
         assert size == seq
         sr = r % seq
         assert rng == (min(sr * n_loc, 960), min((sr + 1) * n_loc, 960))
+
+
+def _worker_teacache(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easyanimate_amd import EasyAnimateTransformer3DModel, FlowMatchEulerDiscreteScheduler, sequence_parallel
+        from easyanimate_amd.synthetic import synth_state_dict
+        g = torch.load(os.path.join(GOLD, "teacache_loop.pt"), weights_only=False)
+        m = EasyAnimateTransformer3DModel.from_config(g["cfg"])
+        m.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+        m = m.to(torch.bfloat16).to("cuda:0").eval()
+        enc = g["enc"].to("cuda:0").bfloat16()
+
+        def loop():
+            m.enable_teacache(g["steps"], 0.5, coefficients=g["coefficients"])
+            s = FlowMatchEulerDiscreteScheduler(shift=1.0)
+            s.set_timesteps(g["steps"], device="cuda:0", mu=1)
+            x = g["latents"].to("cuda:0").bfloat16()
+            calcs = []
+            with torch.no_grad():
+                for t in s.timesteps:
+                    li = torch.cat([x] * 2)
+                    v = m(li, torch.stack([t] * 2).to(li.dtype), encoder_hidden_states=enc, image_rotary_emb=(g["cos"], g["sin"]),
+                          return_dict=False)[0]
+                    calcs.append(m.teacache.last_should_calc)
+                    x = s.step(v, t, x, return_dict=False, guidance_scale=g["guidance"])[0]
+            return calcs, x.float().cpu()
+        c1, x1 = loop()
+        sequence_parallel.enable(m)
+        c2, x2 = loop()
+        ret[rank] = (c1, c2, (x1 - x2).abs().max().item(), x1.abs().max().item())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sp_teacache_decisions_equal_single_rank(world):
+    """TeaCache under multi-GPU sampling: the rel-L1 sums are all-reduced over batch slices and token shards, so every
+    rank takes the single-GPU skip decisions (the golden's [calc, skip, skip, calc, skip, skip, calc, calc] pattern)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_teacache, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    print(f"[parity] teacache world {world}:", dict(ret))
+    for r in range(world):
+        c1, c2, err, scale = ret[r]
+        assert c1 == c2 == [True, False, False, True, False, False, True, True]
+        assert err <= 0.06 * max(1.0, scale)
