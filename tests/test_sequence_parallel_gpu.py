@@ -104,10 +104,11 @@ def _worker_teacache(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2])   # (the golden has 32 video tokens: too few for a sequence split, 64 per shard)
 def test_sp_teacache_decisions_equal_single_rank(world):
-    """TeaCache under multi-GPU sampling: the rel-L1 sums are all-reduced over batch slices and token shards, so every
-    rank takes the single-GPU skip decisions (the golden's [calc, skip, skip, calc, skip, skip, calc, calc] pattern)."""
+    """TeaCache under multi-GPU sampling: the rel-L1 sums are all-reduced over the ranks (here: the two batch slices
+    of the CFG split), so every rank takes the single-GPU skip decisions (the golden's [calc, skip, skip, calc, skip,
+    skip, calc, calc] pattern)."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_teacache, args=(world, _free_port(), ret), nprocs=world, join=True)
