@@ -28,7 +28,7 @@ PROTOTYPES = {
     "ea_linear_small_m": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ea_timestep_sinusoid": [_P, _P, _I, _I, _I, _P],
     "ea_gemm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _I, _P],
-    "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P],
     "ea_attention_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P],
     "ea_attention_fwd_range_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(
     unsigned short* __restrict__ k_out, unsigned short* __restrict__ vt_out, const float* __restrict__ nq_w,
     const float* __restrict__ nq_b, const float* __restrict__ nk_w, const float* __restrict__ nk_b,
     const float* __restrict__ cosT, const float* __restrict__ sinT, int heads, int n_tok, int seq_off, int s_pad,
-    float eps) {
+    float eps, float q_scale) {
     __shared__ unsigned short vtile[64][72];  // [token][channel], padded
     const int tid = threadIdx.x;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -97,18 +97,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(
                 // nn.LayerNorm output is rounded to the model dtype before RoPE (processor.py:255-258)
                 v[e] = bf16_bits_to_f32(f32_to_bf16_bits(t));
             }
+            // q only: the softmax scale (x log2 e) may be folded in here, in fp32 ahead of the one bf16 rounding the
+            // reference applies at this point, so that the attention kernel can exponentiate raw scores
+            const float osc = which ? 1.0f : q_scale;
             u16x8 o;
             if (cosT) {
                 // diffusers apply_rotary_emb, interleaved pairs: out[2i] = x[2i]c - x[2i+1]s ; out[2i+1] = x[2i+1]c + x[2i]s
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const float x0 = v[e], x1 = v[e + 1];
-                    o[e] = f32_to_bf16_bits(x0 * cs[e] - x1 * sn[e]);
-                    o[e + 1] = f32_to_bf16_bits(x1 * cs[e + 1] + x0 * sn[e + 1]);
+                    o[e] = f32_to_bf16_bits((x0 * cs[e] - x1 * sn[e]) * osc);
+                    o[e + 1] = f32_to_bf16_bits((x1 * cs[e + 1] + x0 * sn[e + 1]) * osc);
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e] * osc);
             }
             if (valid) {
                 unsigned short* dst = (which ? k_out : q_out) + (bh * s_pad + seq_off + tok) * 64 + sub * 8;
@@ -348,7 +351,7 @@ int ea_attn_variant_set(int v) {
 extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q_out, ea_bf16* k_out,
                                    ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
                                    const float* nk_b, const float* cos, const float* sin, int batch, int heads,
-                                   int n_tok, int seq_off, int s_pad, float ln_eps, void* stream) {
+                                   int n_tok, int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
     EA_REQUIRE(qkv && q_out && k_out && vt_out && nq_w && nq_b && nk_w && nk_b, "ea_qknorm_rope_bf16: null tensor");
     EA_REQUIRE((cos == nullptr) == (sin == nullptr), "ea_qknorm_rope_bf16: cos/sin must come together");
     EA_REQUIRE(batch > 0 && heads > 0 && n_tok >= 0 && seq_off >= 0, "ea_qknorm_rope_bf16: bad sizes");
@@ -357,7 +360,7 @@ extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride,
     if (n_tok == 0) return EA_OK;
     dim3 grid((n_tok + 63) / 64, heads, batch);
     hipLaunchKernelGGL(qknorm_rope_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_batch_stride, q_out,
-                       k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, heads, n_tok, seq_off, s_pad, ln_eps);
+                       k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, heads, n_tok, seq_off, s_pad, ln_eps, q_scale);
     return ea_check_launch("ea_qknorm_rope_bf16");
 }
 
@@ -389,18 +392,24 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     else if (variant == 3)
         hipLaunchKernelGGL(attention_fwd_v3_kernel, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
                            kv_end, s_pad, q_begin, q_end, nqb, scale_log2e);
-    else if (flags == 0)
-        hipLaunchKernelGGL(attention_fwd_v2_kernel<0>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
-                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
-    else if (flags == 1)
-        hipLaunchKernelGGL(attention_fwd_v2_kernel<1>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
-                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
-    else if (flags == 2)
-        hipLaunchKernelGGL(attention_fwd_v2_kernel<2>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
-                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
-    else
-        hipLaunchKernelGGL(attention_fwd_v2_kernel<3>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
-                           kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);
+    else {
+        // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
+        const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;
+#define EA_ATT_LAUNCH(MODE, FOLDED)                                                                                   \
+    hipLaunchKernelGGL((attention_fwd_v2_kernel<MODE, FOLDED>), grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, \
+                       heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4)
+        switch (flags * 2 + (folded ? 1 : 0)) {
+            case 0: EA_ATT_LAUNCH(0, false); break;
+            case 1: EA_ATT_LAUNCH(0, true); break;
+            case 2: EA_ATT_LAUNCH(1, false); break;
+            case 3: EA_ATT_LAUNCH(1, true); break;
+            case 4: EA_ATT_LAUNCH(2, false); break;
+            case 5: EA_ATT_LAUNCH(2, true); break;
+            case 6: EA_ATT_LAUNCH(3, false); break;
+            default: EA_ATT_LAUNCH(3, true); break;
+        }
+#undef EA_ATT_LAUNCH
+    }
     return ea_check_launch("ea_attention_fwd");
 }
 

@@ -179,10 +179,17 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     return out.squeeze(0) if squeeze else out
 
 
+# Softmax scale of head_dim 64 folded into Q (exp2 domain): q_scale = 64^-1/2 * log2(e) at ea_qknorm_rope_bf16, and
+# scale = ln(2) at ea_attention_fwd_* (scale * log2(e) == 1 selects the kernel that exponentiates raw scores).
+FOLDED_Q_SCALE = 0.125 * 1.4426950408889634
+FOLDED_ATTN_SCALE = 0.6931471805599453
+
+
 def qknorm_rope(qkv: torch.Tensor, q_out: torch.Tensor, k_out: torch.Tensor, vt_out: torch.Tensor,
                 nq_w, nq_b, nk_w, nk_b, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
-                seq_off: int, eps: float) -> None:
-    """qkv bf16 [B,n_tok,3*H*64]; q_out/k_out bf16 [B,H,S_pad,64]; vt_out bf16 [B,H,64,S_pad]."""
+                seq_off: int, eps: float, q_scale: float = 1.0) -> None:
+    """qkv bf16 [B,n_tok,3*H*64]; q_out/k_out bf16 [B,H,S_pad,64]; vt_out bf16 [B,H,64,S_pad].
+    q_scale multiplies q ahead of its bf16 rounding (FOLDED_Q_SCALE folds the softmax scale of head_dim 64)."""
     _dev(qkv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin)
     _chk(qkv, _BF16, "qkv")
     B, n_tok, three_inner = qkv.shape
@@ -194,7 +201,7 @@ def qknorm_rope(qkv: torch.Tensor, q_out: torch.Tensor, k_out: torch.Tensor, vt_
         _chk(cos, _F32, "cos"); _chk(sin, _F32, "sin")
         assert cos.shape == (n_tok, 64) and cos.is_contiguous() and sin.is_contiguous()
     _lib.call("ea_qknorm_rope_bf16", _p(qkv), qkv.stride(0), _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b),
-              _p(nk_w), _p(nk_b), _p(cos), _p(sin), B, H, n_tok, seq_off, s_pad, float(eps), _stream())
+              _p(nk_w), _p(nk_b), _p(cos), _p(sin), B, H, n_tok, seq_off, s_pad, float(eps), float(q_scale), _stream())
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scale: float,

@@ -120,9 +120,11 @@ class EasyAnimateAttnProcessor2_0:
         if attn.norm_q is None or attn.norm_k is None:
             raise NotImplementedError("qk_norm=None is not supported by the HIP processor")
         ops.qknorm_rope(qkv_t, ws["q"], ws["k"], ws["vt"], f32(tattn.norm_q.weight), f32(tattn.norm_q.bias),
-                        f32(tattn.norm_k.weight), f32(tattn.norm_k.bias), None, None, 0, tattn.norm_q.eps)
+                        f32(tattn.norm_k.weight), f32(tattn.norm_k.bias), None, None, 0, tattn.norm_q.eps,
+                        q_scale=ops.FOLDED_Q_SCALE)
         ops.qknorm_rope(qkv_v, ws["q"], ws["k"], ws["vt"], f32(attn.norm_q.weight), f32(attn.norm_q.bias),
-                        f32(attn.norm_k.weight), f32(attn.norm_k.bias), cos, sin, v_off, attn.norm_q.eps)
+                        f32(attn.norm_k.weight), f32(attn.norm_k.bias), cos, sin, v_off, attn.norm_q.eps,
+                        q_scale=ops.FOLDED_Q_SCALE)
 
         # ---- joint attention (processor.py:287-291): queries = text rows + this rank's video rows
         o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
@@ -132,18 +134,18 @@ class EasyAnimateAttnProcessor2_0:
             pending = sp.exchange_start(ws, v_off)
             state = _attention_state(B, H, S, dev)
             for i, (lo, hi) in enumerate(lay.local_ranges):
-                ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, lo, hi, state=state, load_state=i > 0,
+                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
                                     store_state=True)
             sp.exchange_finish(pending, ws, v_off)
-            ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, lay.remote_begin, lay.remote_end,
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lay.remote_begin, lay.remote_end,
                                 state=state, load_state=True, out=o)
         elif v_off != T:
             # single sequence rank with unaligned text: rows [T, v_off) are padding between the two key ranges
             state = _attention_state(B, H, S, dev)
-            ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, 0, T, state=state, store_state=True)
-            ops.attention_range(ws["q"], ws["k"], ws["vt"], 1.0 / 8.0, 0, S, v_off, S, state=state, load_state=True, out=o)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, 0, T, state=state, store_state=True)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, v_off, S, state=state, load_state=True, out=o)
         else:
-            ops.attention(ws["q"], ws["k"], ws["vt"], S, 1.0 / 8.0, out=o)
+            ops.attention(ws["q"], ws["k"], ws["vt"], S, ops.FOLDED_ATTN_SCALE, out=o)
         o_t, o_v = o[:, :T], o[:, v_off:]
 
         # ---- output projections (:293-311), optionally with the gated residual fused (attention.py:1140-1141)

@@ -101,11 +101,14 @@ int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16*
  *   vt_out: bf16 [batch, heads, 64, s_pad]   (V transposed: the PV operand layout of ea_attention_fwd)
  *   nq_w,nq_b,nk_w,nk_b: fp32 [64] LayerNorm affine of norm_q / norm_k (eps = ln_eps)
  *   cos,sin: fp32 [n_tok, 64] or NULL (text tokens: no RoPE), row r applies to token r
+ *   q_scale: multiplies q (not k) in fp32 ahead of its bf16 rounding; 1.0 reproduces the reference's q.  Passing
+ *            scale*log2(e) here and scale = ln(2) to ea_attention_fwd_* folds the softmax scale into Q: the
+ *            attention kernel then exponentiates the raw MFMA scores (one VALU instruction per score less).
  * s_pad % 64 == 0. */
 int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q_out, ea_bf16* k_out,
                         ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
                         const float* nk_b, const float* cos, const float* sin, int batch, int heads,
-                        int n_tok, int seq_off, int s_pad, float ln_eps, void* stream);
+                        int n_tok, int seq_off, int s_pad, float ln_eps, float q_scale, void* stream);
 
 /* Non-causal, unmasked softmax(Q K^T * scale) V, head_dim 64, bf16 in/out, fp32 softmax state.
  * Replaces F.scaled_dot_product_attention at processor.py:287-289 plus the transpose/reshape at :291.

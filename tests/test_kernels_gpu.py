@@ -225,6 +225,12 @@ def test_qknorm_rope(B, H, n_tok, seq_off, use_rope):
     vt = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=DEV)
     ops.qknorm_rope(qkv, q, k, vt, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off, 1e-6)
     rq, rk, rv = _ref_qknorm_rope(qkv, H, nq_w, nq_b, nk_w, nk_b, cos, sin, 1e-6)
+    # the folded softmax scale multiplies q only, ahead of the bf16 rounding
+    q2, k2, vt2 = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(vt)
+    ops.qknorm_rope(qkv, q2, k2, vt2, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off, 1e-6, q_scale=ops.FOLDED_Q_SCALE)
+    assert torch.equal(k2, k) and torch.equal(vt2, vt)
+    e2, r2 = _report("qknorm_rope folded q", q2[:, :, seq_off:seq_off + n_tok], rq.float() * ops.FOLDED_Q_SCALE)
+    assert r2 < 6e-3   # (the reference value here is the already rounded q times the scale: two roundings apart)
     sl = slice(seq_off, seq_off + n_tok)
     for name, got, ref in (("q", q[:, :, sl], rq), ("k", k[:, :, sl], rk), ("v", vt[:, :, :, sl].transpose(2, 3), rv)):
         err, rel = _report(f"qknorm_rope {name} B{B}H{H}n{n_tok}", got, ref)
@@ -258,13 +264,26 @@ def _attn_ref(q, k, v, S):
     return o.transpose(1, 2).reshape(B, S, H * 64)
 
 
+def _fold(q):
+    """What ea_qknorm_rope_bf16(q_scale=FOLDED_Q_SCALE) hands the attention kernel: bf16(q * 64^-1/2 * log2 e)."""
+    from easyanimate_amd import ops
+    return (q.float() * ops.FOLDED_Q_SCALE).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("folded", [False, True])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 64), (1, 2, 256), (2, 3, 333), (1, 2, 1000), (2, 9, 2048 + 77), (1, 1, 5)])
-def test_attention(B, H, S):
+def test_attention(B, H, S, folded):
+    """folded: the softmax scale lives in Q and the kernel runs its RAW path (P = exp2 of the raw scores, no shift)."""
     ops = _ops()
     q, k, vt, v = _attn_inputs(B, H, S, 7, scale_q=2.0)
-    out = ops.attention(q, k, vt, S, 0.125)
-    ref = _attn_ref(q, k, v, S)
-    err, rel = _report(f"attention B{B}H{H}S{S}", out, ref)
+    if folded:
+        qs = _fold(q)
+        out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+        ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)   # the reference of the rounded, folded q
+    else:
+        out = ops.attention(q, k, vt, S, 0.125)
+        ref = _attn_ref(q, k, v, S)
+    err, rel = _report(f"attention B{B}H{H}S{S} folded={folded}", out, ref)
     assert rel < 8e-3 and err < 0.05, (err, rel)
 
 
@@ -283,6 +302,54 @@ def test_attention_forced_rescale_and_padding_garbage():
     err, rel = _report("attention forced-rescale", out, ref)
     assert torch.isfinite(out.float()).all()
     assert rel < 8e-3 and err < 0.05
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_attention_extreme_dynamic_range(variant):
+    """Scores spanning +-600 (log2 units) inside one query row, row maxima in either key half of a 32-key block:
+    every exponential that is not the row maximum's under- or overflows.  (Caught a mis-compiled cross-half max in
+    the rescale path: the running max came from the lower key half only, finite until the halves differ by 2^127.)"""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    _lib.set_option("attn_variant", variant)
+    try:
+        B, H, S = 1, 3, 1000
+        q, k, vt, v = _attn_inputs(B, H, S, 37)
+        q = (q.float() * 30.0).to(torch.bfloat16)
+        for (qq, kk, a) in [(3, 40, 3.0), (3, 70, 2.5), (17, 31, 4.0), (200, 999, 9.0), (777, 960, 5.0), (64, 0, 6.0)]:
+            k[:, 0, kk] = (q[:, 0, qq].float() / 30.0 * a).to(torch.bfloat16)
+        out = ops.attention(q, k, vt, S, 0.125)
+        ref = _attn_ref(q, k, v, S)
+        assert torch.isfinite(out.float()).all()
+        err, rel = _report(f"attention v{variant} extreme range", out, ref)
+        assert rel < 8e-3 and err < 0.05
+    finally:
+        _lib.set_option("attn_variant", 2)
+
+
+@pytest.mark.parametrize("amp", [0.02, 1.0, 30.0])
+def test_attention_folded_leaves_raw_mode(amp):
+    """The RAW path (m = 0, P = exp2(raw score)) has to hand over to the shifted path when a row sum leaves
+    [2^-60, 2^60): scores scaled to +-a few (stays RAW), to hundreds (overflow side, head 0 / underflow side, head 1:
+    every key of a query far below zero until a late block), spikes in even / odd blocks and in the ragged tail."""
+    ops = _ops()
+    B, H, S = 1, 3, 1000
+    q, k, vt, v = _attn_inputs(B, H, S, 37)
+    q = (q.float() * amp).to(torch.bfloat16)
+    for (qq, kk, a) in [(3, 40, 3.0), (3, 70, 2.5), (17, 31, 4.0), (200, 999, 9.0), (777, 960, 5.0), (64, 0, 6.0)]:
+        k[:, 0, kk] = (q[:, 0, qq].float() / max(amp, 1e-3) * a).to(torch.bfloat16)
+    # head 1: all scores strongly negative (q . k = -|const|) except a few late keys
+    d = torch.ones(64, device=DEV)
+    q[:, 1, :S] = (d * 2.0 * amp).to(torch.bfloat16)
+    k[:, 1, :S] = (-d * 1.5 + 0.05 * torch.randn(S, 64, device=DEV)).to(torch.bfloat16)
+    k[:, 1, 900:905] = (d * 0.5).to(torch.bfloat16)
+    qs = _fold(q)
+    out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+    ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
+    assert torch.isfinite(out.float()).all()
+    for h in range(H):
+        err, rel = _report(f"attention folded amp {amp} head{h}", out[:, :, h * 64:(h + 1) * 64], ref[:, :, h * 64:(h + 1) * 64])
+        assert rel < 8e-3 and err < 0.05, (h, err, rel)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3])

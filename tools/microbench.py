@@ -53,7 +53,7 @@ def _bench_gemm(tile):
 
 def bench_attn():
     from easyanimate_amd import _lib
-    for var in (2, 3, 2, 3):
+    for var in (2, 2):
         _lib.set_option("attn_variant", var)
         _bench_attn(var)
     _lib.set_option("attn_variant", 2)
@@ -66,8 +66,13 @@ def _bench_attn(var):
         k = torch.randn(B, H, s_pad, 64, device=DEV).to(torch.bfloat16)
         vt = torch.randn(B, H, 64, s_pad, device=DEV).to(torch.bfloat16)
         out = torch.empty(B, S, H * 64, dtype=torch.bfloat16, device=DEV)
-        fn = lambda: ops.attention(q, k, vt, S, 0.125, out=out)
-        ms = timeit(fn, warm=1, iters=3)
+        for folded in ((False, True) if var == 2 else (False,)):
+            qq = (q.float() * ops.FOLDED_Q_SCALE).to(torch.bfloat16) if folded else q
+            sc = ops.FOLDED_ATTN_SCALE if folded else 0.125
+            fn = lambda: ops.attention(qq, k, vt, S, sc, out=out)
+            ms = timeit(fn, warm=1, iters=3)
+            print(json.dumps({"kernel": "attention", "variant": var, "folded": folded, "B": B, "H": H, "S": S, "ms": ms, "TFLOPs": 4.0 * B * H * S * S * 64 / ms / 1e9}), flush=True)
+        continue
         print(json.dumps({"kernel": "attention", "variant": var, "B": B, "H": H, "S": S, "ms": ms, "TFLOPs": 4.0 * B * H * S * S * 64 / ms / 1e9}), flush=True)
         del q, k, vt, out
 
