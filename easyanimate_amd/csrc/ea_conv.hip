@@ -211,6 +211,239 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
     }
 }
 
+
+// =================================================================================================
+// 256 x {128 | 256} x 64 "ping-pong" variant for the large convolutions (the structure of gemm256_bf16_kernel in
+// ea_gemm.hip: 8 waves, two wave groups staggered by one barrier, four phases per K-tile, s_setprio around the MFMA
+// clusters, one workgroup per CU).  K-tiles run tap-major / channel-block-minor; the per-lane gather pointers of the
+// A rows are recomputed only when the tap changes (every C_in/64 tiles) -- in the L-part of phase 0, i.e. under the
+// other wave group's MFMAs -- with incremental (dt, dh, dw) counters instead of divisions.
+//   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64;  BN = 128 (C_out = 128): waves 4 x 2, wave tile 64 x 64.
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
+    constexpr int WN = BN / 64, WM = 8 / WN;
+    constexpr int MI = 256 / WM / 32;          // 32-row MFMA tiles per wave along M
+    constexpr int WP = BN / 64;                // W-tile DMA pieces per wave (A: always 4)
+    constexpr int A_BYTES = 256 * 128, W_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2 stages] | W[2 stages]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int grp = wave >> 2;                 // waves w and w+4 share a SIMD: one of each group per SIMD
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    int tm, tn;
+    {
+        const int rpx = (p.tiles_m + 7) / 8;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int m_lo = xcd * rpx;
+        int rows = p.tiles_m - m_lo;
+        rows = rows < rpx ? rows : rpx;
+        if (rows <= 0 || idx >= rows * p.tiles_n) return;
+        tm = m_lo + idx / p.tiles_n;
+        tn = idx % p.tiles_n;
+    }
+    const int64_t row0 = (int64_t)tm * 256;
+    const int col0 = tn * BN;
+
+    // ---- this lane's 4 A rows (output voxels) and W rows
+    int vt[4], vh[4], vw[4], csw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
+        csw[i] = (c ^ ((r >> 1) & 7)) * 8;
+        int64_t m = row0 + r;
+        m = m < p.M ? m : p.M - 1;
+        vw[i] = (int)(m % p.W_out);
+        const int64_t q = m / p.W_out;
+        vh[i] = (int)(q % p.H_out) * p.ss - p.pad;     // input coordinates of tap (0,0,0)
+        vt[i] = (int)(q / p.H_out) * p.st - (p.kt - 1);
+        vw[i] = vw[i] * p.ss - p.pad;
+    }
+    const int64_t wk = (int64_t)p.kt * p.kh * p.kw * p.C_in;
+    const unsigned short* wsrc[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = (wave * WP + i) * 8 + (lane >> 3), c = lane & 7;
+        int rw = col0 + r;
+        rw = rw < p.C_out ? rw : p.C_out - 1;
+        wsrc[i] = p.w + (int64_t)rw * wk + ((c ^ ((r >> 1) & 7)) * 8);
+    }
+    char* const dma_a = smem + wave * 4096;
+    char* const dma_w = smem + 2 * A_BYTES + wave * (WP * 1024);
+
+    const int H_eff = p.ups ? p.H_in * 2 : p.H_in;
+    const int W_eff = p.ups ? p.W_in * 2 : p.W_in;
+    const unsigned short* a_tap[4];
+    auto set_tap = [&](int dt, int dh, int dw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ti = vt[i] + dt;
+            ti = ti < 0 ? 0 : ti;                       // causal replicate padding
+            int hh = vh[i] + dh, ww = vw[i] + dw;
+            const bool ok = hh >= 0 && hh < H_eff && ww >= 0 && ww < W_eff;
+            if (p.ups) {
+                hh >>= 1;
+                ww >>= 1;
+            }
+            a_tap[i] = ok ? p.x + (((int64_t)ti * p.H_in + hh) * p.W_in + ww) * p.C_in + csw[i] : p.zeros + csw[i];
+        }
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_row = wr * (MI * 32) + l31;
+    const int w_row = wc * 64 + swap23(l31);
+    const int a_sw = (l31 >> 1) & 7, w_sw = (swap23(l31) >> 1) & 7;
+    const char* a_k[4];
+    const char* w_k[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a_k[ks] = smem + a_row * 128 + (((ks * 2 + hi) ^ a_sw) << 4);
+        w_k[ks] = smem + 2 * A_BYTES + w_row * 128 + (((ks * 2 + hi) ^ w_sw) << 4);
+    }
+
+    const int cblocks = p.C_in / BK;
+    const int nk = p.kt * p.kh * p.kw * cblocks;
+    // position of the NEXT tile to stage: (dt, dh, dw, cb); tile t reads channels cb*64.. of tap (dt,dh,dw)
+    int n_dt = 0, n_dh = 0, n_dw = 0, n_cb = 0;
+    auto advance = [&]() {
+        if (++n_cb == cblocks) {
+            n_cb = 0;
+            if (++n_dw == p.kw) {
+                n_dw = 0;
+                if (++n_dh == p.kh) {
+                    n_dh = 0;
+                    ++n_dt;
+                }
+            }
+            set_tap(n_dt, n_dh, n_dw);
+        }
+    };
+
+#define EA_C2_PHASE(S, KS, HAS_NEXT)                                                                        \
+    {                                                                                                       \
+        bf16x8 af[MI], wf[2];                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            wf[j] = *reinterpret_cast<const bf16x8*>(w_k[KS] + (S) * W_BYTES + j * 4096);                   \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                      \
+            af[i] = *reinterpret_cast<const bf16x8*>(a_k[KS] + (S) * A_BYTES + i * 4096);                   \
+        if ((KS) == 0 && (HAS_NEXT)) {                                                                      \
+            advance();                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+                const unsigned short* src = a_tap[i];                                                       \
+                src = (src >= p.zeros && src < p.zeros + 64) ? src : src + n_cb * BK;                       \
+                glds16(src, dma_a + ((S) ^ 1) * A_BYTES + i * 1024);                                        \
+            }                                                                                               \
+        }                                                                                                   \
+        if ((KS) == 1 && (HAS_NEXT)) {                                                                      \
+            _Pragma("unroll") for (int i = 0; i < WP; ++i) {                                                \
+                wsrc[i] += BK;                                                                              \
+                glds16(wsrc[i], dma_w + ((S) ^ 1) * W_BYTES + i * 1024);                                    \
+            }                                                                                               \
+        }                                                                                                   \
+        if ((KS) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);      \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+#define EA_C2_TILE(S, HAS_NEXT) \
+    EA_C2_PHASE(S, 0, HAS_NEXT) \
+    EA_C2_PHASE(S, 1, HAS_NEXT) \
+    EA_C2_PHASE(S, 2, HAS_NEXT) \
+    EA_C2_PHASE(S, 3, HAS_NEXT)
+
+    // ---- prologue: tile 0 (tap 0, channel block 0) -> stage 0
+    set_tap(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_tap[i], dma_a + i * 1024);
+#pragma unroll
+    for (int i = 0; i < WP; ++i) glds16(wsrc[i], dma_w + i * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t < nk; t += 2) {
+        const bool n0_ = t + 1 < nk;
+        EA_C2_TILE(0, n0_)
+        if (n0_) {
+            const bool n1_ = t + 2 < nk;
+            EA_C2_TILE(1, n1_)
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+#undef EA_C2_TILE
+#undef EA_C2_PHASE
+
+    // ---- epilogue: lane owns voxel m, channels n0..n0+7
+    const int64_t frame = (int64_t)p.H_out * p.W_out;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int64_t m = row0 + wr * (MI * 32) + i * 32 + l31;
+        if (m >= p.M) continue;
+        int64_t m_dst0 = m, m_dst1 = -1;
+        if (p.tdup) {
+            const int64_t to = m / frame, rem = m - to * frame;
+            if (to >= 1) {
+                m_dst0 = (2 * to - 1) * frame + rem;
+                m_dst1 = (2 * to) * frame + rem;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int n0 = col0 + wc * 64 + j * 32 + g * 16 + hi * 8;
+                if (n0 >= p.C_out) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += b0[e];
+                        v[4 + e] += b1[e];
+                    }
+                }
+                if (p.res) {
+                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + m * p.C_out + n0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(rr[e]);
+                }
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
+                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
+            }
+        }
+    }
+}
+
+int g_conv_tile = 0;   // 0 = auto, 128 = force the 128^2 kernel, 256 = force the ping-pong kernels (benchmarking)
+
 // Explicit im2col for the few convolutions whose C_in is not a multiple of 64 (conv_in 3->128, decoder conv_in
 // 16->512, 1x1x1 quant convs): cols[m, tap*C_in + c], zero-padded to k_pad; the product is then ea_gemm_bf16.
 __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ cols, int T_in,
@@ -236,6 +469,12 @@ __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned s
 }
 
 }  // namespace
+
+int ea_conv_tile_set(int v) {
+    if (v != 0 && v != 128 && v != 256) return -1;
+    g_conv_tile = v;
+    return 0;
+}
 
 static int conv_out_dim(int in, int k, int s, int pad_lo, int pad_hi) { return (in + pad_lo + pad_hi - k) / s + 1; }
 
@@ -264,6 +503,30 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
     p.W_out = conv_out_dim(We, kw, ss, pad, pad_hi);
     p.M = (int64_t)p.T_out * p.H_out * p.W_out;
     EA_REQUIRE(p.M > 0 && p.M < (1ll << 40), "ea_conv3d_cl_bf16: bad output size");
+    // ping-pong kernels: C_out a multiple of 128 and enough 256-voxel tiles to fill the chip
+    const int bn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 0);
+    const int64_t tiles256 = (p.M + 255) / 256;
+    bool pp = bn != 0 && tiles256 * (C_out / (bn ? bn : 1)) >= 256;
+    if (g_conv_tile == 128) pp = false;
+    if (g_conv_tile == 256 && bn != 0) pp = true;
+    if (pp) {
+        p.tiles_m = (int)tiles256;
+        p.tiles_n = C_out / bn;
+        const int64_t grid2 = (int64_t)8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+        EA_REQUIRE(grid2 < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
+        static bool attr2_done = false;
+        if (!attr2_done) {
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_pp_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 2 * 128 * 128);
+            attr2_done = true;
+        }
+        if (bn == 256)
+            hipLaunchKernelGGL(conv3d_cl_pp_kernel<256>, dim3((unsigned)grid2), dim3(512), 4 * 256 * 128, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(conv3d_cl_pp_kernel<128>, dim3((unsigned)grid2), dim3(512), 2 * 256 * 128 + 2 * 128 * 128,
+                               (hipStream_t)stream, p);
+        return ea_check_launch("ea_conv3d_cl_bf16");
+    }
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = (C_out + BN - 1) / BN;
     const int64_t grid = (int64_t)8 * ((p.tiles_m + 7) / 8) * p.tiles_n;

@@ -547,6 +547,7 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
 }
 
 int ea_attn_variant_set(int v);
+int ea_conv_tile_set(int v);
 
 #ifdef EA_GEMM_TIMESTAMPS
 extern "C" int ea_debug_gemm_timestamps(void* buf) {
@@ -559,6 +560,10 @@ extern "C" int ea_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_tile")) {
         EA_REQUIRE(value == 0 || value == 128 || value == 256, "ea_set_option: gemm_tile must be 0, 128 or 256");
         g_gemm_tile = value;
+        return EA_OK;
+    }
+    if (!strcmp(name, "conv_tile")) {
+        EA_REQUIRE(ea_conv_tile_set(value) == 0, "ea_set_option: conv_tile must be 0, 128 or 256");
         return EA_OK;
     }
     if (!strcmp(name, "attn_variant")) {

@@ -69,6 +69,53 @@ def test_conv3d_cl(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res):
     assert rel < 4e-3
 
 
+PP_CASES = [
+    # the 256 x {128,256} ping-pong kernels, forced: ragged M, taps crossing every border, strides, folded up-sampling,
+    # temporal dup, residual, 1x1x1, odd / even K-tile counts (C_in 64 -> 27 tiles, 128 -> 54, 192 -> 81)
+    (3, 10, 12, 64, 128, 3, 1, 1, 1, False, False, False),
+    (4, 9, 7, 128, 256, 3, 1, 1, 1, False, False, True),
+    (5, 16, 12, 64, 128, 3, 1, 2, 0, False, False, False),
+    (5, 16, 12, 192, 256, 3, 2, 2, 0, False, False, False),
+    (3, 6, 5, 64, 128, 3, 1, 1, 1, True, True, True),
+    (1, 6, 6, 128, 128, 3, 1, 1, 1, True, True, False),
+    (4, 5, 6, 128, 256, 1, 1, 1, 0, False, False, False),
+    (2, 40, 40, 256, 256, 3, 1, 1, 1, False, False, True),
+    (3, 33, 31, 128, 512, 3, 1, 1, 1, False, False, False),
+]
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,k,st,ss,pad,ups,tdup,res", PP_CASES)
+def test_conv3d_cl_pingpong(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res):
+    from easyanimate_amd import _lib
+    _lib.set_option("conv_tile", 256)
+    try:
+        test_conv3d_cl(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res)
+    finally:
+        _lib.set_option("conv_tile", 0)
+
+
+def test_conv3d_cl_pingpong_equals_128_bitwise():
+    """Race screen for the hand-placed vmcnt / barrier schedule: identical results on repeated launches and bit-equal to
+    the 128^2 kernel (same K order, same fp32 accumulation chain) at a VAE-sized layer."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight
+    g = torch.Generator().manual_seed(8)
+    for (Ci, Co) in ((128, 128), (256, 256)):
+        x = _bf(torch.randn(5, 96, 96, Ci, generator=g)).to(DEV)
+        w = _pack_conv_weight(_bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)).to(DEV)
+        b = torch.randn(Co, generator=g).to(DEV)
+        _lib.set_option("conv_tile", 128)
+        y0 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+        _lib.set_option("conv_tile", 256)
+        try:
+            y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+            for _ in range(4):
+                assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
+        finally:
+            _lib.set_option("conv_tile", 0)
+        assert torch.equal(y0, y1)
+
+
 def test_small_cin_conv_via_im2col():
     from easyanimate_amd.vae_modules import CausalConv3d
     g = torch.Generator().manual_seed(4)
