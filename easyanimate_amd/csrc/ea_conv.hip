@@ -218,13 +218,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
 // clusters, one workgroup per CU).  K-tiles run tap-major / channel-block-minor; the per-lane gather pointers of the
 // A rows are recomputed only when the tap changes (every C_in/64 tiles) -- in the L-part of phase 0, i.e. under the
 // other wave group's MFMAs -- with incremental (dt, dh, dw) counters instead of divisions.
-//   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64;  BN = 128 (C_out = 128): waves 4 x 2, wave tile 64 x 64.
-template <int BN>
+//   256 x 256: waves 2 (M) x 4 (N), wave tile 128 x 64.   C_out = 128: 512 x 128, waves 4 x 2, wave tile 128 x 64 (all
+//   160 KiB of LDS: the same 6 fragment reads per 8 MFMAs as 256 x 256); 256 x 128 (wave tile 64 x 64) for short M.
+template <int BM, int BN>
 __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
     constexpr int WN = BN / 64, WM = 8 / WN;
-    constexpr int MI = 256 / WM / 32;          // 32-row MFMA tiles per wave along M
-    constexpr int WP = BN / 64;                // W-tile DMA pieces per wave (A: always 4)
-    constexpr int A_BYTES = 256 * 128, W_BYTES = BN * 128;
+    constexpr int MI = BM / WM / 32;           // 32-row MFMA tiles per wave along M
+    constexpr int AP = BM / 64;                // A-tile DMA pieces (8 rows x 128 B) per wave
+    constexpr int WP = BN / 64;                // W-tile DMA pieces per wave
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2 stages] | W[2 stages]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -244,14 +246,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
         tm = m_lo + idx / p.tiles_n;
         tn = idx % p.tiles_n;
     }
-    const int64_t row0 = (int64_t)tm * 256;
+    const int64_t row0 = (int64_t)tm * BM;
     const int col0 = tn * BN;
 
-    // ---- this lane's 4 A rows (output voxels) and W rows
-    int vt[4], vh[4], vw[4], csw[4];
+    // ---- this lane's AP A rows (output voxels) and W rows
+    int vt[AP], vh[AP], vw[AP], csw[AP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
+    for (int i = 0; i < AP; ++i) {
+        const int r = (wave * AP + i) * 8 + (lane >> 3), c = lane & 7;
         csw[i] = (c ^ ((r >> 1) & 7)) * 8;
         int64_t m = row0 + r;
         m = m < p.M ? m : p.M - 1;
@@ -270,15 +272,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
         rw = rw < p.C_out ? rw : p.C_out - 1;
         wsrc[i] = p.w + (int64_t)rw * wk + ((c ^ ((r >> 1) & 7)) * 8);
     }
-    char* const dma_a = smem + wave * 4096;
+    char* const dma_a = smem + wave * (AP * 1024);
     char* const dma_w = smem + 2 * A_BYTES + wave * (WP * 1024);
 
     const int H_eff = p.ups ? p.H_in * 2 : p.H_in;
     const int W_eff = p.ups ? p.W_in * 2 : p.W_in;
-    const unsigned short* a_tap[4];
+    const unsigned short* a_tap[AP];
     auto set_tap = [&](int dt, int dh, int dw) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AP; ++i) {
             int ti = vt[i] + dt;
             ti = ti < 0 ? 0 : ti;                       // causal replicate padding
             int hh = vh[i] + dh, ww = vw[i] + dw;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
             af[i] = *reinterpret_cast<const bf16x8*>(a_k[KS] + (S) * A_BYTES + i * 4096);                   \
         if ((KS) == 0 && (HAS_NEXT)) {                                                                      \
             advance();                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+            _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                \
                 const unsigned short* src = a_tap[i];                                                       \
                 src = (src >= p.zeros && src < p.zeros + 64) ? src : src + n_cb * BK;                       \
                 glds16(src, dma_a + ((S) ^ 1) * A_BYTES + i * 1024);                                        \
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
     // ---- prologue: tile 0 (tap 0, channel block 0) -> stage 0
     set_tap(0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(a_tap[i], dma_a + i * 1024);
+    for (int i = 0; i < AP; ++i) glds16(a_tap[i], dma_a + i * 1024);
 #pragma unroll
     for (int i = 0; i < WP; ++i) glds16(wsrc[i], dma_w + i * 1024);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
     }
 }
 
-int g_conv_tile = 0;   // 0 = auto, 128 = force the 128^2 kernel, 256 = force the ping-pong kernels (benchmarking)
+int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles
 
 // Explicit im2col for the few convolutions whose C_in is not a multiple of 64 (conv_in 3->128, decoder conv_in
 // 16->512, 1x1x1 quant convs): cols[m, tap*C_in + c], zero-padded to k_pad; the product is then ea_gemm_bf16.
@@ -471,7 +473,7 @@ __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned s
 }  // namespace
 
 int ea_conv_tile_set(int v) {
-    if (v != 0 && v != 128 && v != 256) return -1;
+    if (v != 0 && v != 128 && v != 256 && v != 512) return -1;
     g_conv_tile = v;
     return 0;
 }
@@ -503,28 +505,35 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
     p.W_out = conv_out_dim(We, kw, ss, pad, pad_hi);
     p.M = (int64_t)p.T_out * p.H_out * p.W_out;
     EA_REQUIRE(p.M > 0 && p.M < (1ll << 40), "ea_conv3d_cl_bf16: bad output size");
-    // ping-pong kernels: C_out a multiple of 128 and enough 256-voxel tiles to fill the chip
+    // ping-pong kernels: C_out a multiple of 128 and enough tiles to fill the chip
     const int bn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 0);
     const int64_t tiles256 = (p.M + 255) / 256;
     bool pp = bn != 0 && tiles256 * (C_out / (bn ? bn : 1)) >= 256;
     if (g_conv_tile == 128) pp = false;
-    if (g_conv_tile == 256 && bn != 0) pp = true;
+    if (g_conv_tile >= 256 && bn != 0) pp = true;
     if (pp) {
-        p.tiles_m = (int)tiles256;
+        // 512 x 128 when there are enough 512-voxel tiles (or when forced: g_conv_tile == 256 tests every variant by size)
+        const bool big_m = bn == 128 && (g_conv_tile == 512 || (g_conv_tile == 0 && (p.M + 511) / 512 * (C_out / 128) >= 512));
+        const int bm = big_m ? 512 : 256;
+        p.tiles_m = (int)((p.M + bm - 1) / bm);
         p.tiles_n = C_out / bn;
         const int64_t grid2 = (int64_t)8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
         EA_REQUIRE(grid2 < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
+        const int lds = 2 * bm * 128 + 2 * bn * 128;
         static bool attr2_done = false;
         if (!attr2_done) {
-            (void)hipFuncSetAttribute((const void*)conv3d_cl_pp_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
-            (void)hipFuncSetAttribute((const void*)conv3d_cl_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 2 * 128 * 128);
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_pp_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_pp_kernel<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_pp_kernel<512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             attr2_done = true;
         }
+        hipStream_t st2 = (hipStream_t)stream;
         if (bn == 256)
-            hipLaunchKernelGGL(conv3d_cl_pp_kernel<256>, dim3((unsigned)grid2), dim3(512), 4 * 256 * 128, (hipStream_t)stream, p);
+            hipLaunchKernelGGL((conv3d_cl_pp_kernel<256, 256>), dim3((unsigned)grid2), dim3(512), lds, st2, p);
+        else if (bm == 512)
+            hipLaunchKernelGGL((conv3d_cl_pp_kernel<512, 128>), dim3((unsigned)grid2), dim3(512), lds, st2, p);
         else
-            hipLaunchKernelGGL(conv3d_cl_pp_kernel<128>, dim3((unsigned)grid2), dim3(512), 2 * 256 * 128 + 2 * 128 * 128,
-                               (hipStream_t)stream, p);
+            hipLaunchKernelGGL((conv3d_cl_pp_kernel<256, 128>), dim3((unsigned)grid2), dim3(512), lds, st2, p);
         return ea_check_launch("ea_conv3d_cl_bf16");
     }
     p.tiles_m = (int)((p.M + BM - 1) / BM);

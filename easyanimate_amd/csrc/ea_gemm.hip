@@ -563,7 +563,7 @@ extern "C" int ea_set_option(const char* name, int value) {
         return EA_OK;
     }
     if (!strcmp(name, "conv_tile")) {
-        EA_REQUIRE(ea_conv_tile_set(value) == 0, "ea_set_option: conv_tile must be 0, 128 or 256");
+        EA_REQUIRE(ea_conv_tile_set(value) == 0, "ea_set_option: conv_tile must be 0, 128, 256 or 512");
         return EA_OK;
     }
     if (!strcmp(name, "attn_variant")) {

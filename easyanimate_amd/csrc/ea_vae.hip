@@ -102,6 +102,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
     }
 }
 
+// Fast path of the same for C/8 dividing 256 (every V5 VAE layer: C = 64 .. 512): a thread keeps ONE 8-channel chunk
+// and walks the voxels of ONE frame, so the per-(frame, channel) affine a = rstd*gamma, b = beta - mean*a is built once
+// per thread (16 registers) and an element costs one fma (+ 4 ops of SiLU as x * rcp(1 + 2^(-x log2 e))); no integer
+// division in the loop.  HBM-bound (4 B per element).
+__global__ __launch_bounds__(256) void gn_apply_frame_kernel(const unsigned short* __restrict__ x,
+                                                             unsigned short* __restrict__ y,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int64_t hw, int C, int groups,
+                                                             int act) {
+    const int nvec = C >> 3;
+    const int cpg = C / groups;
+    const int vc = threadIdx.x % nvec, vr = threadIdx.x / nvec, rows = 256 / nvec;
+    const int t = blockIdx.y, c0 = vc * 8;
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* st = stats + ((int64_t)t * groups + (c0 + j) / cpg) * 2;
+        a[j] = st[1] * gamma[c0 + j];
+        b[j] = beta[c0 + j] - st[0] * a[j];
+    }
+    const unsigned short* xf = x + (int64_t)t * hw * C + c0;
+    unsigned short* yf = y + (int64_t)t * hw * C + c0;
+    for (int64_t v = (int64_t)blockIdx.x * rows + vr; v < hw; v += (int64_t)gridDim.x * rows) {
+        const u16x8 raw = *reinterpret_cast<const u16x8*>(xf + v * C);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = __builtin_fmaf(bf16_bits_to_f32(raw[j]), a[j], b[j]);
+            if (act == 1) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
+            o[j] = f32_to_bf16_bits(r);
+        }
+        *reinterpret_cast<u16x8*>(yf + v * C) = o;
+    }
+}
+
 // ---- row softmax: y = softmax(x * scale) per row, bf16 in/out, fp32 math; one block per row --------------------
 template <int NV, bool F32IN>  // NV 8-element vectors per thread kept in registers (cols <= NV * 2048)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const void* __restrict__ xv, unsigned short* __restrict__ y,
@@ -222,6 +258,16 @@ extern "C" int ea_groupnorm_apply_bf16(const ea_bf16* x, ea_bf16* y, const float
                                        const float* beta, int T, int64_t hw, int C, int groups, int act, void* stream) {
     EA_REQUIRE(x && y && stats && gamma && beta, "ea_groupnorm_apply_bf16: null tensor");
     EA_REQUIRE(C % 8 == 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "ea_groupnorm_apply_bf16: bad channels/groups");
+    const int nvec = C / 8;
+    if (nvec <= 256 && 256 % nvec == 0 && T <= 65535) {
+        const int rows = 256 / nvec;
+        int64_t bx = (hw + rows - 1) / rows;
+        const int64_t cap = (16384 + T - 1) / T;   // ~64 workgroups per CU in flight over the whole grid
+        bx = bx > cap ? cap : bx;
+        hipLaunchKernelGGL(gn_apply_frame_kernel, dim3((unsigned)bx, (unsigned)T), dim3(256), 0, (hipStream_t)stream, x, y,
+                           stats, gamma, beta, hw, C, groups, act);
+        return ea_check_launch("ea_groupnorm_apply_bf16");
+    }
     const int64_t total = (int64_t)T * hw * (C / 8);
     int64_t blocks = (total + 255) / 256;
     blocks = blocks > 65536 ? 65536 : blocks;

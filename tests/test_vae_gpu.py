@@ -84,10 +84,13 @@ PP_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [256, 512])
 @pytest.mark.parametrize("T,H,W,Ci,Co,k,st,ss,pad,ups,tdup,res", PP_CASES)
-def test_conv3d_cl_pingpong(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res):
+def test_conv3d_cl_pingpong(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res, tile):
     from easyanimate_amd import _lib
-    _lib.set_option("conv_tile", 256)
+    if tile == 512 and Co != 128:
+        pytest.skip("the 512-row tile exists for C_out = 128 only")
+    _lib.set_option("conv_tile", tile)
     try:
         test_conv3d_cl(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res)
     finally:
@@ -106,14 +109,15 @@ def test_conv3d_cl_pingpong_equals_128_bitwise():
         b = torch.randn(Co, generator=g).to(DEV)
         _lib.set_option("conv_tile", 128)
         y0 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
-        _lib.set_option("conv_tile", 256)
-        try:
-            y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
-            for _ in range(4):
-                assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
-        finally:
-            _lib.set_option("conv_tile", 0)
-        assert torch.equal(y0, y1)
+        for tile in ((256, 512) if Co == 128 else (256,)):
+            _lib.set_option("conv_tile", tile)
+            try:
+                y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+                for _ in range(4):
+                    assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
+            finally:
+                _lib.set_option("conv_tile", 0)
+            assert torch.equal(y0, y1)
 
 
 def test_small_cin_conv_via_im2col():
