@@ -431,6 +431,57 @@ def test_attention_resumable_key_ranges(splits):
     assert (out[:, qb:qe].float() - one[:, qb:qe].float()).abs().max().item() < 0.02
 
 
+def test_attention_full_size_config3():
+    """BASELINE.json config 3 sequence (S = 53 504 = 836 key tiles, 209 query blocks), 2 heads: the product kernel against
+    a chunked fp32 torch evaluation of the same attention on the GPU (checker only), plus the size-independent
+    property the domain offers -- softmax attention is invariant to a permutation of the (key, value) rows."""
+    ops = _ops()
+    B, H, S = 1, 2, 53504
+    q, k, vt, v = _attn_inputs(B, H, S, 41, scale_q=1.5)
+    qs = _fold(q)
+    out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+    qf = qs[:, :, :S].float() / ops.FOLDED_Q_SCALE
+    ref = torch.empty(B, S, H * 64, dtype=torch.float32, device=DEV)
+    kf, vf = k[:, :, :S].float(), v.float()
+    for lo in range(0, S, 4096):
+        p = torch.softmax(qf[:, :, lo:lo + 4096] @ kf.transpose(2, 3) / 8.0, dim=-1)
+        ref[:, lo:lo + 4096] = (p @ vf).transpose(1, 2).reshape(B, -1, H * 64)
+    err, rel = _report("attention full size S=53504", out, ref)
+    assert rel < 8e-3 and err < 0.02
+    perm = torch.randperm(S, device=DEV)
+    k2, vt2 = torch.zeros_like(k), torch.zeros_like(vt)
+    k2[:, :, :S] = k[:, :, perm]
+    vt2[:, :, :, :S] = vt[:, :, :, perm]
+    out2 = ops.attention(qs, k2, vt2, S, ops.FOLDED_ATTN_SCALE)
+    e2, r2 = _report("attention full size, keys permuted vs not", out2, out.float())
+    assert r2 < 6e-3
+
+
+def test_gemm_full_size_config3_sampled_rows():
+    """The three DiT GEMM shapes at config-3 size (M = 106 496 rows): 512 sampled output rows against fp64."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(43)
+    M = 106496
+    rows = torch.randint(0, M, (512,), generator=g).to(DEV)
+    for (N, K, epi) in ((3072, 3072, 0), (12288, 3072, 1), (3072, 12288, 2)):
+        A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV)
+        gate = torch.randn(1, N, device=DEV)
+        res = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+        ref = A[rows].double() @ W.double().t() + bias.double()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref, approximate="tanh")
+        if epi == 2:
+            ref = res[rows].double() + gate.double() * ref
+            y = ops.gemm(A, W, bias, 2, out=res, res=res, gate=gate)
+        else:
+            y = ops.gemm(A, W, bias, epi)
+        err, rel = _report(f"gemm full size {M}x{N}x{K} epi{epi} (512 rows)", y[rows], ref)
+        assert rel < 4e-3
+        del A, W, res, y
+
+
 def test_attention_query_range():
     """Sequence-parallel use: only rows [q_begin, q_end) are produced, the rest of `out` is untouched."""
     ops = _ops()
