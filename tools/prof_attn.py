@@ -11,12 +11,12 @@ if what == "attn":
     _lib.set_option("attn_variant", var)
     B, H, S = 2, 48, 53504
     s_pad = ops.round_up(S, 256)
-    q = torch.randn(B, H, s_pad, 64, device="cuda").to(torch.bfloat16)
+    q = (torch.randn(B, H, s_pad, 64, device="cuda") * ops.FOLDED_Q_SCALE).to(torch.bfloat16)   # scale folded into Q
     k = torch.randn(B, H, s_pad, 64, device="cuda").to(torch.bfloat16)
     vt = torch.randn(B, H, 64, s_pad, device="cuda").to(torch.bfloat16)
     out = torch.empty(B, S, H * 64, dtype=torch.bfloat16, device="cuda")
     for _ in range(3):
-        ops.attention(q, k, vt, S, 0.125, out=out)
+        ops.attention(q, k, vt, S, ops.FOLDED_ATTN_SCALE, out=out)
 else:
     tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     _lib.set_option("gemm_tile", tile)
