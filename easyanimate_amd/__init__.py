@@ -21,6 +21,11 @@ _LAZY = {
 }
 
 
+def invalidate_weight_cache() -> None:
+    from ._params import invalidate_weight_cache as _inv
+    _inv()
+
+
 def __getattr__(name):
     if name in _LAZY:
         import importlib

@@ -31,6 +31,13 @@ def derived(p: torch.Tensor, tag: str, fn: Callable[[torch.Tensor], torch.Tensor
     return val
 
 
+def invalidate_weight_cache() -> None:
+    """Drop every derived copy.  Needed only after writes the version counter cannot see, i.e. `param.data.add_(...)`
+    style updates (the reference's utils/lora_utils.py:merge_lora / unmerge_lora) on parameters that are NOT used in
+    place -- contiguous 2-D bf16 Linear weights are read directly and need nothing."""
+    _cache.clear()
+
+
 def f32(p):
     """fp32 contiguous view/copy of a parameter (bias, LayerNorm affine)."""
     if p is None:

@@ -160,6 +160,61 @@ def test_teacache_kernels():
         assert torch.equal(ops.bf16_add_(y, prev), cur + prev)
 
 
+def test_fp8_weight_storage_and_lora_merge_are_observed():
+    """SURVEY 8(f) rank 2.  (a) fp8 weight storage (utils/fp8_optimization.py:17-22 stores every parameter as
+    float8_e4m3fn and up-casts per call): the kernels read weights through the derived-parameter cache, which up-casts
+    once -- the output equals that of a model holding the fp8-rounded values in bf16, bit for bit.  (b) LoRA merge
+    (utils/lora_utils.py:369-433 does `weight.data += delta`): bf16 Linear weights are read in place, so the merged
+    weights are used by the very next forward; derived copies (fp32 masters, the 4-D patch-embedding kernel) need
+    easyanimate_amd.invalidate_weight_cache() because `.data` writes do not bump the version counter."""
+    import copy
+    import easyanimate_amd
+    g = _load("transformer_t2v.pt")
+    lat, enc, t = g["latents"].to(DEV).bfloat16(), g["enc"].to(DEV).bfloat16(), g["t"].to(DEV).bfloat16()
+    rope = (g["cos"], g["sin"])
+    fwd = lambda m: m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+    base = _product_model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    with torch.no_grad():
+        y0 = fwd(base)
+        # ---- (a) fp8 storage
+        m8 = copy.deepcopy(base)
+        mq = copy.deepcopy(base)
+        for (n8, p8), (nq, pq) in zip(m8.named_parameters(), mq.named_parameters()):
+            q = p8.data.to(torch.float8_e4m3fn)
+            p8.data = q                                   # what convert_model_weight_to_float8 does
+            pq.data = q.to(torch.bfloat16)                # the values an up-cast per call would compute with
+        y8, yq = fwd(m8), fwd(mq)
+        assert torch.equal(y8, yq)
+        assert not torch.equal(y8, y0) and (y8.float() - y0.float()).abs().max().item() < 0.5   # fp8 rounding is visible, not wild
+        # ---- (b) LoRA merge into bf16 Linear weights, in place through .data
+        ml = copy.deepcopy(base)
+        gen = torch.Generator().manual_seed(3)
+        deltas = {}
+        for name, mod in ml.named_modules():
+            if name.endswith(("attn1.to_q", "attn1.to_out.0", "ff.net.2")):
+                w = mod.weight
+                up, down = torch.randn(w.shape[0], 4, generator=gen), torch.randn(4, w.shape[1], generator=gen)
+                d = (0.02 * up @ down).to(w.device, w.dtype)
+                w.data += d
+                deltas[name] = d
+        assert len(deltas) >= 3
+        y1 = fwd(ml)
+        mm = copy.deepcopy(base)
+        sd = mm.state_dict()
+        for name, d in deltas.items():
+            sd[name + ".weight"] = sd[name + ".weight"] + d
+        mm.load_state_dict(sd)
+        assert torch.equal(y1, fwd(mm)) and not torch.equal(y1, y0)
+        # a derived copy (4-D patch-embedding weight -> padded 2-D GEMM operand) after a .data write
+        ml.proj.weight.data *= 1.5
+        easyanimate_amd.invalidate_weight_cache()
+        y2 = fwd(ml)
+        sd = mm.state_dict()
+        sd["proj.weight"] = sd["proj.weight"] * 1.5
+        mm.load_state_dict(sd)
+        assert torch.equal(y2, fwd(mm))
+
+
 def test_block_full_width_vs_oracle():
     """One 12B-width block (d=3072, 48 heads, ff 12288) on 640 video + 256 text tokens, stress init, against the
     fp32 oracle restatement on CPU; also checks the un-gated attention and FFN branch outputs."""
