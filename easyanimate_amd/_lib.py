@@ -14,7 +14,8 @@ from ctypes import c_float, c_int, c_int64, c_void_p
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libea_mi355x.so")
+# EA_LIB_PATH: load another build of the same ABI (compiler-flag A/B runs: tools/build_variants.sh)
+LIB_PATH = os.environ.get("EA_LIB_PATH") or os.path.join(_HERE, "lib", "libea_mi355x.so")
 
 _P = c_void_p
 _I = c_int
