@@ -109,12 +109,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # EA_BENCH_SHARED_DEVICE=1 (testing only, 1-GPU box): every rank uses cuda:0 and the rendezvous is gloo -- RCCL
+    # refuses two ranks on one device; the timing of such a run means nothing, it exercises the multi-rank code path.
+    shared = os.environ.get("EA_BENCH_SHARED_DEVICE") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from easyanimate_amd import FlowMatchEulerDiscreteScheduler, ops, sequence_parallel
     from easyanimate_amd.pipeline import EasyAnimatePipeline
