@@ -33,14 +33,17 @@ CONFIGS = {
                layers=48, frames=49, height=1024, width=1024),
     "c2": dict(desc="7B-class DiT (28 MMDiT layers, d=3072), 49f x 512x512, T=256, CFG batch 2, bf16",
                layers=28, frames=49, height=512, width=512),
+    "c5": dict(desc="12B InP DiT (48 MMDiT layers, d=3072, in_channels 33), 49f x 768x768, T=256, CFG batch 2, bf16, "
+                    "random inpaint latents (I2V, BASELINE config 5: the denoise loop without its one VAE encode)",
+               layers=48, frames=49, height=768, width=768, in_channels=33),
     "tiny": dict(desc="2-layer d=3072 DiT, 5f x 128x128 (debug)", layers=2, frames=5, height=128, width=128),
 }
 
 
-def build_model(layers: int, device):
+def build_model(layers: int, device, in_channels: int = 16):
     from easyanimate_amd import EasyAnimateTransformer3DModel
     with torch.device("meta"):
-        m = EasyAnimateTransformer3DModel(num_attention_heads=48, attention_head_dim=64, in_channels=16, out_channels=16,
+        m = EasyAnimateTransformer3DModel(num_attention_heads=48, attention_head_dim=64, in_channels=in_channels, out_channels=16,
                                           patch_size=2, num_layers=layers, time_embed_dim=512, add_norm_text_encoder=True,
                                           text_embed_dim=3584, text_embed_dim_t5=None, norm_eps=1e-5,
                                           time_position_encoding_type="3d_rope", enable_text_attention_mask=True)
@@ -128,7 +131,7 @@ def main():
     from easyanimate_amd.pipeline import EasyAnimatePipeline
 
     cfg = CONFIGS[args.config]
-    model = build_model(cfg["layers"], device)
+    model = build_model(cfg["layers"], device, cfg.get("in_channels", 16))
     if world > 1:
         sequence_parallel.enable(model)
     sched = FlowMatchEulerDiscreteScheduler(shift=1.0)
@@ -141,6 +144,9 @@ def main():
     latents = pipe.prepare_latents(1, 16, cfg["frames"], cfg["height"], cfg["width"], torch.bfloat16, device, g)
     embeds = torch.randn(2, 256, 3584, generator=torch.Generator(device="cpu").manual_seed(1)).to(device, torch.bfloat16)
     rope = pipe.rotary_embedding(cfg["height"], cfg["width"], latents.size(2))
+    inpaint = None
+    if cfg.get("in_channels", 16) > 16:
+        inpaint = torch.randn((2, cfg["in_channels"] - 16) + tuple(latents.shape[2:]), generator=torch.Generator(device="cpu").manual_seed(2)).to(device, torch.bfloat16)
     Fl, hl, wl = latents.shape[2:]
     N_tok = Fl * (hl // 2) * (wl // 2)
     S = 256 + N_tok
@@ -153,11 +159,11 @@ def main():
 
     with torch.no_grad():
         if W > 0:
-            latents = pipe.denoise(latents, embeds, rope, sched.timesteps[:W], 6.0)
+            latents = pipe.denoise(latents, embeds, rope, sched.timesteps[:W], 6.0, inpaint_latents=inpaint)
         sync()
         t0 = time.perf_counter()
         with ops.KernelTimer("attention") as kt:
-            latents = pipe.denoise(latents, embeds, rope, sched.timesteps[W:W + K], 6.0)
+            latents = pipe.denoise(latents, embeds, rope, sched.timesteps[W:W + K], 6.0, inpaint_latents=inpaint)
         sync()
         elapsed = time.perf_counter() - t0
     if world > 1:

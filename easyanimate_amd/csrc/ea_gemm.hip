@@ -14,7 +14,6 @@
 //     accumulator registers: 16-byte bf16 stores, 16-byte residual loads, vector bias/gate loads.
 //   * blockIdx is remapped so that the 8 XCDs (private L2s) each walk a contiguous band of M-tiles.
 #include "ea_common.h"
-#include <string.h>
 
 namespace {
 
@@ -546,30 +545,14 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
     return ea_check_launch("ea_gemm_bf16");
 }
 
-int ea_attn_variant_set(int v);
-int ea_conv_tile_set(int v);
-
 #ifdef EA_GEMM_TIMESTAMPS
 extern "C" int ea_debug_gemm_timestamps(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_ts), &buf, sizeof(void*));
 }
 #endif
 
-extern "C" int ea_set_option(const char* name, int value) {
-    EA_REQUIRE(name, "ea_set_option: null name");
-    if (!strcmp(name, "gemm_tile")) {
-        EA_REQUIRE(value == 0 || value == 128 || value == 256, "ea_set_option: gemm_tile must be 0, 128 or 256");
-        g_gemm_tile = value;
-        return EA_OK;
-    }
-    if (!strcmp(name, "conv_tile")) {
-        EA_REQUIRE(ea_conv_tile_set(value) == 0, "ea_set_option: conv_tile must be 0, 128, 256 or 512");
-        return EA_OK;
-    }
-    if (!strcmp(name, "attn_variant")) {
-        EA_REQUIRE(ea_attn_variant_set(value) == 0, "ea_set_option: attn_variant must be 1, 2 or 3");
-        return EA_OK;
-    }
-    ea_set_error("ea_set_option: unknown option '%s'", name);
-    return EA_ERR_ARG;
+int ea_gemm_tile_set(int v) {
+    if (v != 0 && v != 128 && v != 256) return -1;
+    g_gemm_tile = v;
+    return 0;
 }
