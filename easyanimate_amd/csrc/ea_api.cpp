@@ -29,7 +29,7 @@ extern "C" int ea_version(void) { return 100; }
 
 // Tuning / benchmarking switches.  Each kernel file owns its switch; results never depend on them.
 int ea_gemm_tile_set(int v);      // ea_gemm.hip:      0 (auto) | 128 | 256
-int ea_attn_variant_set(int v);   // ea_attention.hip: 1 | 2 | 3
+int ea_attn_variant_set(int v);   // ea_attention.hip: 1 | 2
 int ea_conv_tile_set(int v);      // ea_conv.hip:      0 (auto) | 128 | 256 | 512
 
 extern "C" int ea_set_option(const char* name, int value) {

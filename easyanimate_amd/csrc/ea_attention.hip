@@ -338,12 +338,11 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
 }
 
 #include "ea_attention_v2.inc"
-#include "ea_attention_v3.inc"
 
 }  // namespace
 
 int ea_attn_variant_set(int v) {
-    if (v < 1 || v > 3) return -1;
+    if (v != 1 && v != 2) return -1;
     g_attn_variant = v;
     return 0;
 }
@@ -376,8 +375,7 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     if (q_end == q_begin) return EA_OK;
     const bool plain = flags == 0 && kv_begin == 0;
     const int variant = plain ? g_attn_variant : 2;   // key ranges / resumable state: the v2 kernel only
-    const int qblk = variant == 3 ? ATT3_QB : ATT_QB;
-    const int nqb = (q_end - q_begin + qblk - 1) / qblk;
+    const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
     const int bh = batch * heads;
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
     EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd: grid too large");
@@ -389,9 +387,6 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     if (variant == 1)
         hipLaunchKernelGGL(attention_fwd_kernel, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh, kv_end,
                            s_pad, q_begin, q_end, nqb, scale_log2e);
-    else if (variant == 3)
-        hipLaunchKernelGGL(attention_fwd_v3_kernel, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh,
-                           kv_end, s_pad, q_begin, q_end, nqb, scale_log2e);
     else {
         // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
         const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;

@@ -304,7 +304,7 @@ def test_attention_forced_rescale_and_padding_garbage():
     assert rel < 8e-3 and err < 0.05
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2])
 def test_attention_extreme_dynamic_range(variant):
     """Scores spanning +-600 (log2 units) inside one query row, row maxima in either key half of a 32-key block:
     every exponential that is not the row maximum's under- or overflows.  (Caught a mis-compiled cross-half max in
@@ -352,7 +352,7 @@ def test_attention_folded_leaves_raw_mode(amp):
         assert rel < 8e-3 and err < 0.05, (h, err, rel)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2])
 def test_attention_variants_rescale_paths(variant):
     """Both kernels (v1: per-block rescale; v2: software-pipelined, deferred rescale with the pending P.V flushed in the
     rare branch) against an fp64 reference on inputs that force the rescale branch at chosen blocks (CDNA4 guide,
@@ -396,7 +396,7 @@ def test_attention_v2_matches_v1_large():
     o1 = ops.attention(q, k, vt, S, 0.125)
     ref = _attn_ref(q, k, v, S)
     e1, r1 = _report("attention v1 S8300", o1, ref)
-    for var in (2, 3):
+    for var in (2,):
         _lib.set_option("attn_variant", var)
         o2 = ops.attention(q, k, vt, S, 0.125)
         o2b = ops.attention(q, k, vt, S, 0.125)
