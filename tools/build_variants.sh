@@ -16,9 +16,9 @@ build() {  # tag, extra flags...
   rm $OUT/ea_attention_$tag.o
   echo built $tag
 }
+# (measured in round 1: F 1141 TF > D 1133 > E 1112 > A 1105; -amdgpu-igrouplp-exact-solver needs
+#  -amdgpu-igrouplp-exact-solver-max-branches=<N> and a `timeout`: uncapped it ran for > 30 minutes on this kernel)
 build A -DEA_ATT_SGB=1 &
-build B -DEA_ATT_SGB=1 -mllvm -amdgpu-igrouplp-exact-solver &
-build C -DEA_ATT_SGB=2 -mllvm -amdgpu-igrouplp-exact-solver &
 build D -DEA_ATT_SGB=0 -mllvm -amdgpu-sched-strategy=max-ilp &
 build E -DEA_ATT_SGB=1 -mllvm -amdgpu-sched-strategy=max-ilp &
 build F -DEA_ATT_SGB=0 &
