@@ -447,7 +447,249 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
     }
 }
 
-int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles
+
+// =================================================================================================
+// "Row-slab" variant of the ping-pong kernel for the plain 3x3x3 / stride 1 / pad 1 convolutions (no folded
+// up-sampling) whose output rows are a multiple of 256 voxels wide -- i.e. the full-resolution layers that dominate the
+// VAE.  An M-tile is 256 consecutive voxels of ONE output row, so the three taps dw = 0,1,2 of a (dt, dh) pair read
+// the same input row shifted by one voxel: the A operand is staged ONCE per (dt, dh, channel block) as a 258-row slab
+// (w0-1 .. w0+256; 33 LDS-DMA pieces) and consumed three times with fragment row offsets 0 / 1 / 2.  LDS-DMA traffic per
+// MFMA drops 1.8x (BN = 128) / 1.5x (BN = 256) against the tile-per-tap kernels above.
+//   K order: (dt, dh) -> channel block -> dw  (the accumulation order differs from the other kernels: results agree to
+//   fp32 summation-order noise, not bit for bit).
+//   LDS: A slab stages at 0 and 34 KiB (33 KiB used each), W stages behind them; BN = 128: 100 KiB, BN = 256: 132 KiB.
+template <int BN, bool UPS>
+__global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
+    // UPS: nearest x2 up-sampling folded into the addressing -- output voxel u reads input voxel u >> 1, so the slab holds
+    // the 130 input voxels under the 258 up-sampled ones and two neighbouring lanes share a fragment row
+    constexpr int NPIECE = UPS ? 17 : 33, PPW = UPS ? 3 : 5, NROW = UPS ? 130 : 258, ISTEP = UPS ? 2048 : 4096;
+    constexpr int WN = BN / 64, WM = 8 / WN;
+    constexpr int MI = 256 / WM / 32;
+    constexpr int WP = BN / 64;
+    constexpr int A_STAGE = 34 * 1024, W_BYTES = BN * 128, W_BASE = 2 * A_STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int grp = wave >> 2;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    int tm, tn;
+    {
+        const int rpx = (p.tiles_m + 7) / 8;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int m_lo = xcd * rpx;
+        int rows = p.tiles_m - m_lo;
+        rows = rows < rpx ? rows : rpx;
+        if (rows <= 0 || idx >= rows * p.tiles_n) return;
+        tm = m_lo + idx / p.tiles_n;
+        tn = idx % p.tiles_n;
+    }
+    const int tiles_w = p.W_out / 256;
+    const int w0 = (tm % tiles_w) * 256;
+    const int orow = tm / tiles_w;                 // t_out * H_out + h_out
+    const int h_out = orow % p.H_out, t_out = orow / p.H_out;
+    const int col0 = tn * BN;
+
+    // ---- this lane's slab rows: piece q = wave*5 + i (q < 33), LDS row r = 8q + lane/8  <->  input voxel w0 - 1 + r
+    int a_woff[PPW];      // element offset of (voxel, source chunk) inside an input row, or -1: zero padding / unused row
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int r = q * 8 + (lane >> 3), c = lane & 7;
+        const int w = (UPS ? (w0 >> 1) : w0) - 1 + r;
+        a_woff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? w * p.C_in + (c ^ ((r >> 1) & 7)) * 8 : -1;
+    }
+    const int zoff = (lane & 7) * 8;   // any 16 bytes of the zero page will do
+    const int64_t wk = (int64_t)27 * p.C_in;
+    const unsigned short* wbase[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = (wave * WP + i) * 8 + (lane >> 3), c = lane & 7;
+        int rw = col0 + r;
+        rw = rw < p.C_out ? rw : p.C_out - 1;
+        wbase[i] = p.w + (int64_t)rw * wk + ((c ^ ((r >> 1) & 7)) * 8);
+    }
+    char* const dma_a = smem + wave * PPW * 1024;
+    char* const dma_w = smem + W_BASE + wave * (WP * 1024);
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: A row = wr*(MI*32) + i*32 + l31 + dw (the swizzle term follows the actual LDS row)
+    unsigned a_k[3][4];   // LDS byte offsets
+    unsigned w_k[4];
+    const int w_row = wc * 64 + swap23(l31);
+    const int w_sw = (swap23(l31) >> 1) & 7;
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+        {
+            const int row = UPS ? (wr * (MI * 16) + ((l31 + dw + 1) >> 1)) : (wr * (MI * 32) + l31 + dw);
+            a_k[dw][ks] = row * 128 + (((ks * 2 + hi) ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w_k[ks] = W_BASE + w_row * 128 + (((ks * 2 + hi) ^ w_sw) << 4);
+
+    const int cblocks = p.C_in / BK;
+    // the NEXT tile to stage: (dtdh, cb, dw)
+    int n_dtdh = 0, n_cb = 0;
+    const unsigned short* slab_row = p.zeros;   // input row (ti, hh) of the staged (dt, dh), or the zero page
+    bool slab_ok = false;
+    auto set_slab = [&](int dtdh) {
+        const int dt = dtdh / 3, dh = dtdh - dt * 3;
+        int ti = t_out + dt - 2;
+        ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
+        const int hu = h_out + dh - 1;                         // row in the (up-sampled) padded input
+        slab_ok = hu >= 0 && hu < p.H_out;                     // wave-uniform (stride 1, pad 1: H_out rows)
+        const int hh = UPS ? hu >> 1 : hu;
+        slab_row = p.x + ((int64_t)ti * p.H_in + (slab_ok ? hh : 0)) * p.W_in * p.C_in;
+    };
+    int a_dst = 0, w_dst = 0;                   // stage (0 / 1) the NEXT A slab / W tile is written to
+    auto stage_a = [&](int sa, int cb) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (wave * PPW + i < NPIECE) {                     // wave-uniform
+                const bool ok = slab_ok && a_woff[i] >= 0;
+                const unsigned short* src = ok ? slab_row + a_woff[i] + cb * BK : p.zeros + zoff;
+                glds16(src, dma_a + sa * A_STAGE + i * 1024);
+            }
+        }
+    };
+    auto stage_w = [&](int sw, int dtdh, int cb, int dw) {
+        const int koff = (dtdh * 3 + dw) * p.C_in + cb * BK;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) glds16(wbase[i] + koff, dma_w + sw * W_BYTES + i * 1024);
+    };
+    auto next_slab = [&]() {
+        if (++n_cb == cblocks) {
+            n_cb = 0;
+            ++n_dtdh;
+            set_slab(n_dtdh);
+        }
+    };
+
+#define EA_C3_PHASE(DW, KS, HAS_NEXT)                                                                       \
+    {                                                                                                       \
+        bf16x8 af[MI], wf[2];                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k[KS] + j * 4096));                          \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                      \
+            af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[DW][KS] + i * ISTEP));                     \
+        if ((KS) == 0 && (DW) == 2 && (HAS_NEXT)) {                                                         \
+            next_slab();                                                                                    \
+            stage_a(a_dst, n_cb);                                                                           \
+        }                                                                                                   \
+        if ((KS) == 1 && (HAS_NEXT)) stage_w(w_dst, n_dtdh, n_cb, ((DW) + 1) % 3);                          \
+        if ((KS) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);      \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+    // one tile = one (slab, dw): four k-steps; afterwards the W stage toggles (in place, on the fragment offsets)
+#define EA_C3_TILE(DW, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 0, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 1, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 2, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 3, HAS_NEXT)                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) w_k[ks] += w_step;   \
+    w_step = -w_step;                                                     \
+    w_dst ^= 1;
+
+    // ---- prologue: slab (dt,dh) = 0, channel block 0 -> A stage 0; its dw = 0 weights -> W stage 0
+    set_slab(0);
+    stage_a(0, 0);
+    stage_w(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // one trip = one slab = three tiles (dw = 0, 1, 2); the A stage toggles per slab, the W stage per tile
+    const int nslabs = 9 * cblocks;
+    int a_step = A_STAGE, w_step = W_BYTES;
+    a_dst = 1;
+    w_dst = 1;
+    for (int sl = 0; sl < nslabs; ++sl) {
+        EA_C3_TILE(0, true)
+        EA_C3_TILE(1, true)
+        EA_C3_TILE(2, sl + 1 < nslabs)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a_k[dw][ks] += a_step;
+        a_step = -a_step;
+        a_dst ^= 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef EA_C3_TILE
+#undef EA_C3_PHASE
+
+    // ---- epilogue: lane owns voxel m, channels n0..n0+7
+    const int64_t frame = (int64_t)p.H_out * p.W_out;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int64_t m = (int64_t)orow * p.W_out + w0 + wr * (MI * 32) + i * 32 + l31;
+        int64_t m_dst0 = m, m_dst1 = -1;
+        if (p.tdup && t_out >= 1) {
+            const int64_t rem = m - (int64_t)t_out * frame;
+            m_dst0 = (2 * (int64_t)t_out - 1) * frame + rem;
+            m_dst1 = (2 * (int64_t)t_out) * frame + rem;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int n0 = col0 + wc * 64 + j * 32 + g * 16 + hi * 8;
+                if (n0 >= p.C_out) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][g * 8 + e];
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += b0[e];
+                        v[4 + e] += b1[e];
+                    }
+                }
+                if (p.res) {
+                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + m * p.C_out + n0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(rr[e]);
+                }
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
+                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
+                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
+            }
+        }
+    }
+}
+
+int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles;
+                       // 1024: force the row-slab kernel wherever it applies
 
 // Explicit im2col for the few convolutions whose C_in is not a multiple of 64 (conv_in 3->128, decoder conv_in
 // 16->512, 1x1x1 quant convs): cols[m, tap*C_in + c], zero-padded to k_pad; the product is then ea_gemm_bf16.
@@ -476,7 +718,7 @@ __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned s
 }  // namespace
 
 int ea_conv_tile_set(int v) {
-    if (v != 0 && v != 128 && v != 256 && v != 512) return -1;
+    if (v != 0 && v != 128 && v != 256 && v != 512 && v != 1024) return -1;
     g_conv_tile = v;
     return 0;
 }
@@ -514,6 +756,35 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
     bool pp = bn != 0 && tiles256 * (C_out / (bn ? bn : 1)) >= 256;
     if (g_conv_tile == 128) pp = false;
     if (g_conv_tile >= 256 && bn != 0) pp = true;
+    // row-slab kernel: 3x3x3, stride 1, pad 1 (with or without the folded x2 up-sampling), output rows a multiple of 256
+    // voxels wide
+    const bool row_ok = bn != 0 && kt == 3 && st == 1 && ss == 1 && pad == 1 && p.W_out % 256 == 0 && C_in % 64 == 0;
+    const bool row_use = row_ok && (g_conv_tile == 1024 || (g_conv_tile == 0 && tiles256 * (C_out / bn) >= 512));
+    if (row_use) {
+        p.tiles_m = (int)(p.M / 256);
+        p.tiles_n = C_out / bn;
+        const int64_t grid3 = (int64_t)8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+        EA_REQUIRE(grid3 < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
+        const int lds3 = 2 * 34 * 1024 + 2 * bn * 128;
+        static bool attr3_done = false;
+        if (!attr3_done) {
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 128 * 128);
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 256 * 128);
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 128 * 128);
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 256 * 128);
+            attr3_done = true;
+        }
+        const dim3 g3((unsigned)grid3), b3(512);
+        if (bn == 256 && ups)
+            hipLaunchKernelGGL((conv3d_cl_row_kernel<256, true>), g3, b3, lds3, (hipStream_t)stream, p);
+        else if (bn == 256)
+            hipLaunchKernelGGL((conv3d_cl_row_kernel<256, false>), g3, b3, lds3, (hipStream_t)stream, p);
+        else if (ups)
+            hipLaunchKernelGGL((conv3d_cl_row_kernel<128, true>), g3, b3, lds3, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((conv3d_cl_row_kernel<128, false>), g3, b3, lds3, (hipStream_t)stream, p);
+        return ea_check_launch("ea_conv3d_cl_bf16");
+    }
     if (pp) {
         // 512 x 128 when there are enough 512-voxel tiles (or when forced: g_conv_tile == 256 tests every variant by size)
         const bool big_m = bn == 128 && (g_conv_tile == 512 || (g_conv_tile == 0 && (p.M + 511) / 512 * (C_out / 128) >= 512));

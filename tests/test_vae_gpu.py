@@ -120,6 +120,57 @@ def test_conv3d_cl_pingpong_equals_128_bitwise():
             assert torch.equal(y0, y1)
 
 
+ROW_CASES = [
+    # the row-slab kernel (forced): rows 256 / 512 / 768 voxels wide, first / last row and frame 0 (causal replicate),
+    # temporal dup, residual, one to four channel blocks, C_out 128 / 256 / 512 (N tiles)
+    (3, 4, 256, 64, 128, False, False, False),
+    (2, 3, 512, 128, 128, False, False, True),
+    (3, 2, 256, 128, 256, False, True, True),
+    (1, 5, 768, 64, 256, False, False, False),
+    (4, 3, 256, 256, 512, False, False, True),
+    (2, 1, 256, 192, 128, False, False, False),
+    # nearest x2 up-sampling folded into the slab addressing (input rows 128 / 256 / 384 wide -> output 256 / 512 / 768)
+    (3, 3, 128, 64, 128, True, True, False),
+    (2, 2, 256, 128, 256, True, False, False),
+    (1, 3, 128, 128, 128, True, True, False),
+    (2, 1, 384, 64, 256, True, True, False),
+]
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,ups,tdup,res", ROW_CASES)
+def test_conv3d_cl_row_slab(T, H, W, Ci, Co, ups, tdup, res):
+    from easyanimate_amd import _lib
+    _lib.set_option("conv_tile", 1024)
+    try:
+        test_conv3d_cl(T, H, W, Ci, Co, 3, 1, 1, 1, ups, tdup, res)
+    finally:
+        _lib.set_option("conv_tile", 0)
+
+
+def test_conv3d_cl_row_slab_is_deterministic_and_matches_tilewise():
+    """Race screen for the row-slab schedule: repeated launches are bit-identical; against the tile-per-tap kernel (a
+    different K order) the results agree to fp32 summation-order noise."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight
+    g = torch.Generator().manual_seed(9)
+    for (Ci, Co) in ((128, 128), (256, 256)):
+        x = _bf(torch.randn(3, 40, 512, Ci, generator=g)).to(DEV)
+        w = _pack_conv_weight(_bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)).to(DEV)
+        b = torch.randn(Co, generator=g).to(DEV)
+        _lib.set_option("conv_tile", 256)
+        y0 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+        _lib.set_option("conv_tile", 1024)
+        try:
+            y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+            for _ in range(4):
+                assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
+        finally:
+            _lib.set_option("conv_tile", 0)
+        d = (y0.float() - y1.float()).abs()
+        # a few last-bit bf16 flips only
+        assert bool((d <= 2 ** -7 * y0.float().abs().clamp_min(1.0)).all()) and (d > 0).float().mean().item() < 0.01
+
+
 def test_small_cin_conv_via_im2col():
     from easyanimate_amd.vae_modules import CausalConv3d
     g = torch.Generator().manual_seed(4)

@@ -26,7 +26,7 @@ for (T, H, W, Ci, Co) in [(13, 1024, 1024, 128, 128), (13, 1024, 1024, 256, 128)
     w = (torch.randn(Co, 27 * Ci, device="cuda") / (27 * Ci) ** 0.5).to(torch.bfloat16)
     b = torch.randn(Co, device="cuda")
     fl = 2.0 * 27 * Ci * Co * T * H * W
-    for tile in ((128, 256, 512) if Co == 128 else (128, 256)):
+    for tile in ((256, 512, 1024) if Co == 128 else (256, 1024)):
         _lib.set_option("conv_tile", tile)
         ms = timeit(lambda: ops.conv3d_cl(x, w, b, 3, 1, 1, 1))
         print(json.dumps({"kernel": "conv3d_cl", "tile": tile, "T": T, "HW": H, "Cin": Ci, "Cout": Co, "ms": ms, "TFLOPs": fl / ms / 1e9}), flush=True)
