@@ -8,86 +8,105 @@ namespace {
 constexpr int LN_MAXV = 16;  // up to 16 x (64 lanes x 8 elems) = 8192 columns
 
 // reference: easyanimate/models/norm.py:16-26 (FP32LayerNorm) + :164-165 (modulation)
+// y = LN(x) * gamma + beta, then * (1 + scale) + shift, applied as one multiply-add per element with
+// A = gamma * (1 + scale), B = beta * (1 + scale) + shift.  A workgroup builds A and B once in LDS (the four parameter
+// vectors are 8x the bytes of a row: re-reading them per row made the kernel L2-bound at 3.1 TB/s) and each of its four
+// waves walks LN_ROWS rows, the next row's loads in flight while the current one is reduced and written.
+constexpr int LN_ROWS = 8;
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     const unsigned short* __restrict__ x, unsigned short* __restrict__ y, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift,
     int64_t mod_stride, int rows, int dim, int64_t xbs, int64_t ybs, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float ln_ab[];   // A[dim] | B[dim]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     const int b = blockIdx.y;
-    if (row >= rows) return;
-    const unsigned short* xr = x + b * xbs + row * dim;
-    unsigned short* yr = y + b * ybs + row * dim;
     const int nvec = dim >> 3;
+    {
+        const float* sc = scale ? scale + b * mod_stride : nullptr;
+        const float* sh = shift ? shift + b * mod_stride : nullptr;
+        // the reference rounds the LN output to bf16 before the modulation (FP32LayerNorm .to(dtype)); we keep fp32
+        // through the modulation: strictly closer to the fp32 oracle.
+        for (int c = threadIdx.x * 4; c < dim; c += 1024) {
+            f32x4 a = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+            if (gamma) {
+                a = *reinterpret_cast<const f32x4*>(gamma + c);
+                bb = *reinterpret_cast<const f32x4*>(beta + c);
+            }
+            if (sc) {
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(sc + c);
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(sh + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] *= 1.0f + s1[j];
+                    bb[j] = bb[j] * (1.0f + s1[j]) + h1[j];
+                }
+            }
+            *reinterpret_cast<f32x4*>(ln_ab + c) = a;
+            *reinterpret_cast<f32x4*>(ln_ab + dim + c) = bb;
+        }
+    }
+    __syncthreads();
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * LN_ROWS;
+    if (row0 >= rows) return;
+    const int nrow = rows - row0 < LN_ROWS ? (int)(rows - row0) : LN_ROWS;
+    const unsigned short* xr = x + b * xbs + row0 * dim;
+    unsigned short* yr = y + b * ybs + row0 * dim;
 
-    float v[NV][8];
-    float s = 0.f;
+    u16x8 raw[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int vi = i * 64 + lane;
-        if (vi < nvec) {
-            u16x8 raw = *reinterpret_cast<const u16x8*>(xr + vi * 8);
+        if (vi < nvec) raw[i] = *reinterpret_cast<const u16x8*>(xr + vi * 8);
+    }
+    for (int rr = 0; rr < nrow; ++rr, xr += dim, yr += dim) {
+        float v[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = i * 64 + lane;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                v[i][j] = bf16_bits_to_f32(raw[j]);
+                v[i][j] = vi < nvec ? bf16_bits_to_f32(raw[i][j]) : 0.f;
                 s += v[i][j];
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
-    }
-    const float mean = wave_sum(s) / (float)dim;
-    float q = 0.f;
+        if (rr + 1 < nrow) {   // next row in flight under this row's reductions
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = i * 64 + lane;
-        if (vi < nvec) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = v[i][j] - mean;
-                q += d * d;
+            for (int i = 0; i < NV; ++i) {
+                const int vi = i * 64 + lane;
+                if (vi < nvec) raw[i] = *reinterpret_cast<const u16x8*>(xr + dim + vi * 8);
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
-    const float* sc = scale ? scale + b * mod_stride : nullptr;
-    const float* sh = shift ? shift + b * mod_stride : nullptr;
-    const bool has_affine = gamma != nullptr, has_mod = sc != nullptr;  // block-uniform
+        const float mean = wave_sum(s) / (float)dim;
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = i * 64 + lane;
-        if (vi < nvec) {
-            const int c0 = vi * 8;
-            float t[8];
+        for (int i = 0; i < NV; ++i) {
+            const int vi = i * 64 + lane;
+            if (vi < nvec) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = (v[i][j] - mean) * rstd;
-            if (has_affine) {
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    t[j] = t[j] * g0[j] + b0[j];
-                    t[4 + j] = t[4 + j] * g1[j] + b1[j];
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[i][j] - mean;
+                    q += d * d;
                 }
             }
-            // the reference rounds the LN output to bf16 before the modulation (FP32LayerNorm .to(dtype));
-            // we keep fp32 through the modulation: strictly closer to the fp32 oracle.
-            if (has_mod) {
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + c0), s1 = *reinterpret_cast<const f32x4*>(sc + c0 + 4);
-                const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + c0), h1 = *reinterpret_cast<const f32x4*>(sh + c0 + 4);
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = i * 64 + lane;
+            if (vi < nvec) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ln_ab + vi * 8), a1 = *reinterpret_cast<const f32x4*>(ln_ab + vi * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln_ab + dim + vi * 8), b1 = *reinterpret_cast<const f32x4*>(ln_ab + dim + vi * 8 + 4);
+                u16x8 out;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    t[j] = t[j] * (1.0f + s0[j]) + h0[j];
-                    t[4 + j] = t[4 + j] * (1.0f + s1[j]) + h1[j];
+                    out[j] = f32_to_bf16_bits((v[i][j] - mean) * rstd * a0[j] + b0[j]);
+                    out[4 + j] = f32_to_bf16_bits((v[i][4 + j] - mean) * rstd * a1[j] + b1[j]);
                 }
+                *reinterpret_cast<u16x8*>(yr + vi * 8) = out;
             }
-            u16x8 out;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] = f32_to_bf16_bits(t[j]);
-            *reinterpret_cast<u16x8*>(yr + c0) = out;
         }
     }
 }
@@ -204,8 +223,8 @@ template <int NV>
 int launch_ln(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* beta, const float* scale,
               const float* shift, int64_t mod_stride, int batch, int rows, int dim, int64_t xbs,
               int64_t ybs, float eps, hipStream_t st) {
-    dim3 grid((rows + 3) / 4, batch);
-    hipLaunchKernelGGL(layernorm_modulate_kernel<NV>, grid, dim3(256), 0, st, x, y, gamma, beta, scale, shift,
+    dim3 grid((rows + 4 * LN_ROWS - 1) / (4 * LN_ROWS), batch);
+    hipLaunchKernelGGL(layernorm_modulate_kernel<NV>, grid, dim3(256), 2 * dim * sizeof(float), st, x, y, gamma, beta, scale, shift,
                        mod_stride, rows, dim, xbs, ybs, eps);
     return ea_check_launch("ea_layernorm_modulate_bf16");
 }
