@@ -49,6 +49,27 @@ __global__ void k(float* out, long long* cyc, float seed) {
                 }
                 if (OP == 12) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
                 if (OP == 13) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(a[i]) : "v"(3));
+                if (OP == 14) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(a[(i + 1) & 7]));
+                if (OP == 15) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(0x07060302));
+                if (OP == 16) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(0xffff0000), "v"(seed));
+                if (OP == 17) asm volatile("v_lshrrev_b32 %0, 16, %0" : "+v"(a[i]));
+                if (OP == 18) asm volatile("v_exp_f16 %0, %0" : "+v"(a[i]));
+                if (OP == 19) {  // the attention mix per MFMA: 2 exp + 1 cvt_pk + 2 add (+ 1 slot)
+                    if (i == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
+                    else if (i < 3) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                    else if (i == 3) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+                    else if (i < 6) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+                }
+                if (OP == 20) {  // trimmed mix: 2 exp + 1 perm + 1 dot2c
+                    if (i == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
+                    else if (i < 3) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                    else if (i == 3) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(0x07060302));
+                    else if (i == 4) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(a[3]));
+                }
+                if (OP == 21) {  // 2 exp only per MFMA
+                    if (i == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
+                    else if (i < 3) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                }
             }
         }
     }
@@ -96,6 +117,14 @@ int main() {
     run<8>("1 mfma + 7 fma", out, cyc);
     run<9>("1 mfma + 7 exp", out, cyc);
     run<11>("1 mfma + 3 exp + 4 fma", out, cyc);
+    run<14>("v_dot2c_f32_bf16", out, cyc);
+    run<15>("v_perm_b32", out, cyc);
+    run<16>("v_and_or_b32", out, cyc);
+    run<17>("v_lshrrev_b32", out, cyc);
+    run<18>("v_exp_f16", out, cyc);
+    run<19>("mfma+2exp+cvt+2add (x8/6)", out, cyc);
+    run<20>("mfma+2exp+perm+dot2c (x8/5)", out, cyc);
+    run<21>("mfma+2exp (x8/3)", out, cyc);
     // wall-clock calibration of the counter
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
