@@ -13,7 +13,7 @@ for f in $UNIT $(git ls-tree --name-only $REF easyanimate_amd/csrc/ | xargs -n1 
 sed "s#\"../../include/ea_mi355x.h\"#\"$PWD/include/ea_mi355x.h\"#" easyanimate_amd/csrc/ea_common.h > $T/ea_common.h
 mkdir -p easyanimate_amd/lib/variants
 EXTRA=""
-[ "$UNIT" = ea_attention.hip ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+[ "$UNIT" = ea_attention.hip ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 O=${UNIT%.hip}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $EXTRA -x hip -c $T/$UNIT -o $T/${O}_old.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o easyanimate_amd/lib/variants/libea_old.so $(ls easyanimate_amd/build/*.o | grep -v "/$O.o") $T/${O}_old.o
