@@ -59,7 +59,7 @@ def bench_attn():
     _lib.set_option("attn_variant", 2)
 
 
-def _bench_attn(var):
+def _bench_attn(var, waves=0):
     for (B, H, S) in [(2, 48, 13568), (1, 48, 53504), (2, 8, 53504)]:
         s_pad = ops.round_up(S, 256)
         q = torch.randn(B, H, s_pad, 64, device=DEV).to(torch.bfloat16)
@@ -71,7 +71,7 @@ def _bench_attn(var):
             sc = ops.FOLDED_ATTN_SCALE if folded else 0.125
             fn = lambda: ops.attention(qq, k, vt, S, sc, out=out)
             ms = timeit(fn, warm=1, iters=3)
-            print(json.dumps({"kernel": "attention", "variant": var, "folded": folded, "B": B, "H": H, "S": S, "ms": ms, "TFLOPs": 4.0 * B * H * S * S * 64 / ms / 1e9}), flush=True)
+            print(json.dumps({"kernel": "attention", "variant": var, "waves": waves, "folded": folded, "B": B, "H": H, "S": S, "ms": ms, "TFLOPs": 4.0 * B * H * S * S * 64 / ms / 1e9}), flush=True)
         continue
         print(json.dumps({"kernel": "attention", "variant": var, "B": B, "H": H, "S": S, "ms": ms, "TFLOPs": 4.0 * B * H * S * S * 64 / ms / 1e9}), flush=True)
         del q, k, vt, out
