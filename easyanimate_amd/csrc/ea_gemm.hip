@@ -480,6 +480,203 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
 #endif
 }
 
+// =================================================================================================
+// The same 256 x 256 x 64 ping-pong structure on v_mfma_f32_16x16x32_bf16.  Under the package power limit the 16x16x32
+// shape sustains 14 % more than 32x32x16 on random operands (tools/ubench/mfma_power.hip: 2070 vs 1820 TFLOP/s with every
+// SIMD issuing nothing else; both reach 2470 on zeros) -- the accumulator traffic per flop is half -- and the big GEMMs
+// run power-limited.
+//   * wave tile 128 (M) x 64 (N) = 8 x 4 MFMA tiles of 16 x 16 (128 accumulator registers, as before); C^T orientation:
+//     the W fragment (16 n-rows x 32 k) is the A operand, the activation fragment (32 k x 16 m-columns) the B operand, so
+//     a lane holds 4 consecutive n of one output row m = lane & 15.
+//   * a fragment read is 16 rows x 4 chunks of 16 B (row = lane & 15, chunk = 4 * kstep + lane / 16): the LDS rows are
+//     XOR-swizzled with row & 7 (eight consecutive rows hit eight different 16-byte columns); the LDS-DMA applies the
+//     swizzle on the source address as before.
+//   * a K-tile is four phases: (k32 step, M half).  The first phase of a step reads the four W fragments (kept for the
+//     second) and four A fragments, the second four A fragments; 16 MFMAs (256 cycles) per phase as with 8 x 32x32x16.
+//   * epilogue through the wave-private LDS image (8-byte writes in accumulator layout, 16-byte row-wise read-out).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm, tn;
+    if (!tile_of_block(p, tm, tn)) return;
+    const int b = blockIdx.y;
+    const int row0 = tm * 256, col0 = tn * 256;
+    const unsigned short* Ab = p.A + b * p.abs_;
+
+    const unsigned short* asrc[4];
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ (r & 7);
+        int ra = row0 + r;
+        ra = ra < p.M ? ra : p.M - 1;
+        int rw = col0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
+        wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
+    }
+    char* const dma_a = smem + wave * 4096;
+    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment byte offsets: row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 * ks2 + lq; + 2048 per 16-row MFMA tile
+    unsigned a_k[2], w_k[2];
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+        w_k[ks2] = 2 * OPER2 + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+    }
+    const int nk = p.K / BK;
+    bf16x8 wf[4];
+
+#define EA_G3_PHASE(S, P, HAS_NEXT)                                                                           \
+    {                                                                                                         \
+        bf16x8 af[4];                                                                                         \
+        if (((P) & 1) == 0) {                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+                wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k[(P) >> 1] + (S) * OPER2 + j * 2048));    \
+        }                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+            af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[(P) >> 1] + (S) * OPER2 + (((P) & 1) * 4 + i) * 2048)); \
+        if ((P) == 0 && (HAS_NEXT)) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+                asrc[i] += BK;                                                                                \
+                glds16(asrc[i], dma_a + ((S) ^ 1) * OPER2 + i * 1024);                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+        if ((P) == 1 && (HAS_NEXT)) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+                wsrc[i] += BK;                                                                                \
+                glds16(wsrc[i], dma_w + ((S) ^ 1) * OPER2 + i * 1024);                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+        if ((P) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+                acc[((P) & 1) * 4 + i][j] =                                                                   \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[((P) & 1) * 4 + i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+#define EA_G3_TILE(S, HAS_NEXT)      \
+    EA_G3_PHASE(S, 0, HAS_NEXT)      \
+    EA_G3_PHASE(S, 1, HAS_NEXT)      \
+    EA_G3_PHASE(S, 2, HAS_NEXT)      \
+    EA_G3_PHASE(S, 3, HAS_NEXT)
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        glds16(asrc[i], dma_a + i * 1024);
+        glds16(wsrc[i], dma_w + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t < nk; t += 2) {
+        const bool n0_ = t + 1 < nk;
+        EA_G3_TILE(0, n0_)
+        if (n0_) {
+            const bool n1_ = t + 2 < nk;
+            EA_G3_TILE(1, n1_)
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+#undef EA_G3_TILE
+#undef EA_G3_PHASE
+
+    // ---- epilogue through the wave-private 16 KiB image (rows = the wave's 128 output rows, 128 B = its 64 columns,
+    // 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and the read-out already use)
+    char* const img = smem + wave * 16384;
+    const int mrow0 = row0 + wr * 128, ncol0 = col0 + wc * 64;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    if (EPI == EA_EPI_BIAS_GATE_RES) {
+        const unsigned short* Rb = p.res + b * p.rbs;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = q * 8 + r8;
+            int m = mrow0 + r;
+            m = m < p.M ? m : p.M - 1;
+            int n = ncol0 + ((c8 ^ ((r >> 1) & 7)) << 3);
+            n = n < p.N ? n : 0;
+            glds16(Rb + (int64_t)m * p.ldres + n, img + q * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        const float* gb = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = ncol0 + j * 16 + lq * 4;          // this lane's 4 columns of MFMA tile column j
+            if (n0 >= p.N) continue;                          // N tail (N % 8 == 0, lq*4 pairs stay inside a chunk of 8)
+            f32x4_t bv = {0.f, 0.f, 0.f, 0.f}, gv = bv;
+            if (p.bias) bv = *reinterpret_cast<const f32x4_t*>(p.bias + n0);
+            if (EPI == EA_EPI_BIAS_GATE_RES) gv = *reinterpret_cast<const f32x4_t*>(gb + n0);
+            const int ch = j * 2 + (lq >> 1);                 // 16-byte chunk of the row, 8-byte half lq & 1
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = i * 16 + lr;
+                char* cell = img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq & 1) * 8;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
+                if (EPI == EA_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                if (EPI == EA_EPI_BIAS_GATE_RES) {
+                    const u16x4 rr = *reinterpret_cast<const u16x4*>(cell);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = bf16_bits_to_f32(rr[e]) + gv[e] * v[e];
+                }
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[e]);
+                *reinterpret_cast<u16x4*>(cell) = o;
+            }
+        }
+    }
+    unsigned short* Cb = p.C + b * p.cbs;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = q * 8 + r8;
+        const int m = mrow0 + r;
+        const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
+        if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8) = o;
+    }
+}
+
+int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of the 256^2 kernel (32: the first version, kept as cross-check)
+
 template <int EPI>
 int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
     GemmArgs p = p0;
@@ -496,7 +693,16 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done[1] = true;
         }
-        hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
+        if (g_gemm_mfma == 16 && EPI != EA_EPI_F32_OUT) {
+            static bool attr16_done = false;
+            if (!attr16_done) {
+                hipFuncSetAttribute((const void*)gemm256_mi16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                attr16_done = true;
+            }
+            hipLaunchKernelGGL(gemm256_mi16_kernel<EPI>, grid, dim3(threads), lds, st, p);
+        } else {
+            hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
+        }
     } else {
         if (!attr_done[0]) {
             hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -554,5 +760,10 @@ extern "C" int ea_debug_gemm_timestamps(void* buf) {
 int ea_gemm_tile_set(int v) {
     if (v != 0 && v != 128 && v != 256) return -1;
     g_gemm_tile = v;
+    return 0;
+}
+int ea_gemm_mfma_set(int v) {
+    if (v != 16 && v != 32) return -1;
+    g_gemm_mfma = v;
     return 0;
 }

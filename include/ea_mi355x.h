@@ -42,6 +42,7 @@ const char* ea_last_error_string(void);
 int ea_version(void);
 /* Tuning / benchmarking switches (process-wide; results never depend on them):
  *   "gemm_tile":    0 = automatic (default), 128 / 256 = force that block tile in ea_gemm_bf16;
+ *   "gemm_mfma":    MFMA shape of the 256^2 GEMM kernel: 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = 32x32x16;
  *   "conv_tile":    0 = automatic, 128 = the 128^2 kernel, 256 / 512 = the ping-pong kernels with 256- / 512-voxel tiles,
  *                   1024 = the row-slab kernel wherever it applies (3x3x3, stride 1, rows a multiple of 256 voxels wide);
  *   "attn_variant": 2 = the pipelined kernel (default), 1 = the first, un-pipelined kernel (cross-check). */

@@ -29,10 +29,12 @@ def timeit(fn, warm=2, iters=5):
 
 def bench_gemm():
     from easyanimate_amd import _lib
-    for tile in (128, 256, 128, 256):
-        _lib.set_option("gemm_tile", tile)
-        _bench_gemm(tile)
+    _lib.set_option("gemm_tile", 256)
+    for mfma in (32, 16, 32, 16):
+        _lib.set_option("gemm_mfma", mfma)
+        _bench_gemm(f"256/mfma{mfma}")
     _lib.set_option("gemm_tile", 0)
+    _lib.set_option("gemm_mfma", 16)
 
 
 def _bench_gemm(tile):
