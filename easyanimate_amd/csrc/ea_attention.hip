@@ -338,11 +338,12 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
 }
 
 #include "ea_attention_v2.inc"
+#include "ea_attention_v3.inc"
 
 }  // namespace
 
 int ea_attn_variant_set(int v) {
-    if (v != 1 && v != 2) return -1;
+    if (v != 1 && v != 2 && v != 3) return -1;
     g_attn_variant = v;
     return 0;
 }
@@ -374,7 +375,7 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     EA_REQUIRE((flags & ~3) == 0 && (flags == 0 || state), "ea_attention_fwd: bad flags / missing state buffer");
     if (q_end == q_begin) return EA_OK;
     const bool plain = flags == 0 && kv_begin == 0;
-    const int variant = plain ? g_attn_variant : 2;   // key ranges / resumable state: the v2 kernel only
+    const int variant = plain ? g_attn_variant : (g_attn_variant == 3 ? 3 : 2);   // key ranges / resumable state: v2 / v3 only
     const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
     const int bh = batch * heads;
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
@@ -390,9 +391,13 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     else {
         // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
         const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;
-#define EA_ATT_LAUNCH(MODE, FOLDED)                                                                                   \
-    hipLaunchKernelGGL((attention_fwd_v2_kernel<MODE, FOLDED>), grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, \
-                       heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4)
+#define EA_ATT_LAUNCH(MODE, FOLDED)                                                                                       \
+    if (variant == 3 && FOLDED)                                                                                           \
+        hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid, blk, ATT_LDS, st, q, k, vt, o16,                         \
+                           out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);  \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((attention_fwd_v2_kernel<MODE, FOLDED>), grid, blk, ATT_LDS, st, q, k, vt, o16,                 \
+                           out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4)
         switch (flags * 2 + (folded ? 1 : 0)) {
             case 0: EA_ATT_LAUNCH(0, false); break;
             case 1: EA_ATT_LAUNCH(0, true); break;
@@ -418,7 +423,7 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
 
 extern "C" int64_t ea_attention_state_bytes(int batch, int heads, int q_begin, int q_end) {
     const int64_t nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
-    return (int64_t)batch * heads * nqb * ATT_STATE_F4 * 256 * 16;
+    return (int64_t)batch * heads * nqb * ATT3_STATE_F4 * 256 * 16;   // v3 layout (18 float4 / thread) >= v2 (17)
 }
 
 extern "C" int ea_attention_fwd_range_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,

@@ -288,9 +288,20 @@ def _fold(q):
     return (q.float() * ops.FOLDED_Q_SCALE).to(torch.bfloat16)
 
 
+@pytest.fixture(params=[2, 3])
+def attn_kernel(request):
+    """Run a test with the 32x32x16 (v2) and the 16x16x32 (v3, default) pipelined attention kernels.  v3 serves calls
+    with the scale folded into Q; everything else falls through to v2."""
+    from easyanimate_amd import _lib
+    _lib.set_option("attn_variant", request.param)
+    yield request.param
+    _lib.set_option("attn_variant", 3)
+
+
+
 @pytest.mark.parametrize("folded", [False, True])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 64), (1, 2, 256), (2, 3, 333), (1, 2, 1000), (2, 9, 2048 + 77), (1, 1, 5)])
-def test_attention(B, H, S, folded):
+def test_attention(B, H, S, folded, attn_kernel):
     """folded: the softmax scale lives in Q and the kernel runs its RAW path (P = exp2 of the raw scores, no shift)."""
     ops = _ops()
     q, k, vt, v = _attn_inputs(B, H, S, 7, scale_q=2.0)
@@ -342,11 +353,11 @@ def test_attention_extreme_dynamic_range(variant):
         err, rel = _report(f"attention v{variant} extreme range", out, ref)
         assert rel < 8e-3 and err < 0.05
     finally:
-        _lib.set_option("attn_variant", 2)
+        _lib.set_option("attn_variant", 3)
 
 
 @pytest.mark.parametrize("amp", [0.02, 1.0, 30.0])
-def test_attention_folded_leaves_raw_mode(amp):
+def test_attention_folded_leaves_raw_mode(amp, attn_kernel):
     """The RAW path (m = 0, P = exp2(raw score)) has to hand over to the shifted path when a row sum leaves
     [2^-60, 2^60): scores scaled to +-a few (stays RAW), to hundreds (overflow side, head 0 / underflow side, head 1:
     every key of a query far below zero until a late block), spikes in even / odd blocks and in the ragged tail."""
@@ -400,7 +411,7 @@ def test_attention_variants_rescale_paths(variant):
             assert rel < 8e-3 and err < 0.05, (h, err, rel)
         assert torch.isfinite(out.float()).all()
     finally:
-        _lib.set_option("attn_variant", 2)
+        _lib.set_option("attn_variant", 3)
 
 
 def test_attention_v2_matches_v1_large():
@@ -421,31 +432,40 @@ def test_attention_v2_matches_v1_large():
         assert torch.equal(o2, o2b)
         e2, r2 = _report(f"attention v{var} S8300", o2, ref)
         assert r2 < 8e-3 and e2 < 0.05 and r2 < 1.5 * r1 + 1e-4
-    _lib.set_option("attn_variant", 2)
+    _lib.set_option("attn_variant", 3)
 
 
 @pytest.mark.parametrize("splits", [(0, 320, 1000), (0, 64, 128, 1000), (0, 960, 1000), (0, 256, 576, 999)])
-def test_attention_resumable_key_ranges(splits):
+@pytest.mark.parametrize("folded", [False, True])
+def test_attention_resumable_key_ranges(splits, folded, attn_kernel):
     """ea_attention_fwd_range_bf16: chaining key ranges through the fp32 state equals the one-shot attention (the
-    sequence-parallel overlap path).  Ranges are visited OUT of order (softmax is order invariant); ragged last range."""
+    sequence-parallel overlap path).  Ranges are visited OUT of order (softmax is order invariant); ragged last range.
+    folded: the production path (scale in Q, RAW mode, v3 when selected); the spike at key 700 makes the rows of head 1
+    leave RAW mode inside a late range, so the state carries a non-zero running maximum into the next launch."""
     ops = _ops()
     B, H = 2, 3
     S = splits[-1]
     q, k, vt, v = _attn_inputs(B, H, S, 31, scale_q=1.5)
-    k[:, 1, 700] = q[:, 1, 5] * 6     # a spike inside a late range
-    ref = _attn_ref(q, k, v, S)
+    k[:, 1, 700] = q[:, 1, 5] * (40 if folded else 6)     # a spike inside a late range
+    if folded:
+        qs, sc = _fold(q), ops.FOLDED_ATTN_SCALE
+        ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
+    else:
+        qs, sc = q, 0.125
+        ref = _attn_ref(q, k, v, S)
     qb, qe = 64, 900                   # a query sub-range, as a rank would own
     out = torch.full((B, S, H * 64), 3.0, dtype=torch.bfloat16, device=DEV)
     st = ops.attention_state(B, H, qb, qe, DEV)
     ranges = list(zip(splits[:-1], splits[1:]))
     order = ranges[1:] + ranges[:1]    # start with the second range, finish with the first
     for i, (lo, hi) in enumerate(order):
-        ops.attention_range(q, k, vt, 0.125, qb, qe, lo, hi, state=st, load_state=i > 0,
+        ops.attention_range(qs, k, vt, sc, qb, qe, lo, hi, state=st, load_state=i > 0,
                             store_state=i < len(order) - 1, out=out)
-    err, rel = _report(f"attention ranges {splits}", out[:, qb:qe], ref[:, qb:qe])
+    err, rel = _report(f"attention ranges {splits} folded={folded}", out[:, qb:qe], ref[:, qb:qe])
+    assert torch.isfinite(out.float()).all()
     assert rel < 8e-3 and err < 0.05
     assert (out[:, :qb] == 3.0).all() and (out[:, qe:] == 3.0).all()
-    one = ops.attention(q, k, vt, S, 0.125, q_begin=qb, q_end=qe)
+    one = ops.attention(qs, k, vt, S, sc, q_begin=qb, q_end=qe)
     assert (out[:, qb:qe].float() - one[:, qb:qe].float()).abs().max().item() < 0.02
 
 
@@ -500,17 +520,19 @@ def test_gemm_full_size_config3_sampled_rows():
         del A, W, res, y
 
 
-def test_attention_query_range():
-    """Sequence-parallel use: only rows [q_begin, q_end) are produced, the rest of `out` is untouched."""
+def test_attention_query_range(attn_kernel):
+    """Sequence-parallel use: only rows [q_begin, q_end) are produced, the rest of `out` is untouched (plain and
+    folded scale: v2 / v3)."""
     ops = _ops()
     B, H, S = 1, 2, 1300
     q, k, vt, v = _attn_inputs(B, H, S, 13)
-    ref = _attn_ref(q, k, v, S)
-    out = torch.full((B, S, H * 64), 7.0, dtype=torch.bfloat16, device=DEV)
-    ops.attention(q, k, vt, S, 0.125, out=out, q_begin=512, q_end=1024)
-    err, rel = _report("attention q-range", out[:, 512:1024], ref[:, 512:1024])
-    assert rel < 8e-3
-    assert (out[:, :512] == 7.0).all() and (out[:, 1024:] == 7.0).all()
+    for qs, sc, ref in ((q, 0.125, _attn_ref(q, k, v, S)),
+                        (_fold(q), ops.FOLDED_ATTN_SCALE, _attn_ref((_fold(q).float() / ops.FOLDED_Q_SCALE).double(), k, v, S))):
+        out = torch.full((B, S, H * 64), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.attention(qs, k, vt, S, sc, out=out, q_begin=512, q_end=1024)
+        err, rel = _report("attention q-range", out[:, 512:1024], ref[:, 512:1024])
+        assert rel < 8e-3
+        assert (out[:, :512] == 7.0).all() and (out[:, 1024:] == 7.0).all()
 
 
 def test_patchify_unpatchify_cfg_euler():

@@ -58,10 +58,16 @@ def main():
     k = torch.randn(B, H, S, 64, device=dev).to(torch.bfloat16)
     vt = torch.randn(B, H, 64, S, device=dev).to(torch.bfloat16)
     out = torch.empty(B, S, H * 64, dtype=torch.bfloat16, device=dev)
-    run("attention c3 (B=1)", lambda: ops.attention(q, k, vt, S, ops.FOLDED_ATTN_SCALE, out=out), 4.0 * B * H * S * S * 64)
+    from easyanimate_amd import _lib
     zq = torch.zeros_like(q)
-    run("attention c3, all-zero Q (same instruction stream, idle data)", lambda: ops.attention(zq, k, vt, S, ops.FOLDED_ATTN_SCALE, out=out), 4.0 * B * H * S * S * 64)
+    for var in (3, 2):
+        _lib.set_option("attn_variant", var)
+        run(f"attention v{var} c3 (B=1)", lambda: ops.attention(q, k, vt, S, ops.FOLDED_ATTN_SCALE, out=out), 4.0 * B * H * S * S * 64)
+        run(f"attention v{var} c3, all-zero Q (same instruction stream, idle data)", lambda: ops.attention(zq, k, vt, S, ops.FOLDED_ATTN_SCALE, out=out), 4.0 * B * H * S * S * 64)
+    _lib.set_option("attn_variant", 3)
     del q, k, vt, out, zq
+    if "--attn-only" in sys.argv:
+        return
     for (M, N, K) in [(8192, 8192, 8192), (53504, 12288, 3072)]:
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = torch.randn(N, K, device=dev).to(torch.bfloat16)
