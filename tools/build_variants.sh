@@ -19,14 +19,12 @@ build() {  # tag, extra flags...
 # (measured in round 1: F 1141 TF > D 1133 > E 1112 > A 1105; -amdgpu-igrouplp-exact-solver needs
 #  -amdgpu-igrouplp-exact-solver-max-branches=<N> and a `timeout`: uncapped it ran for > 30 minutes on this kernel)
 COMMON="$COMMON -fno-slp-vectorize"
-build L2G2P -DEA_ATT_LEAD=2 -DEA_ATT_LAG=2 -DEA_ATT_ORDER=2 &
-build L2G2PS16 -DEA_ATT_LEAD=2 -DEA_ATT_LAG=2 -DEA_ATT_ORDER=2 -DEA_ATT_SPAN=16 &
-build L3G2PS15 -DEA_ATT_LEAD=3 -DEA_ATT_LAG=2 -DEA_ATT_ORDER=2 -DEA_ATT_SPAN=15 &
-build L2G3PS17 -DEA_ATT_LEAD=2 -DEA_ATT_LAG=3 -DEA_ATT_ORDER=2 -DEA_ATT_SPAN=17 &
+build P2 -DEA_ATT3_PPG=2 &
+build P4 -DEA_ATT3_PPG=4 &
+build L1 -DEA_ATT3_LEAD=1 &
+build L0 -DEA_ATT3_LEAD=0 &
 wait
-build L2G2S16 -DEA_ATT_LEAD=2 -DEA_ATT_LAG=2 -DEA_ATT_ORDER=0 -DEA_ATT_SPAN=16 &
-build L4G2PS14 -DEA_ATT_LEAD=4 -DEA_ATT_LAG=2 -DEA_ATT_ORDER=2 -DEA_ATT_SPAN=14 &
-build L1G1PS16 -DEA_ATT_LEAD=1 -DEA_ATT_LAG=1 -DEA_ATT_ORDER=2 -DEA_ATT_SPAN=16 &
-build L2G2QS16 -DEA_ATT_LEAD=2 -DEA_ATT_LAG=2 -DEA_ATT_ORDER=1 -DEA_ATT_SPAN=16 &
+build LP0 -DEA_ATT3_LDSPTR=0 &
+build L1P2 -DEA_ATT3_LEAD=1 -DEA_ATT3_PPG=2 &
 wait
 ls $OUT
