@@ -215,7 +215,7 @@ def main():
                    "parallelism": par,
                    "flop_per_step": flop_step, "step_mfma_frac": flop_step * K / elapsed / (PEAK_BF16_TFLOPS * 1e12 * world),
                    "finite_output": finite},
-        "roofline": {"bound": "mfma", "kernel": "attention_fwd_v2_kernel (ea_attention_fwd_bf16 / _range_bf16)",
+        "roofline": {"bound": "mfma", "kernel": "attention_fwd_v3_kernel (ea_attention_fwd_bf16 / _range_bf16)",
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                      "traffic": traffic, "flop_per_launch": att_flop, "avg_launch_ms": att_ms,
                      "launches_timed": len(durs), "launches_per_block": len(durs) / max(n_blocks, 1)},
