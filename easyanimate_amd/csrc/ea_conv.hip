@@ -688,6 +688,235 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
     }
 }
 
+// The row-slab kernel on v_mfma_f32_16x16x32_bf16 (see gemm256_mi16_kernel in ea_gemm.hip: the shape sustains 14 % more under
+// the power limit).  Wave tile (256 / WM) voxels x 64 channels = MT x 4 tiles of 16 x 16; a (slab, dw) K-tile is four
+// phases (k32 step, M half); LDS rows swizzled with row & 7; 8-byte stores (4 channels per lane and tile).
+template <int BN, bool UPS>
+__global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
+    // UPS: nearest x2 up-sampling folded into the addressing -- output voxel u reads input voxel u >> 1, so the slab holds
+    // the 130 input voxels under the 258 up-sampled ones and two neighbouring lanes share a fragment row
+    constexpr int NPIECE = UPS ? 17 : 33, PPW = UPS ? 3 : 5, NROW = UPS ? 130 : 258, ISTEP = UPS ? 1024 : 2048;
+    constexpr int WN = BN / 64, WM = 8 / WN;
+    constexpr int MT = 256 / WM / 16, MH = MT / 2;   // 16-voxel MFMA tiles per wave, per phase
+    constexpr int WP = BN / 64;
+    constexpr int A_STAGE = 34 * 1024, W_BYTES = BN * 128, W_BASE = 2 * A_STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int grp = wave >> 2;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm, tn;
+    {
+        const int rpx = (p.tiles_m + 7) / 8;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int m_lo = xcd * rpx;
+        int rows = p.tiles_m - m_lo;
+        rows = rows < rpx ? rows : rpx;
+        if (rows <= 0 || idx >= rows * p.tiles_n) return;
+        tm = m_lo + idx / p.tiles_n;
+        tn = idx % p.tiles_n;
+    }
+    const int tiles_w = p.W_out / 256;
+    const int w0 = (tm % tiles_w) * 256;
+    const int orow = tm / tiles_w;                 // t_out * H_out + h_out
+    const int h_out = orow % p.H_out, t_out = orow / p.H_out;
+    const int col0 = tn * BN;
+
+    // ---- this lane's slab rows: piece q = wave*5 + i (q < 33), LDS row r = 8q + lane/8  <->  input voxel w0 - 1 + r
+    int a_woff[PPW];      // element offset of (voxel, source chunk) inside an input row, or -1: zero padding / unused row
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int r = q * 8 + (lane >> 3), c = lane & 7;
+        const int w = (UPS ? (w0 >> 1) : w0) - 1 + r;
+        a_woff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? w * p.C_in + (c ^ (r & 7)) * 8 : -1;
+    }
+    const int zoff = (lane & 7) * 8;   // any 16 bytes of the zero page will do
+    const int64_t wk = (int64_t)27 * p.C_in;
+    const unsigned short* wbase[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = (wave * WP + i) * 8 + (lane >> 3), c = lane & 7;
+        int rw = col0 + r;
+        rw = rw < p.C_out ? rw : p.C_out - 1;
+        wbase[i] = p.w + (int64_t)rw * wk + ((c ^ (r & 7)) * 8);
+    }
+    char* const dma_a = smem + wave * PPW * 1024;
+    char* const dma_w = smem + W_BASE + wave * (WP * 1024);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses (16x16x32: row = lane & 15, 16-byte chunk 4 * ks2 + lane / 16, swizzle row & 7):
+    // A row = wr*(MT*16) + i*16 + lr + dw (the swizzle term follows the actual LDS row); W row = wc*64 + j*16 + lr
+    unsigned a_k[3][2];   // LDS byte offsets
+    unsigned w_k[2];
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const int row = UPS ? (wr * (MT * 8) + ((lr + dw + 1) >> 1)) : (wr * (MT * 16) + lr + dw);
+            a_k[dw][ks2] = row * 128 + (((ks2 * 4 + lq) ^ (row & 7)) << 4);
+        }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) w_k[ks2] = W_BASE + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+    bf16x8 wf[4];
+
+    const int cblocks = p.C_in / BK;
+    // the NEXT tile to stage: (dtdh, cb, dw)
+    int n_dtdh = 0, n_cb = 0;
+    const unsigned short* slab_row = p.zeros;   // input row (ti, hh) of the staged (dt, dh), or the zero page
+    bool slab_ok = false;
+    auto set_slab = [&](int dtdh) {
+        const int dt = dtdh / 3, dh = dtdh - dt * 3;
+        int ti = t_out + dt - 2;
+        ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
+        const int hu = h_out + dh - 1;                         // row in the (up-sampled) padded input
+        slab_ok = hu >= 0 && hu < p.H_out;                     // wave-uniform (stride 1, pad 1: H_out rows)
+        const int hh = UPS ? hu >> 1 : hu;
+        slab_row = p.x + ((int64_t)ti * p.H_in + (slab_ok ? hh : 0)) * p.W_in * p.C_in;
+    };
+    int a_dst = 0, w_dst = 0;                   // stage (0 / 1) the NEXT A slab / W tile is written to
+    auto stage_a = [&](int sa, int cb) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (wave * PPW + i < NPIECE) {                     // wave-uniform
+                const bool ok = slab_ok && a_woff[i] >= 0;
+                const unsigned short* src = ok ? slab_row + a_woff[i] + cb * BK : p.zeros + zoff;
+                glds16(src, dma_a + sa * A_STAGE + i * 1024);
+            }
+        }
+    };
+    auto stage_w = [&](int sw, int dtdh, int cb, int dw) {
+        const int koff = (dtdh * 3 + dw) * p.C_in + cb * BK;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) glds16(wbase[i] + koff, dma_w + sw * W_BYTES + i * 1024);
+    };
+    auto next_slab = [&]() {
+        if (++n_cb == cblocks) {
+            n_cb = 0;
+            ++n_dtdh;
+            set_slab(n_dtdh);
+        }
+    };
+
+#define EA_C3_PHASE(DW, KS, HAS_NEXT)   /* KS = phase: k32 step KS >> 1, M half KS & 1 */                    \
+    {                                                                                                       \
+        bf16x8 af[MH];                                                                                      \
+        if (((KS) & 1) == 0) {                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+                wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k[(KS) >> 1] + j * 2048));               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                      \
+            af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[DW][(KS) >> 1] + (((KS) & 1) * MH + i) * ISTEP)); \
+        if ((KS) == 0 && (DW) == 2 && (HAS_NEXT)) {                                                         \
+            next_slab();                                                                                    \
+            stage_a(a_dst, n_cb);                                                                           \
+        }                                                                                                   \
+        if ((KS) == 1 && (HAS_NEXT)) stage_w(w_dst, n_dtdh, n_cb, ((DW) + 1) % 3);                          \
+        if ((KS) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                  \
+                acc[((KS) & 1) * MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+                    wf[j], af[i], acc[((KS) & 1) * MH + i][j], 0, 0, 0);                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+    // one tile = one (slab, dw): four k-steps; afterwards the W stage toggles (in place, on the fragment offsets)
+#define EA_C3_TILE(DW, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 0, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 1, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 2, HAS_NEXT)                                          \
+    EA_C3_PHASE(DW, 3, HAS_NEXT)                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) w_k[ks] += w_step;   \
+    w_step = -w_step;                                                     \
+    w_dst ^= 1;
+
+    // ---- prologue: slab (dt,dh) = 0, channel block 0 -> A stage 0; its dw = 0 weights -> W stage 0
+    set_slab(0);
+    stage_a(0, 0);
+    stage_w(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // one trip = one slab = three tiles (dw = 0, 1, 2); the A stage toggles per slab, the W stage per tile
+    const int nslabs = 9 * cblocks;
+    int a_step = A_STAGE, w_step = W_BYTES;
+    a_dst = 1;
+    w_dst = 1;
+    for (int sl = 0; sl < nslabs; ++sl) {
+        EA_C3_TILE(0, true)
+        EA_C3_TILE(1, true)
+        EA_C3_TILE(2, sl + 1 < nslabs)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a_k[dw][ks] += a_step;
+        a_step = -a_step;
+        a_dst ^= 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef EA_C3_TILE
+#undef EA_C3_PHASE
+
+    // ---- epilogue: lane owns voxel m (one per M tile), channels n0 .. n0+3 of every N tile
+    const int64_t frame = (int64_t)p.H_out * p.W_out;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int64_t m = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + i * 16 + lr;
+        int64_t m_dst0 = m, m_dst1 = -1;
+        if (p.tdup && t_out >= 1) {
+            const int64_t rem = m - (int64_t)t_out * frame;
+            m_dst0 = (2 * (int64_t)t_out - 1) * frame + rem;
+            m_dst1 = (2 * (int64_t)t_out) * frame + rem;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = col0 + wc * 64 + j * 16 + lq * 4;
+            if (n0 >= p.C_out) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+            if (p.bias) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += b0[e];
+            }
+            if (p.res) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res + m * p.C_out + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x4*>(p.y + m_dst0 * p.C_out + n0) = o;
+            if (m_dst1 >= 0) *reinterpret_cast<bf16x4*>(p.y + m_dst1 * p.C_out + n0) = o;
+        }
+    }
+}
+
+int g_conv_mfma = 16;  // ea_set_option("conv_mfma", 16 | 32): MFMA shape of the row-slab kernel
 int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles;
                        // 1024: force the row-slab kernel wherever it applies
 
@@ -717,6 +946,11 @@ __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned s
 
 }  // namespace
 
+int ea_conv_mfma_set(int v) {
+    if (v != 16 && v != 32) return -1;
+    g_conv_mfma = v;
+    return 0;
+}
 int ea_conv_tile_set(int v) {
     if (v != 0 && v != 128 && v != 256 && v != 512 && v != 1024) return -1;
     g_conv_tile = v;
@@ -775,6 +1009,25 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
             attr3_done = true;
         }
         const dim3 g3((unsigned)grid3), b3(512);
+        if (g_conv_mfma == 16) {
+            static bool attr4_done = false;
+            if (!attr4_done) {
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 128 * 128);
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 256 * 128);
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 128 * 128);
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 256 * 128);
+                attr4_done = true;
+            }
+            if (bn == 256 && ups)
+                hipLaunchKernelGGL((conv3d_cl_row16_kernel<256, true>), g3, b3, lds3, (hipStream_t)stream, p);
+            else if (bn == 256)
+                hipLaunchKernelGGL((conv3d_cl_row16_kernel<256, false>), g3, b3, lds3, (hipStream_t)stream, p);
+            else if (ups)
+                hipLaunchKernelGGL((conv3d_cl_row16_kernel<128, true>), g3, b3, lds3, (hipStream_t)stream, p);
+            else
+                hipLaunchKernelGGL((conv3d_cl_row16_kernel<128, false>), g3, b3, lds3, (hipStream_t)stream, p);
+            return ea_check_launch("ea_conv3d_cl_bf16");
+        }
         if (bn == 256 && ups)
             hipLaunchKernelGGL((conv3d_cl_row_kernel<256, true>), g3, b3, lds3, (hipStream_t)stream, p);
         else if (bn == 256)

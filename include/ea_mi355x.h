@@ -45,6 +45,7 @@ int ea_version(void);
  *   "gemm_mfma":    MFMA shape of the 256^2 GEMM kernel: 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = 32x32x16;
  *   "conv_tile":    0 = automatic, 128 = the 128^2 kernel, 256 / 512 = the ping-pong kernels with 256- / 512-voxel tiles,
  *                   1024 = the row-slab kernel wherever it applies (3x3x3, stride 1, rows a multiple of 256 voxels wide);
+ *   "conv_mfma":    MFMA shape of the row-slab convolution kernel: 16 = 16x16x32 (default), 32 = 32x32x16;
  *   "attn_variant": 3 = the pipelined kernel on 16x16x32 MFMAs (default; serves calls with the scale folded into Q,
  *                   others fall through to 2), 2 = the pipelined kernel on 32x32x16, 1 = the first, un-pipelined kernel. */
 int ea_set_option(const char* name, int value);

@@ -137,14 +137,17 @@ ROW_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mfma", [16, 32])
 @pytest.mark.parametrize("T,H,W,Ci,Co,ups,tdup,res", ROW_CASES)
-def test_conv3d_cl_row_slab(T, H, W, Ci, Co, ups, tdup, res):
+def test_conv3d_cl_row_slab(T, H, W, Ci, Co, ups, tdup, res, mfma):
     from easyanimate_amd import _lib
     _lib.set_option("conv_tile", 1024)
+    _lib.set_option("conv_mfma", mfma)
     try:
         test_conv3d_cl(T, H, W, Ci, Co, 3, 1, 1, 1, ups, tdup, res)
     finally:
         _lib.set_option("conv_tile", 0)
+        _lib.set_option("conv_mfma", 16)
 
 
 def test_conv3d_cl_row_slab_is_deterministic_and_matches_tilewise():
@@ -161,14 +164,17 @@ def test_conv3d_cl_row_slab_is_deterministic_and_matches_tilewise():
         y0 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
         _lib.set_option("conv_tile", 1024)
         try:
-            y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
-            for _ in range(4):
-                assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
+            for mfma in (32, 16):
+                _lib.set_option("conv_mfma", mfma)
+                y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+                for _ in range(4):
+                    assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
+                d = (y0.float() - y1.float()).abs()
+                # a few last-bit bf16 flips only
+                assert bool((d <= 2 ** -7 * y0.float().abs().clamp_min(1.0)).all()) and (d > 0).float().mean().item() < 0.01
         finally:
             _lib.set_option("conv_tile", 0)
-        d = (y0.float() - y1.float()).abs()
-        # a few last-bit bf16 flips only
-        assert bool((d <= 2 ** -7 * y0.float().abs().clamp_min(1.0)).all()) and (d > 0).float().mean().item() < 0.01
+            _lib.set_option("conv_mfma", 16)
 
 
 def test_small_cin_conv_via_im2col():

@@ -26,11 +26,13 @@ for (T, H, W, Ci, Co) in [(13, 1024, 1024, 128, 128), (13, 1024, 1024, 256, 128)
     w = (torch.randn(Co, 27 * Ci, device="cuda") / (27 * Ci) ** 0.5).to(torch.bfloat16)
     b = torch.randn(Co, device="cuda")
     fl = 2.0 * 27 * Ci * Co * T * H * W
-    for tile in ((256, 512, 1024) if Co == 128 else (256, 1024)):
+    for tile, mfma in (((512, 32), (1024, 32), (1024, 16)) if Co == 128 else ((256, 32), (1024, 32), (1024, 16))):
         _lib.set_option("conv_tile", tile)
+        _lib.set_option("conv_mfma", mfma)
         ms = timeit(lambda: ops.conv3d_cl(x, w, b, 3, 1, 1, 1))
-        print(json.dumps({"kernel": "conv3d_cl", "tile": tile, "T": T, "HW": H, "Cin": Ci, "Cout": Co, "ms": ms, "TFLOPs": fl / ms / 1e9}), flush=True)
+        print(json.dumps({"kernel": "conv3d_cl", "tile": tile, "mfma": mfma, "T": T, "HW": H, "Cin": Ci, "Cout": Co, "ms": ms, "TFLOPs": fl / ms / 1e9}), flush=True)
     _lib.set_option("conv_tile", 0)
+    _lib.set_option("conv_mfma", 16)
     del x, w
 for (T, HW, C) in [(13, 1024 * 1024, 128), (13, 512 * 512, 256)]:
     x = torch.randn(T, HW, C, device="cuda").to(torch.bfloat16)
