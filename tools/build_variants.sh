@@ -19,12 +19,6 @@ build() {  # tag, extra flags...
 # (measured in round 1: F 1141 TF > D 1133 > E 1112 > A 1105; -amdgpu-igrouplp-exact-solver needs
 #  -amdgpu-igrouplp-exact-solver-max-branches=<N> and a `timeout`: uncapped it ran for > 30 minutes on this kernel)
 COMMON="$COMMON -fno-slp-vectorize"
-build P2 -DEA_ATT3_PPG=2 &
-build P4 -DEA_ATT3_PPG=4 &
-build L1 -DEA_ATT3_LEAD=1 &
-build L0 -DEA_ATT3_LEAD=0 &
-wait
-build LP0 -DEA_ATT3_LDSPTR=0 &
-build L1P2 -DEA_ATT3_LEAD=1 -DEA_ATT3_PPG=2 &
+build MS0 -DEA_ATT3_MFMASUM=0 &
 wait
 ls $OUT
