@@ -71,6 +71,12 @@ def load() -> ctypes.CDLL:
     lib.ea_attention_state_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.ea_set_option.restype = c_int
     lib.ea_set_option.argtypes = [ctypes.c_char_p, c_int]
+    lib.ea_get_counter.restype = ctypes.c_longlong
+    lib.ea_get_counter.argtypes = [ctypes.c_char_p]
+    lib.ea_counter_name.restype = c_int
+    lib.ea_counter_name.argtypes = [c_int, ctypes.c_char_p, c_int]
+    lib.ea_reset_counters.restype = None
+    lib.ea_reset_counters.argtypes = []
     _lib = lib
     return lib
 
@@ -85,3 +91,19 @@ def call(name: str, *args) -> None:
 def set_option(name: str, value: int) -> None:
     """ea_set_option: tuning / benchmarking switches (e.g. "gemm_tile" 0|128|256)."""
     call("ea_set_option", name.encode(), int(value))
+
+
+def reset_counters() -> None:
+    load().ea_reset_counters()
+
+
+def counters() -> dict:
+    """ea_get_counter / ea_counter_name: {kernel variant: launches since the last reset} (non-zero entries)."""
+    lib = load()
+    out, buf, i = {}, ctypes.create_string_buffer(64), 0
+    while lib.ea_counter_name(i, buf, 64) == 0:
+        n = lib.ea_get_counter(buf.value)
+        if n:
+            out[buf.value.decode()] = int(n)
+        i += 1
+    return out

@@ -25,6 +25,41 @@ int ea_check_launch(const char* what) {
 }
 
 extern "C" const char* ea_last_error_string(void) { return g_err; }
+
+// Dispatch counters: which kernel variant served a call (tests assert that the kernels a parity test is meant to
+// cover actually ran; host-side bookkeeping only, one relaxed increment per launch).
+namespace {
+struct Counter { char name[48]; long long n; };
+Counter g_counters[64];
+int g_ncounters = 0;
+}  // namespace
+
+void ea_count(const char* name) {
+    for (int i = 0; i < g_ncounters; ++i)
+        if (!strcmp(g_counters[i].name, name)) { ++g_counters[i].n; return; }
+    if (g_ncounters < 64) {
+        strncpy(g_counters[g_ncounters].name, name, sizeof(g_counters[0].name) - 1);
+        g_counters[g_ncounters++].n = 1;
+    }
+}
+
+extern "C" long long ea_get_counter(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < g_ncounters; ++i)
+        if (!strcmp(g_counters[i].name, name)) return g_counters[i].n;
+    return 0;
+}
+
+extern "C" int ea_counter_name(int index, char* buf, int buf_len) {
+    if (index < 0 || index >= g_ncounters || !buf || buf_len <= 0) return EA_ERR_ARG;
+    strncpy(buf, g_counters[index].name, (size_t)buf_len - 1);
+    buf[buf_len - 1] = 0;
+    return EA_OK;
+}
+
+extern "C" void ea_reset_counters(void) {
+    for (int i = 0; i < g_ncounters; ++i) g_counters[i].n = 0;
+}
 extern "C" int ea_version(void) { return 100; }
 
 // Tuning / benchmarking switches.  Each kernel file owns its switch; results never depend on them.

@@ -385,12 +385,14 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     hipStream_t st = (hipStream_t)stream;
     unsigned short* o16 = (unsigned short*)out;
     f32x4* st4 = reinterpret_cast<f32x4*>(state);
-    if (variant == 1)
+    if (variant == 1) {
+        ea_count("attention_v1");
         hipLaunchKernelGGL(attention_fwd_kernel, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh, kv_end,
                            s_pad, q_begin, q_end, nqb, scale_log2e);
-    else {
+    } else {
         // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
         const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;
+        ea_count(variant == 3 && folded ? "attention_v3" : "attention_v2");
 #define EA_ATT_LAUNCH(MODE, FOLDED)                                                                                       \
     if (variant == 3 && FOLDED)                                                                                           \
         hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid, blk, ATT_LDS, st, q, k, vt, o16,                         \

@@ -20,6 +20,7 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 // ---- error plumbing (host) --------------------------------------------------------------------
 void ea_set_error(const char* fmt, ...);
 int ea_check_launch(const char* what);
+void ea_count(const char* name);   // dispatch counter (ea_get_counter)
 
 #define EA_REQUIRE(cond, ...)        \
     do {                             \

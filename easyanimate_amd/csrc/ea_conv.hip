@@ -1018,6 +1018,7 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
                 (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 256 * 128);
                 attr4_done = true;
             }
+            ea_count(bn == 256 ? (ups ? "conv_row16_256_ups" : "conv_row16_256") : (ups ? "conv_row16_128_ups" : "conv_row16_128"));
             if (bn == 256 && ups)
                 hipLaunchKernelGGL((conv3d_cl_row16_kernel<256, true>), g3, b3, lds3, (hipStream_t)stream, p);
             else if (bn == 256)
@@ -1028,6 +1029,7 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
                 hipLaunchKernelGGL((conv3d_cl_row16_kernel<128, false>), g3, b3, lds3, (hipStream_t)stream, p);
             return ea_check_launch("ea_conv3d_cl_bf16");
         }
+        ea_count(bn == 256 ? (ups ? "conv_row32_256_ups" : "conv_row32_256") : (ups ? "conv_row32_128_ups" : "conv_row32_128"));
         if (bn == 256 && ups)
             hipLaunchKernelGGL((conv3d_cl_row_kernel<256, true>), g3, b3, lds3, (hipStream_t)stream, p);
         else if (bn == 256)
@@ -1055,6 +1057,7 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
             attr2_done = true;
         }
         hipStream_t st2 = (hipStream_t)stream;
+        ea_count(bn == 256 ? "conv_pp_256x256" : (bm == 512 ? "conv_pp_512x128" : "conv_pp_256x128"));
         if (bn == 256)
             hipLaunchKernelGGL((conv3d_cl_pp_kernel<256, 256>), dim3((unsigned)grid2), dim3(512), lds, st2, p);
         else if (bm == 512)
@@ -1072,6 +1075,7 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
         (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
         attr_done = true;
     }
+    ea_count("conv_128x128");
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)grid), dim3(256), CONV_LDS, (hipStream_t)stream, p);
     return ea_check_launch("ea_conv3d_cl_bf16");
 }

@@ -699,8 +699,10 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
                 hipFuncSetAttribute((const void*)gemm256_mi16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 attr16_done = true;
             }
+            ea_count("gemm_256_mi16");
             hipLaunchKernelGGL(gemm256_mi16_kernel<EPI>, grid, dim3(threads), lds, st, p);
         } else {
+            ea_count("gemm_256_mi32");
             hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
         }
     } else {
@@ -708,6 +710,7 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done[0] = true;
         }
+        ea_count("gemm_128");
         hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
     }
     return EA_OK;

@@ -19,9 +19,12 @@ def _gen(seed: int, name: str) -> torch.Generator:
 def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, style: str = "default") -> torch.Tensor:
     """PyTorch-default-like init: weights U(-1/sqrt(fan_in), +), biases likewise; norm gains 1+N(0,.02).
     style="stress": adaLN linears x4 and norm affines perturbed x5 so that gates/scales are O(1) and kernel
-    errors are visible at the output (SURVEY 8d noise-floor finding)."""
+    errors are visible at the output (SURVEY 8d noise-floor finding).  A "_bf16" suffix rounds the values to bf16."""
+    if style.endswith("_bf16"):
+        # bf16-representable values (what a released bf16 checkpoint holds): the fp32 reference and the bf16 product
+        # then really do start from IDENTICAL weights
+        return synth_tensor(name, shape, seed, style[:-5]).to(torch.bfloat16).to(torch.float32)
     g = _gen(seed, name)
-    leaf = name.rsplit(".", 2)
     is_bias = name.endswith(".bias")
     is_norm = any(t in name for t in (".norm.", "norm_q", "norm_k", "norm_final", ".norm1.", ".norm2.", "group_norm",
                                       "conv_norm_out", "text_proj.0")) and len(shape) == 1 and "linear" not in name

@@ -15,7 +15,10 @@
  *   - return value: 0 = success; EA_ERR_ARG = invalid argument / unsupported shape; any other value
  *     is the hipError_t of the failed launch.  ea_last_error_string() describes the last non-zero
  *     return on the calling thread.  Nothing aborts or throws across this boundary.
- *   - re-entrant, stateless; safe to call from one thread per process (one process per GPU).
+ *   - the compute entry points keep no state between calls and own no memory.  Two pieces of PROCESS-WIDE mutable
+ *     state exist, both host-side and neither affecting results: the tuning switches of ea_set_option() (they select
+ *     WHICH kernel variant serves a call) and the dispatch counters read by ea_get_counter().  Neither is
+ *     synchronised: call from one thread per process (one process per GPU), as the reference's single Python thread does.
  */
 #ifndef EA_MI355X_H
 #define EA_MI355X_H
@@ -49,6 +52,14 @@ int ea_version(void);
  *   "attn_variant": 3 = the pipelined kernel on 16x16x32 MFMAs (default; serves calls with the scale folded into Q,
  *                   others fall through to 2), 2 = the pipelined kernel on 32x32x16, 1 = the first, un-pipelined kernel. */
 int ea_set_option(const char* name, int value);
+/* Dispatch counters (host-side bookkeeping): how many launches each kernel variant has served since the last reset,
+ * e.g. "conv_row16_128", "conv_row16_256_ups", "conv_pp_256x256", "conv_128x128", "gemm_256_mi16", "gemm_128",
+ * "attention_v3".  Tests use them to assert that the kernels a parity case is meant to cover actually ran.
+ * ea_get_counter: count (0 for a name never hit, -1 for NULL); ea_counter_name: name of the index-th counter seen so
+ * far (EA_ERR_ARG past the end). */
+long long ea_get_counter(const char* name);
+int ea_counter_name(int index, char* buf, int buf_len);
+void ea_reset_counters(void);
 
 /* ---- normalisation ------------------------------------------------------------------------- */
 

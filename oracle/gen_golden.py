@@ -44,12 +44,18 @@ def _g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@torch.no_grad()
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    ns = ref_loader.load()
-    shim = ns.shim
+SECTIONS = {}
 
+
+def section(name):
+    def deco(fn):
+        SECTIONS[name] = fn
+        return fn
+    return deco
+
+
+@section("rope")
+def gen_rope(ns, shim):
     # ---- rope tables + crop regions (pipeline_easyanimate.py:82-97, 999-1011)
     rope = {}
     for (gh, gw, f) in [(4, 4, 3), (16, 16, 1), (24, 42, 1), (6, 10, 4)]:
@@ -58,6 +64,9 @@ def main():
         rope[f"{gh}x{gw}x{f}"] = dict(crops=cc, cos=cos, sin=sin)
     torch.save(rope, os.path.join(OUT, "rope.pt"))
 
+
+@section("scheduler")
+def gen_scheduler(ns, shim):
     # ---- scheduler (diffusers FlowMatchEulerDiscreteScheduler restated in the shim)
     sched = {}
     for n, shift in [(2, 1.0), (50, 1.0), (25, 3.0)]:
@@ -66,6 +75,9 @@ def main():
         sched[f"n{n}_shift{shift}"] = dict(timesteps=s.timesteps.clone(), sigmas=s.sigmas.clone())
     torch.save(sched, os.path.join(OUT, "scheduler.pt"))
 
+
+@section("dit_block")
+def gen_dit_block(ns, shim):
     # ---- one DiT block, stress init (attention.py:1028-1163)
     for name, mmdit in (("dit_block_mmdit", True), ("dit_block_shared", False)):
         blk = ns.attention.EasyAnimateDiTBlock(dim=128, num_attention_heads=2, attention_head_dim=64, time_embed_dim=64,
@@ -82,6 +94,9 @@ def main():
                         h_out_bf16=hb.float(), e_out_bf16=eb.float(), heads=2, norm_eps=1e-5),
                    os.path.join(OUT, f"{name}.pt"))
 
+
+@section("transformer")
+def gen_transformer(ns, shim):
     # ---- tiny transformers: T2V (16 ch), InP (33 ch), mixed mmdit/shared blocks
     for name, over, style in (("transformer_t2v", {}, "stress"), ("transformer_inp", dict(in_channels=33), "default"),
                               ("transformer_mixed", dict(mmdit_layers=1), "stress")):
@@ -103,6 +118,9 @@ def main():
         torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=lat, inpaint=inp, enc=enc, t=t, cos=cos, sin=sin,
                         out=out, out_bf16=outb.float()), os.path.join(OUT, f"{name}.pt"))
 
+
+@section("denoise_loop")
+def gen_denoise_loop(ns, shim):
     # ---- 2-step CFG denoise loops on the tiny T2V model (pipeline_easyanimate.py:1069-1111), fp32 and bf16
     for name, style in (("denoise_loop", "stress"), ("denoise_loop_default", "default")):
         cfg = dict(TINY)
@@ -133,6 +151,10 @@ def main():
         torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=latents, enc=enc, cos=cos, sin=sin,
                         guidance=6.0, steps=2, trace=traces[torch.float32], trace_bf16=traces[torch.bfloat16]),
                    os.path.join(OUT, f"{name}.pt"))
+
+
+@section("teacache")
+def gen_teacache(ns, shim):
     # ---- TeaCache (transformer3d.py:90-121,1564-1636): 8-step CFG loop on the tiny T2V model with the step-skip
     # heuristic on; records the reference's rel-L1 distances, skip decisions and latents (fp32 and bf16 runs)
     cfg = dict(TINY)
@@ -183,6 +205,9 @@ def main():
     torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style="stress", latents=latents, enc=enc, cos=cos, sin=sin, guidance=6.0,
                     steps=n_steps, coefficients=coeff, runs=tea), os.path.join(OUT, "teacache_loop.pt"))
 
+
+@section("vae_tiny")
+def gen_vae_tiny(ns, shim):
     # ---- tiny MAGVIT VAE in the reference's real (chunked, cached) inference mode: encode + decode
     vkw = dict(TINY_VAE)
     vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()
@@ -198,6 +223,9 @@ def main():
     torch.save(dict(cfg=vkw, shapes=shapes, seed=2, style="default", video=video, z=zlat, moments=moments, dec=dec,
                     moments_bf16=moments_b, dec_bf16=dec_b), os.path.join(OUT, "vae_tiny.pt"))
 
+
+@section("i2v")
+def gen_i2v(ns, shim):
     # ---- I2V conditioning helpers (pipeline_easyanimate_inpaint.py:116-149, utils/utils.py:128-157)
     from easyanimate.pipeline import pipeline_easyanimate_inpaint as inp
     g = _g(21)
@@ -209,9 +237,198 @@ def main():
     rm["random_first1"] = inp.resize_mask(1 - mask2, torch.zeros(1, 16, 4, 2, 2), True)
     torch.save(dict(mask=mask, mask2=mask2, resized=rm), os.path.join(OUT, "i2v_resize_mask.pt"))
 
+
+# =====================================================================================================
+# round 2: stated-bar fixtures.  Large inputs are regenerated from seeds by the tests
+# (inputs_from_seed below is imported by tests/ so generator and test cannot drift); large outputs are stored fp16.
+# =====================================================================================================
+FULL_VAE = dict(in_channels=3, out_channels=3, block_out_channels=[128, 256, 512, 512],
+                down_block_types=("SpatialDownBlock3D", "SpatialTemporalDownBlock3D", "SpatialTemporalDownBlock3D", "SpatialTemporalDownBlock3D"),
+                up_block_types=("SpatialUpBlock3D", "SpatialTemporalUpBlock3D", "SpatialTemporalUpBlock3D", "SpatialTemporalUpBlock3D"),
+                mid_block_attention_type="spatial", latent_channels=16, norm_num_groups=32, spatial_group_norm=True,
+                cache_mag_vae=True, slice_mag_vae=False, cache_compression_vae=False, slice_compression_vae=False,
+                mini_batch_encoder=4, mini_batch_decoder=1, layers_per_block=2)
+
+FULL_DIT = dict(num_attention_heads=48, attention_head_dim=64, in_channels=16, out_channels=16, patch_size=2,
+                num_layers=2, time_embed_dim=512, add_norm_text_encoder=True, text_embed_dim=3584, text_embed_dim_t5=None,
+                norm_eps=1e-5, time_position_encoding_type="3d_rope", enable_text_attention_mask=True)
+
+
+def vae_full_inputs(seed=9, frames=9, size=256):
+    """Seeded inputs of the full-width VAE fixture (<= 9 x 256^2)."""
+    g = _g(seed)
+    video = torch.rand(1, 3, frames, size, size, generator=g) * 2 - 1
+    z = torch.randn(1, 16, (frames - 1) // 4 + 1, size // 8, size // 8, generator=g)
+    return video, z
+
+
+def dit_full_inputs(cfg, seed, B, Fr, H, W, T):
+    g = _g(seed)
+    lat = torch.randn(B, 16, Fr, H, W, generator=g)
+    extra = torch.randn(B, cfg["in_channels"] - 16, Fr, H, W, generator=g) if cfg["in_channels"] > 16 else None
+    enc = torch.randn(B, T, cfg["text_embed_dim"], generator=g) * 3
+    return lat, extra, enc
+
+
+def _mse(a, b):
+    return ((a.double() - b.double()) ** 2).mean().item()
+
+
+@section("vae_full")
+def gen_vae_full(ns, shim):
+    # ---- full-width MAGVIT VAE (128/256/512/512, mid-block head_dim 512), 9 x 256^2, the reference's chunked/cached mode
+    vkw = dict(FULL_VAE)
+    vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()
+    shapes = _load_sd(vae, 2, "default")
+    video, zlat = vae_full_inputs()
+    import time
+    t0 = time.time()
+    moments = vae.encode(video)[0].parameters
+    print("  encode fp32", time.time() - t0, flush=True)
+    t0 = time.time()
+    dec = vae.decode(zlat)[0]
+    print("  decode fp32", time.time() - t0, flush=True)
+    out = dict(cfg=vkw, shapes=shapes, seed=2, style="default", input_seed=9, frames=9, size=256,
+               video_sum=video.double().sum().item(), z_sum=zlat.double().sum().item(),
+               moments=moments, dec_f16=dec.to(torch.float16), dec_std=dec.std().item(), moments_std=moments.std().item())
+    torch.save(out, os.path.join(OUT, "vae_full_9x256.pt"))
+    if os.environ.get("EA_GOLDEN_BF16_FLOOR", "1") == "1":   # the reference's own bf16 path: scalars only (slow on CPU)
+        vb = vae.to(torch.bfloat16)
+        t0 = time.time()
+        mb = vb.encode(video.bfloat16())[0].parameters.float()
+        db = vb.decode(zlat.bfloat16())[0].float()
+        print("  bf16 pass", time.time() - t0, flush=True)
+        out.update(moments_floor_mse=_mse(mb, moments), dec_floor_mse=_mse(db, dec))
+        torch.save(out, os.path.join(OUT, "vae_full_9x256.pt"))
+    print("  moments std", out["moments_std"], "dec std", out["dec_std"], {k: v for k, v in out.items() if k.endswith("floor_mse")})
+
+
+def _ref_loop(ns, shim, m, latents, enc, rope, steps, guidance, dt, keep=None):
+    """The reference's sampling loop (pipeline_easyanimate.py:1069-1111) over the shim-hosted reference transformer."""
+    mm = copy.deepcopy(m).to(dt)
+    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(steps, device="cpu", mu=1)
+    x = latents.clone().to(dt)
+    kept = {}
+    for i, t in enumerate(s.timesteps):
+        li = torch.cat([x] * 2)
+        te = torch.tensor([t] * 2).to(dtype=li.dtype)
+        v = mm(li, te, encoder_hidden_states=enc.to(dt), image_rotary_emb=rope, return_dict=False)[0]
+        vu, vt = v.chunk(2)
+        v = vu + guidance * (vt - vu)
+        x = s.step(v, t, x, return_dict=False)[0]
+        if keep and (i + 1) in keep:
+            kept[i + 1] = x.float().clone()
+    return x.float(), kept
+
+
+@section("denoise_loop_50")
+def gen_denoise_loop_50(ns, shim):
+    # ---- the stated bar at the stated schedule: 50 Flow steps, CFG 6, tiny T2V model; reference fp32 and bf16 traces
+    # "_bf16" styles: weights, initial latents and text embeddings are bf16-representable values, i.e. the fp32 reference
+    # and a bf16 implementation start from bit-identical inputs (what a released bf16 checkpoint gives); without it the
+    # fp32 trace uses weights the bf16 model cannot hold and the comparison also measures the checkpoint's rounding.
+    for name, style in (("denoise_loop_50", "stress"), ("denoise_loop_50_default", "default"),
+                        ("denoise_loop_50_bf16in", "stress_bf16"), ("denoise_loop_50_default_bf16in", "default_bf16")):
+        cfg = dict(TINY)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+        shapes = _load_sd(m, 3, style)
+        g = _g(43)
+        Fr, H, W, T = 2, 8, 8, 6
+        latents = torch.randn(1, 16, Fr, H, W, generator=g)
+        enc = torch.randn(2, T, cfg["text_embed_dim"], generator=g)
+        if style.endswith("_bf16"):
+            latents, enc = latents.bfloat16().float(), enc.bfloat16().float()
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        rope = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        keep = (1, 10, 25, 50)
+        xf, kf = _ref_loop(ns, shim, m, latents, enc, rope, 50, 6.0, torch.float32, keep)
+        xb, kb = _ref_loop(ns, shim, m, latents, enc, rope, 50, 6.0, torch.bfloat16, keep)
+        print(f"  {name}: final latent std {xf.std().item():.3f}; reference bf16-vs-fp32 MSE by step",
+              {k: _mse(kb[k], kf[k]) for k in keep})
+        torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=latents, enc=enc, cos=rope[0], sin=rope[1],
+                        guidance=6.0, steps=50, trace=kf, trace_bf16=kb), os.path.join(OUT, f"{name}.pt"))
+
+
+@section("transformer_r2")
+def gen_transformer_r2(ns, shim):
+    # ---- branches of the same forward that round 1 left untested: the V5 two-encoder text path (text_proj_t5,
+    # transformer3d.py:1533-1536; add_norm_text_encoder False as config/easyanimate_video_v5_magvit_multi_text_encoder.yaml
+    # and True), control_latents alone and together with inpaint_latents (:1523-1526)
+    cases = (("transformer_t5", dict(add_norm_text_encoder=False, text_embed_dim=48, text_embed_dim_t5=40), 0, "stress"),
+             ("transformer_t5_norm", dict(add_norm_text_encoder=True, text_embed_dim=48, text_embed_dim_t5=48), 0, "stress"),
+             ("transformer_control", dict(in_channels=32), 16, "stress"),
+             ("transformer_inp_control", dict(in_channels=49), 16, "default"))
+    for name, over, n_ctrl, style in cases:
+        cfg = dict(TINY, **over)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+        shapes = _load_sd(m, 3, style)
+        g = _g(17)
+        B, Fr, H, W, T, T5 = 2, 3, 8, 12, 9, 5
+        lat = torch.randn(B, 16, Fr, H, W, generator=g)
+        n_inp = cfg["in_channels"] - 16 - n_ctrl
+        inp = torch.randn(B, n_inp, Fr, H, W, generator=g) if n_inp else None
+        ctrl = torch.randn(B, n_ctrl, Fr, H, W, generator=g) if n_ctrl else None
+        enc = torch.randn(B, T, cfg["text_embed_dim"], generator=g) * 3
+        enc5 = torch.randn(B, T5, cfg["text_embed_dim_t5"], generator=g) * 3 if cfg["text_embed_dim_t5"] else None
+        t = torch.tensor([603.0, 603.0]).to(torch.bfloat16).float()
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        bf = lambda x: None if x is None else x.bfloat16()
+        out = m(lat, t, encoder_hidden_states=enc, encoder_hidden_states_t5=enc5, image_rotary_emb=(cos, sin),
+                inpaint_latents=inp, control_latents=ctrl, return_dict=False)[0]
+        mb = copy.deepcopy(m).to(torch.bfloat16)
+        outb = mb(bf(lat), t.bfloat16(), encoder_hidden_states=bf(enc), encoder_hidden_states_t5=bf(enc5),
+                  image_rotary_emb=(cos, sin), inpaint_latents=bf(inp), control_latents=bf(ctrl), return_dict=False)[0]
+        print(f"  {name}: out std {out.std().item():.3f}, floor {_mse(outb.float(), out):.3e}")
+        torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=lat, inpaint=inp, control=ctrl, enc=enc, enc_t5=enc5,
+                        t=t, cos=cos, sin=sin, out=out, out_bf16=outb.float()), os.path.join(OUT, f"{name}.pt"))
+
+
+@section("transformer_full")
+def gen_transformer_full(ns, shim):
+    # ---- full-width (d = 3072 = 48 x 64, ff 12288, text 3584, time 512) 2-layer forwards, SURVEY 8d-(i):
+    # T2V 16 channels at 5 x 64 x 64 latents (N = 5120 video + 256 text tokens) and InP 33 channels at 3 x 32 x 48
+    # (N = 1152, T = 77: unaligned text).  Inputs are regenerated from seeds by the tests (dit_full_inputs).
+    import time
+    for name, over, dims, style, floor in (("transformer_full_t2v", {}, (2, 5, 64, 64, 256), "stress", False),
+                                           ("transformer_full_inp", dict(in_channels=33), (2, 3, 32, 48, 77), "stress", True)):
+        cfg = dict(FULL_DIT, **over)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+        shapes = _load_sd(m, 5, style)
+        B, Fr, H, W, T = dims
+        lat, extra, enc = dit_full_inputs(cfg, 23, *dims)
+        t = torch.tensor([799.0] * B).to(torch.bfloat16).float()
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        t0 = time.time()
+        out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), inpaint_latents=extra, return_dict=False)[0]
+        print(f"  {name}: fp32 forward {time.time() - t0:.1f} s, out std {out.std().item():.3f}", flush=True)
+        rec = dict(cfg=cfg, shapes=shapes, seed=5, style=style, input_seed=23, dims=dims, t=t, crops=cc,
+                   lat_sum=lat.double().sum().item(), enc_sum=enc.double().sum().item(), out=out)
+        if floor:
+            t0 = time.time()
+            mb = m.to(torch.bfloat16)
+            outb = mb(lat.bfloat16(), t.bfloat16(), encoder_hidden_states=enc.bfloat16(), image_rotary_emb=(cos, sin),
+                      inpaint_latents=None if extra is None else extra.bfloat16(), return_dict=False)[0]
+            rec["floor_mse"] = _mse(outb.float(), out)
+            print(f"  {name}: bf16 forward {time.time() - t0:.1f} s, floor {rec['floor_mse']:.3e}", flush=True)
+        torch.save(rec, os.path.join(OUT, f"{name}.pt"))
+
+
+@torch.no_grad()
+def main(only=None):
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_loader.load()
+    shim = ns.shim
+    for name, fn in SECTIONS.items():
+        if only and name not in only:
+            continue
+        print(f"== {name}", flush=True)
+        fn(ns, shim)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:] or None)

@@ -221,7 +221,15 @@ class TeaCache:
         return calc, dist
 
 
-def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint_latents=None, teacache=None):
+def text_projection(sd: SD, pre: str, enc):
+    """text_proj / text_proj_t5, transformer3d.py:1405-1418,1533-1535: Linear, or RMSNorm -> Linear (add_norm_text_encoder)."""
+    if pre + ".0.weight" in sd:
+        return F.linear(rmsnorm(enc, sd[pre + ".0.weight"]), sd[pre + ".1.weight"], sd[pre + ".1.bias"])
+    return F.linear(enc, sd[pre + ".weight"], sd[pre + ".bias"])
+
+
+def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint_latents=None, teacache=None,
+                        control_latents=None, enc_t5=None):
     """EasyAnimateTransformer3DModel.forward, transformer3d.py:1496-1689 (no ref/clip inputs)."""
     heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
     inner = heads * dh
@@ -229,14 +237,15 @@ def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint
     B, C, Fr, H, W = latents.shape
     dtype = latents.dtype
     temb = time_embedding(sd, timestep, inner, dtype)
-    x = latents if inpaint_latents is None else torch.cat([latents, inpaint_latents], 1)
+    x = latents if inpaint_latents is None else torch.cat([latents, inpaint_latents], 1)      # :1523-1524
+    if control_latents is not None:
+        x = torch.cat([x, control_latents], 1)                                                  # :1525-1526
     x = x.permute(0, 2, 1, 3, 4).reshape(B * Fr, x.shape[1], H, W)
     x = F.conv2d(x, sd["proj.weight"], sd["proj.bias"], stride=p)
     x = x.reshape(B, Fr, inner, H // p, W // p).permute(0, 2, 1, 3, 4).flatten(2).transpose(1, 2)
-    if "text_proj.0.weight" in sd:
-        e = F.linear(rmsnorm(enc, sd["text_proj.0.weight"]), sd["text_proj.1.weight"], sd["text_proj.1.bias"])
-    else:
-        e = F.linear(enc, sd["text_proj.weight"], sd["text_proj.bias"])
+    e = text_projection(sd, "text_proj", enc)
+    if enc_t5 is not None:                                                                      # :1534-1536
+        e = torch.cat([e, text_projection(sd, "text_proj_t5", enc_t5)], dim=1)
     calc = True
     if teacache is not None:
         mod_in, _, _, _ = layernorm_zero(sd, "transformer_blocks.0.norm1.", x, e, temb, cfg["norm_eps"])

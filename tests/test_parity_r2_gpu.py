@@ -1,0 +1,168 @@
+"""Parity at the STATED bar on STATED configurations (VERDICT r1 "next round" item 1), all through the C ABI:
+
+  (a) the 50-step CFG-6 sampling loop: latent MSE < 1e-4 against the reference's fp32 run, no floor term;
+  (b) the full-width VAE (128/256/512/512, mid-block head_dim 512) at 9 x 256^2 against the reference's chunked /
+      cached run, with the dispatch counters proving that the row-slab and 256x256 ping-pong kernels served it;
+  (c) full-width (d = 3072) two-layer transformer forwards, 16- and 33-channel;
+  (d) the V5 two-encoder text path (text_proj_t5) and control_latents.
+
+Every golden file was produced by oracle/gen_golden.py executing the unchanged reference modules; large inputs are
+regenerated from seeds with the generator functions of that script (checksums stored in the fixture)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+BAR = 1e-4   # BASELINE.json north_star: "latent MSE vs reference < 1e-4"
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=False)
+
+
+def _mse(a, b):
+    return ((a.double().cpu() - b.double().cpu()) ** 2).mean().item()
+
+
+def _model(cfg, shapes, seed, style):
+    from easyanimate_amd import EasyAnimateTransformer3DModel
+    from easyanimate_amd.synthetic import synth_state_dict
+    m = EasyAnimateTransformer3DModel.from_config(cfg)
+    m.load_state_dict(synth_state_dict(shapes, seed, style), strict=True)
+    return m.to(torch.bfloat16).to(DEV).eval()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (a) 50 Flow steps, CFG 6 (pipeline_easyanimate.py:1069-1111) through EasyAnimatePipeline.denoise
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["denoise_loop_50", "denoise_loop_50_default", "denoise_loop_50_bf16in",
+                                  "denoise_loop_50_default_bf16in"])
+def test_denoise_loop_50_steps_meets_the_bar(name):
+    from easyanimate_amd import EasyAnimatePipeline, FlowMatchEulerDiscreteScheduler
+    g = _load(name + ".pt")
+    m = _model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    ref, refb = g["trace"], g["trace_bf16"]
+    enc = g["enc"].to(DEV).bfloat16()
+    res = {}
+    for fp32_latents in (True, False):
+        sched = FlowMatchEulerDiscreteScheduler(shift=1.0)
+        sched.set_timesteps(g["steps"], device=DEV, mu=1)
+        pipe = EasyAnimatePipeline(vae=None, transformer=m, scheduler=sched)
+        pipe.latents_fp32 = fp32_latents
+        kept = {}
+
+        def keep(p, i, t, kw, _k=kept):
+            if (i + 1) in ref:
+                _k[i + 1] = kw["latents"].float().cpu().clone()
+            return {}
+        with torch.no_grad():
+            x = pipe.denoise(g["latents"].to(DEV).bfloat16(), enc, (g["cos"], g["sin"]), sched.timesteps, g["guidance"],
+                             callback_on_step_end=keep)
+        assert x.dtype == torch.bfloat16 and sched.step_index == g["steps"]
+        res[fp32_latents] = {k: _mse(v, ref[k]) for k, v in kept.items()}
+        floor = {k: _mse(refb[k], ref[k]) for k in ref}
+        vs_b = {k: _mse(v, refb[k]) for k, v in kept.items()}
+        mode = "fp32 master latents (default)" if fp32_latents else "bf16 latents (reference bf16 bookkeeping)"
+        print(f"[parity] {name} [{mode}] latent MSE by step: new vs ref-fp32 "
+              + ", ".join(f"{k}: {v:.3e}" for k, v in res[fp32_latents].items())
+              + " | ref-bf16 vs ref-fp32 (floor) " + ", ".join(f"{k}: {v:.3e}" for k, v in floor.items())
+              + " | new vs ref-bf16 " + ", ".join(f"{k}: {v:.3e}" for k, v in vs_b.items()))
+    # the bar, with NO floor term, on the default path
+    assert res[True][g["steps"]] < BAR, res[True]
+    assert all(v < BAR for v in res[True].values())
+    # the reference-bookkeeping mode is held to the reference's own bf16 distance (it cannot do better than that)
+    assert res[False][g["steps"]] <= 1.5 * _mse(refb[g["steps"]], ref[g["steps"]])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (d) text_proj_t5 and control_latents (transformer3d.py:1523-1526, 1533-1536)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["transformer_t5", "transformer_t5_norm", "transformer_control", "transformer_inp_control"])
+def test_transformer_branches_vs_golden(name):
+    g = _load(name + ".pt")
+    m = _model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    dev = lambda x: None if x is None else x.to(DEV).bfloat16()
+    with torch.no_grad():
+        out = m(dev(g["latents"]), dev(g["t"]), encoder_hidden_states=dev(g["enc"]), encoder_hidden_states_t5=dev(g["enc_t5"]),
+                image_rotary_emb=(g["cos"], g["sin"]), inpaint_latents=dev(g["inpaint"]), control_latents=dev(g["control"]),
+                return_dict=False)[0]
+    mse, floor = _mse(out.float(), g["out"]), _mse(g["out_bf16"], g["out"])
+    print(f"[parity] {name}: new-bf16 vs ref-fp32 MSE={mse:.3e} | ref-bf16 floor {floor:.3e} | new vs ref-bf16 "
+          f"{_mse(out.float(), g['out_bf16']):.3e} | ref std {g['out'].std().item():.3f}")
+    assert out.shape == g["out"].shape
+    assert mse < BAR
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (c) full-width two-layer forwards
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["transformer_full_t2v", "transformer_full_inp"])
+def test_transformer_full_width_vs_golden(name):
+    from easyanimate_amd import _lib
+    from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
+    from oracle.gen_golden import dit_full_inputs
+    g = _load(name + ".pt")
+    cfg = g["cfg"]
+    assert cfg["num_attention_heads"] * cfg["attention_head_dim"] == 3072 and cfg["num_layers"] == 2
+    B, Fr, H, W, T = g["dims"]
+    lat, extra, enc = dit_full_inputs(cfg, g["input_seed"], *g["dims"])
+    assert abs(lat.double().sum().item() - g["lat_sum"]) < 1e-6 and abs(enc.double().sum().item() - g["enc_sum"]) < 1e-5
+    rope = get_3d_rotary_pos_embed(64, g["crops"], grid_size=(H // 2, W // 2), temporal_size=Fr, use_real=True)
+    m = _model(cfg, g["shapes"], g["seed"], g["style"])
+    _lib.reset_counters()
+    with torch.no_grad():
+        out = m(lat.to(DEV).bfloat16(), g["t"].to(DEV).bfloat16(), encoder_hidden_states=enc.to(DEV).bfloat16(),
+                image_rotary_emb=rope, inpaint_latents=None if extra is None else extra.to(DEV).bfloat16(),
+                return_dict=False)[0]
+    torch.cuda.synchronize()
+    cnt = _lib.counters()
+    mse = _mse(out.float(), g["out"])
+    rel = ((out.float().cpu().double() - g["out"].double()).norm() / g["out"].double().norm()).item()
+    print(f"[parity] {name} (d=3072, 2 layers, N={Fr * (H // 2) * (W // 2)}, T={T}): new-bf16 vs ref-fp32 MSE={mse:.3e} "
+          f"rel_l2={rel:.3e} ref std {g['out'].std().item():.3f}"
+          + (f" | ref-bf16 floor {g['floor_mse']:.3e}" if "floor_mse" in g else "") + f" | kernels {cnt}")
+    assert mse < BAR
+    assert cnt.get("attention_v3", 0) == 2 * (2 if T % 64 else 1)     # the product attention kernel, per block
+    if name.endswith("t2v"):
+        assert cnt.get("gemm_256_mi16", 0) > 0                          # M = 2 x 5120 rows: the large-tile GEMM path
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (b) full-width VAE at 9 x 256^2
+# ---------------------------------------------------------------------------------------------------------
+def test_vae_full_width_vs_golden():
+    from easyanimate_amd import AutoencoderKLMagvit, _lib
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle.gen_golden import vae_full_inputs
+    g = _load("vae_full_9x256.pt")
+    assert g["cfg"]["block_out_channels"] == [128, 256, 512, 512]
+    video, z = vae_full_inputs(g["input_seed"], g["frames"], g["size"])
+    assert abs(video.double().sum().item() - g["video_sum"]) < 1e-3 and abs(z.double().sum().item() - g["z_sum"]) < 1e-4
+    vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    _lib.reset_counters()
+    with torch.no_grad():
+        mom = vae.encode(video.to(DEV).bfloat16())[0].parameters
+    torch.cuda.synchronize()
+    c_enc = _lib.counters()
+    _lib.reset_counters()
+    with torch.no_grad():
+        dec = vae.decode(z.to(DEV).bfloat16())[0]
+    torch.cuda.synchronize()
+    c_dec = _lib.counters()
+    assert mom.shape == g["moments"].shape and dec.shape == g["dec_f16"].shape == (1, 3, 9, 256, 256)
+    mse_e, mse_d = _mse(mom.float(), g["moments"]), _mse(dec.float(), g["dec_f16"].float())
+    print(f"[parity] full-width VAE 9x256^2: encode moments MSE={mse_e:.3e} (ref-bf16 floor {g.get('moments_floor_mse', float('nan')):.3e}, "
+          f"ref std {g['moments_std']:.3f}); decode MSE={mse_d:.3e} (ref-bf16 floor {g.get('dec_floor_mse', float('nan')):.3e}, "
+          f"ref std {g['dec_std']:.3f})")
+    print(f"[parity] full-width VAE kernels: encode {c_enc}; decode {c_dec}")
+    assert mse_e < BAR and mse_d < BAR
+    # the kernels that carry the 49 x 1024^2 decode must be the ones that ran here (automatic dispatch, no options set)
+    assert c_dec.get("conv_row16_128", 0) >= 6          # C_out = 128 full-resolution layers (row-slab, 16x16x32)
+    assert c_dec.get("conv_row16_256_ups", 0) >= 1      # the 256-channel up-sampler with folded x2 addressing
+    assert c_dec.get("conv_pp_256x256", 0) >= 1         # 256 x 256 ping-pong implicit GEMM
+    assert c_enc.get("conv_row16_128", 0) >= 4 and c_enc.get("conv_pp_256x256", 0) >= 1
