@@ -9,7 +9,9 @@
 One *step* = one iteration of the sampling loop (pipeline_easyanimate.py:1069-1111): transformer forward on the
 CFG pair (B=2) + CFG combine + Flow-matching Euler update, TeaCache off.  Synthetic data: random-init weights of
 the declared 12B architecture, N(0,1) latents and text embeddings.  N>1 = sequence parallel
-over the video tokens (strong scaling: the job is one video).  Rank 0 prints ONE JSON line.
+over the video tokens (strong scaling: the job is one video).  Rank 0 prints ONE JSON line.  At N=1 the same line carries
+the second half of the metric, "vae": decode / encode MPix/s of the causal 3-D VAE at 49 x 1024^2 (config 4), timed in
+the same process after the DiT steps.
 """
 from __future__ import annotations
 
@@ -61,10 +63,14 @@ def build_model(layers: int, device, in_channels: int = 16):
     return m.eval()
 
 
-def cpu_baseline(budget_s: float = 25.0):
-    """The oracle restatement (a port: kind="port") of one full-width MMDiT block, fp32, on the host cores,
-    on a bounded sample: B=1, 1024 video + 256 text tokens.  Extrapolated to one denoise step of the benchmark
-    shape with the algorithmic-FLOP ratio, labelled as such."""
+def cpu_baseline(S_bench: int, budget_s: float = 25.0):
+    """The oracle restatement (a port: kind="port") on the host cores, fp32, on a bounded sample, extrapolated to one
+    denoise step of the benchmark shape.  The two parts of a block scale differently with the sequence length S, so they
+    are timed and extrapolated SEPARATELY: (i) one full-width MMDiT block at B=1, 1024 video + 256
+    text tokens, where the linear layers are 97 % of the FLOPs -> seconds per token of everything but the SDPA; (ii) the
+    oracle's attention call (F.scaled_dot_product_attention, 48 heads x 64) alone at S=4096 -> seconds per S^2.
+    Returns (seconds per block and sample at S_bench, description)."""
+    import torch.nn.functional as F
     from easyanimate_amd.synthetic import synth_state_dict
     from oracle import restatement as R
     torch.set_num_threads(os.cpu_count() or 1)
@@ -83,17 +89,86 @@ def cpu_baseline(budget_s: float = 25.0):
     g = torch.Generator().manual_seed(0)
     h, e, temb = torch.randn(1, N, d, generator=g), torch.randn(1, T, d, generator=g), torch.randn(1, 512, generator=g)
     rope = R.rope_3d(64, ((0, 8), (30, 38)), (32, 32), 1)
-    with torch.no_grad():
-        R.dit_block(sd, "", h, e, temb, rope, H, 1e-5)  # warm-up
+
+    def timed(fn, budget, max_reps=3):
+        fn()  # warm-up
         t0 = time.perf_counter()
         reps = 0
-        while reps < 3 and time.perf_counter() - t0 < budget_s:
-            R.dit_block(sd, "", h, e, temb, rope, H, 1e-5)
+        while reps < max_reps and time.perf_counter() - t0 < budget:
+            fn()
             reps += 1
-        dt = (time.perf_counter() - t0) / max(reps, 1)
-    S_s = T + N
-    flop_sample = 24.0 * S_s * d * d + 4.0 * S_s * S_s * d
-    return dt, flop_sample, f"oracle/restatement.dit_block fp32, 1 block, B=1, {N} video + {T} text tokens, d=3072 ({reps} reps, {dt:.2f} s each)"
+        return (time.perf_counter() - t0) / max(reps, 1), reps
+
+    S_s, S_a = T + N, 4096
+    qs = torch.randn(1, H, S_s, 64, generator=g)
+    qa = torch.randn(1, H, S_a, 64, generator=g)
+    with torch.no_grad():
+        t_blk, r1 = timed(lambda: R.dit_block(sd, "", h, e, temb, rope, H, 1e-5), budget_s * 0.5)
+        t_att_s, _ = timed(lambda: F.scaled_dot_product_attention(qs, qs, qs), budget_s * 0.1)
+        t_att_a, r2 = timed(lambda: F.scaled_dot_product_attention(qa, qa, qa), budget_s * 0.4)
+    per_token = max(t_blk - t_att_s, 0.0) / S_s
+    per_s2 = t_att_a / (S_a * S_a)
+    t_bench = per_token * S_bench + per_s2 * S_bench * S_bench
+    desc = (f"oracle/restatement.dit_block fp32, 1 full-width block, B=1, {N} video + {T} text tokens ({r1} reps, {t_blk:.2f} s; its SDPA "
+            f"{t_att_s:.2f} s) -> {per_token * 1e3:.3f} ms per token for the linear part; the oracle's SDPA alone at S={S_a} "
+            f"({r2} reps, {t_att_a:.2f} s) -> {per_s2 * 1e9:.3f} ns per S^2; extrapolated separately to S={S_bench}: "
+            f"linear {per_token * S_bench:.1f} s + attention {per_s2 * S_bench * S_bench:.1f} s per block and sample")
+    return t_bench, desc
+
+
+def vae_cpu_baseline(frames: int = 5, size: int = 192):
+    """Oracle restatement of the VAE (oracle/restatement_vae.py, fp32, full width) on the host cores on a bounded sample
+    (5 x 192^2): MPix/s of decode and encode, not extrapolated (the rate is what is reported)."""
+    from easyanimate_amd import AutoencoderKLMagvit
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle import restatement_vae as RV
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_vae
+    threads = min(os.cpu_count() or 1, 32)   # oneDNN convolutions of this size get slower beyond a few dozen threads
+    torch.set_num_threads(threads)
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in AutoencoderKLMagvit(**bench_vae.FULL).state_dict().items()}
+    sd = synth_state_dict(shapes, 2)
+    g = torch.Generator().manual_seed(9)
+    video = torch.rand(1, 3, frames, size, size, generator=g) * 2 - 1
+    z = torch.randn(1, 16, (frames - 1) // 4 + 1, size // 8, size // 8, generator=g)
+    mpix = frames * size * size / 1e6
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        RV.vae_decode(sd, z, 32)
+        t_dec = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        RV.vae_encode_moments(sd, video, 32)
+        t_enc = time.perf_counter() - t0
+    return {"decode_mpix_s": mpix / t_dec, "encode_mpix_s": mpix / t_enc, "unit": "MPix/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/restatement_vae fp32, full width, {frames} x {size}^2 (decode {t_dec:.1f} s, encode {t_enc:.1f} s, one pass each)"}
+
+
+def vae_section(cpu: bool):
+    """BASELINE.json metric, second half: VAE decode / encode MPix/s at 49 x 1024^2 (config 4), same process, after the
+    DiT steps.  Inputs are resident in HBM when the timed region starts."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_vae
+    vae = bench_vae.build_vae()
+    r = bench_vae.run(vae, 49, 1024, iters=2, kernel_breakdown=True)
+    dec, enc = r["decode"], r["encode"]
+    out = {"workload": "AutoencoderKLMagvit (V5/V5.1 widths 128/256/512/512), 49 x 1024 x 1024 RGB <-> latents [16,13,128,128], bf16, "
+                       "random-init weights; decode randn/scaling_factor, encode U(-1,1) -> .mode()",
+           "decode_mpix_s": dec["MPix_per_s"], "encode_mpix_s": enc["MPix_per_s"], "unit": "MPix/s",
+           "decode_s": dec["seconds"], "encode_s": enc["seconds"],
+           "bound": "mfma (3x3x3 convolutions, AI ~1300 FLOP/B); hbm_frac is the minimal activation traffic over 8 TB/s",
+           "mfma_frac": dec["mfma_frac"], "hbm_frac": dec["hbm_frac"],
+           "encode_mfma_frac": enc["mfma_frac"], "encode_hbm_frac": enc["hbm_frac"],
+           "flop_decode": dec["algorithmic_flop"], "flop_encode": enc["algorithmic_flop"],
+           "dominant_kernel": dec["dominant_kernel"], "avg_launch_ms": dec["dominant_avg_launch_ms"],
+           "dominant_share_of_decode": dec["dominant_share_of_pass"],
+           "decode_conv_kernels_ms": dec["conv_kernels_ms"], "encode_conv_kernels_ms": enc["conv_kernels_ms"],
+           "finite_output": dec["finite"] and enc["finite"], "peak_mem_GB": r["peak_mem_GB"]}
+    del vae
+    torch.cuda.empty_cache()
+    if cpu:
+        out["cpu_baseline"] = vae_cpu_baseline()
+    return out
 
 
 def main():
@@ -103,6 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE half of the metric (config 4), timed after the DiT steps at N=1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,12 +296,16 @@ def main():
                      "traffic": traffic, "flop_per_launch": att_flop, "avg_launch_ms": att_ms,
                      "launches_timed": len(durs), "launches_per_block": len(durs) / max(n_blocks, 1)},
     }
+    if rank == 0 and world == 1 and not args.no_vae and args.config == "c3":
+        # the other half of BASELINE.json's metric: the DiT is released first (the VAE's activations peak at ~80 GB)
+        del model, pipe, latents, embeds, kt
+        torch.cuda.empty_cache()
+        out["vae"] = vae_section(cpu=not args.no_cpu_baseline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        dt, flop_sample, sample = cpu_baseline()
-        est_step_s = dt * flop_step / flop_sample
-        out["cpu_baseline"] = {"value": 1.0 / est_step_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(),
-                               "kind": "port",
-                               "sample": sample + f"; extrapolated to the full step by the algorithmic-FLOP ratio {flop_step / flop_sample:.3e}"}
+        t_block, sample = cpu_baseline(S)
+        est_step_s = t_block * B * L
+        out["cpu_baseline"] = {"value": 1.0 / est_step_s, "unit": "denoise-steps/s", "cores": os.cpu_count() or 1,
+                               "kind": "port", "sample": sample + f"; x B={B} x L={L} blocks = {est_step_s:.0f} s per denoise step"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -75,6 +75,8 @@ def load() -> ctypes.CDLL:
     lib.ea_get_counter.argtypes = [ctypes.c_char_p]
     lib.ea_counter_name.restype = c_int
     lib.ea_counter_name.argtypes = [c_int, ctypes.c_char_p, c_int]
+    lib.ea_last_dispatch.restype = ctypes.c_char_p
+    lib.ea_last_dispatch.argtypes = []
     lib.ea_reset_counters.restype = None
     lib.ea_reset_counters.argtypes = []
     _lib = lib
@@ -107,3 +109,8 @@ def counters() -> dict:
             out[buf.value.decode()] = int(n)
         i += 1
     return out
+
+
+def last_dispatch() -> str:
+    """Name of the kernel variant the most recent counted launch used (ea_last_dispatch)."""
+    return load().ea_last_dispatch().decode()

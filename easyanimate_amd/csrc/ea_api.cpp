@@ -32,9 +32,11 @@ namespace {
 struct Counter { char name[48]; long long n; };
 Counter g_counters[64];
 int g_ncounters = 0;
+const char* g_last = "";
 }  // namespace
 
 void ea_count(const char* name) {
+    g_last = name;   // string literals of the dispatch sites
     for (int i = 0; i < g_ncounters; ++i)
         if (!strcmp(g_counters[i].name, name)) { ++g_counters[i].n; return; }
     if (g_ncounters < 64) {
@@ -56,6 +58,8 @@ extern "C" int ea_counter_name(int index, char* buf, int buf_len) {
     buf[buf_len - 1] = 0;
     return EA_OK;
 }
+
+extern "C" const char* ea_last_dispatch(void) { return g_last; }
 
 extern "C" void ea_reset_counters(void) {
     for (int i = 0; i < g_ncounters; ++i) g_counters[i].n = 0;

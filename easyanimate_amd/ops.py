@@ -49,6 +49,7 @@ class KernelTimer:
     def __init__(self, name: str):
         self.name = name
         self.events = []
+        self.labels = []   # kernel variant that served each timed call (ea_last_dispatch)
 
     def __enter__(self):
         KernelTimer.active = self
@@ -65,6 +66,7 @@ class KernelTimer:
         r = fn()
         e.record()
         self.events.append((s, e))
+        self.labels.append(_lib.last_dispatch())
         return r
 
     def durations_ms(self):

@@ -60,6 +60,8 @@ int ea_set_option(const char* name, int value);
 long long ea_get_counter(const char* name);
 int ea_counter_name(int index, char* buf, int buf_len);
 void ea_reset_counters(void);
+/* name of the kernel variant that served the most recent counted launch ("" before the first) */
+const char* ea_last_dispatch(void);
 
 /* ---- normalisation ------------------------------------------------------------------------- */
 
