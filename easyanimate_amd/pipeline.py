@@ -142,8 +142,14 @@ class EasyAnimatePipeline:
         gh, gw = height // 8 // p, width // 8 // p
         base_w, base_h = 720 // 8 // p, 480 // 8 // p
         cc = get_resize_crop_region_for_grid((gh, gw), base_w, base_h)
-        return get_3d_rotary_pos_embed(self.transformer.config.attention_head_dim, cc, grid_size=(gh, gw),
-                                       temporal_size=latent_frames, use_real=True)
+        cos, sin = get_3d_rotary_pos_embed(self.transformer.config.attention_head_dim, cc, grid_size=(gh, gw),
+                                           temporal_size=latent_frames, use_real=True)
+        dev = self.transformer.device
+        if dev.type == "cuda":
+            # resident for the whole call (the reference re-uploads them in every attention call); a sequence-parallel
+            # rank slices its shard out of the device tables (a view)
+            cos, sin = cos.to(dev), sin.to(dev)
+        return cos, sin
 
     def decode_latents(self, latents):
         """reference: :722-742.  The 1/scaling_factor multiply touches the 0.9 MB latent only; the clamp / rescale

@@ -17,7 +17,6 @@ from . import ops
 from ._params import bf16_weight, f32
 
 _ws: Dict[tuple, dict] = {}
-_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 
 
 def _workspace(B: int, H: int, s_pad: int, device) -> dict:
@@ -48,18 +47,16 @@ def _attention_state(B: int, H: int, q_end: int, device) -> torch.Tensor:
 
 
 def rope_to_device(image_rotary_emb, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """The reference moves the CPU cos/sin tables to the device on every call (diffusers apply_rotary_emb);
-    here they are uploaded once and kept resident."""
+    """fp32 contiguous device tables.  The reference moves the CPU cos/sin tables to the device inside every attention
+    call (diffusers apply_rotary_emb); here EasyAnimatePipeline.rotary_embedding uploads them once per pipeline call and
+    EasyAnimateTransformer3DModel.forward once per forward for callers that pass CPU tables, so this is a no-op on the
+    hot path.  Nothing is cached by address: tables of equal size but different content (384x672 vs 672x384) must never
+    alias."""
     cos, sin = image_rotary_emb
-    if cos.is_cuda and cos.dtype == torch.float32 and cos.is_contiguous():
-        return cos, sin.contiguous()
-    key = (cos.data_ptr(), sin.data_ptr(), tuple(cos.shape), str(device))
-    ent = _rope_cache.get(key)
-    if ent is None:
-        _rope_cache.clear()
-        ent = (cos.to(device=device, dtype=torch.float32).contiguous(), sin.to(device=device, dtype=torch.float32).contiguous())
-        _rope_cache[key] = ent
-    return ent
+    if cos.is_cuda and cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_cuda and sin.dtype == torch.float32 \
+            and sin.is_contiguous():
+        return cos, sin
+    return (cos.to(device=device, dtype=torch.float32).contiguous(), sin.to(device=device, dtype=torch.float32).contiguous())
 
 
 def _bf16c(x):

@@ -260,6 +260,9 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
         rope = image_rotary_emb
         if rope is not None and sp is not None:
             rope = sp.shard_rope(rope, hs.device)
+        elif rope is not None:
+            from .processor import rope_to_device
+            rope = rope_to_device(rope, hs.device)   # once per forward (the pipeline passes device tables already)
 
         # TeaCache (transformer3d.py:1564-1590): skip the blocks while the accumulated, rescaled rel-L1 change of the
         # first block's modulated input stays under the threshold; a skipped step re-applies the cached residual

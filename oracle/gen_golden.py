@@ -416,6 +416,64 @@ def gen_transformer_full(ns, shim):
         torch.save(rec, os.path.join(OUT, f"{name}.pt"))
 
 
+DIT_7B = dict(FULL_DIT, num_layers=28)     # "7B-class" declared dims, SURVEY Appendix B
+
+
+def config1_inputs():
+    """1 frame 256 x 256 -> latents [1,16,1,32,32]; text embeddings randn[1,256,3584] for the
+    negative and the positive prompt (generator seed 1); latents from torch.Generator("cpu").manual_seed(43).
+    Values are rounded to bf16 so that the fp32 reference and the bf16 product start from identical inputs."""
+    enc = torch.randn(2, 256, 3584, generator=_g(1)).bfloat16().float()
+    latents = torch.randn(1, 16, 1, 32, 32, generator=_g(43)).bfloat16().float()
+    return latents, enc
+
+
+def _meta_build(ctor, seed, style):
+    """Instantiate a (large) reference module without allocating / initialising it twice: parameters are created on the
+    meta device and replaced by the synthetic tensors (load_state_dict(assign=True))."""
+    with torch.device("meta"):
+        m = ctor()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth_state_dict(shapes, seed, style), strict=True, assign=True)
+    for n, b in list(m.named_buffers()):
+        assert not b.is_meta, n
+    return m.eval(), shapes
+
+
+@section("config1")
+def gen_config1(ns, shim):
+    # ---- BASELINE.json configs[0] at its declared dims (SURVEY 8d "Config 1"): v5.1 yaml, 7B-class DiT (L=28, d=3072),
+    # 1 frame 256x256, 2 Flow steps, CFG 6, fp32, then the full-width VAE decode of the one frame.  Reference modules on CPU.
+    import time
+    t0 = time.time()
+    m, shapes = _meta_build(lambda: ns.transformer3d.EasyAnimateTransformer3DModel(**DIT_7B), 0, "default_bf16")
+    print(f"  7B-class reference transformer built in {time.time() - t0:.0f} s, {sum(p.numel() for p in m.parameters()) / 1e9:.2f} B parameters", flush=True)
+    latents, enc = config1_inputs()
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((16, 16), 45, 30)
+    rope = shim.get_3d_rotary_pos_embed(64, cc, (16, 16), 1, use_real=True)
+    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(2, device="cpu", mu=1)
+    x = latents.clone()
+    trace = []
+    for t in s.timesteps:
+        t0 = time.time()
+        li = torch.cat([x] * 2)
+        v = m(li, torch.tensor([t] * 2).to(li.dtype), encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+        vu, vt = v.chunk(2)
+        x = s.step(vu + 6.0 * (vt - vu), t, x, return_dict=False)[0]
+        trace.append(x.clone())
+        print(f"  step: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads", flush=True)
+    del m
+    vae, vshapes = _meta_build(lambda: ns.autoencoder_magvit.AutoencoderKLMagvit(**FULL_VAE), 2, "default_bf16")
+    t0 = time.time()
+    dec = vae.decode(x / 0.1825)[0]
+    frames = (dec.clamp(-1, 1) / 2 + 0.5).clamp(0, 1)    # pipeline_easyanimate.py:731-739
+    print(f"  vae decode {time.time() - t0:.1f} s; latents std {x.std().item():.3f}, frames mean {frames.mean().item():.3f}", flush=True)
+    torch.save(dict(dit_cfg=DIT_7B, vae_cfg=FULL_VAE, dit_seed=0, vae_seed=2, style="default_bf16", steps=2, guidance=6.0,
+                    height=256, width=256, video_length=1, latents_sum=latents.double().sum().item(),
+                    enc_sum=enc.double().sum().item(), trace=trace, frames=frames), os.path.join(OUT, "config1_7b_256.pt"))
+
+
 @torch.no_grad()
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)
