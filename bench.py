@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-rank", default=None, metavar="P,r",
+                    help="one GPU runs the per-step COMPUTE of rank r in a world of P ranks (no communication): a labelled "
+                         "MODEL of the scaling curve, never a measurement of it")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE half of the metric (config 4), timed after the DiT steps at N=1")
     args = ap.parse_args()
 
@@ -210,6 +213,13 @@ def main():
     model = build_model(cfg["layers"], device, cfg.get("in_channels", 16))
     if world > 1:
         sequence_parallel.enable(model)
+    emu = None
+    if args.emulate_rank:
+        if world != 1:
+            raise SystemExit("--emulate-rank is a single-process mode")
+        emu = tuple(int(v) for v in args.emulate_rank.split(","))
+        model.sequence_parallel = sequence_parallel.EmulatedRank(*emu)
+        args.no_vae = args.no_cpu_baseline = True
     sched = FlowMatchEulerDiscreteScheduler(shift=1.0)
     pipe = EasyAnimatePipeline(vae=None, transformer=model, scheduler=sched)
 
@@ -253,7 +263,7 @@ def main():
     # launches per block (local keys while the K/V all-gather is in flight, then the remote keys): they are summed.
     durs = kt.durations_ms()
     n_blocks = L * K
-    if world > 1:
+    if world > 1 or emu:
         sp = model.sequence_parallel
         b_loc = 1 if sp.axis.cfg_degree == 2 else B
         lo, hi = sp.shard_range()
@@ -296,6 +306,14 @@ def main():
                      "traffic": traffic, "flop_per_launch": att_flop, "avg_launch_ms": att_ms,
                      "launches_timed": len(durs), "launches_per_block": len(durs) / max(n_blocks, 1)},
     }
+    if emu:
+        P, r = emu
+        out["metric"] = f"MODELLED per-rank compute-side rate, rank {r} of {P} (not a measurement of {P} GPUs)"
+        out["emulated"] = {"world": P, "rank": r, "what": "this rank's batch slice (CFG axis), token shard through every per-token "
+                           "kernel, and its queries over all keys in the two-pass local / remote form with random remote K / V^T; "
+                           "collectives, their overlap with the local-key pass and the pack / unpack copies are NOT included",
+                           "speedup_upper_bound_needs": "T_1 / this ms_per_step, T_1 from the plain N=1 run of the same session"}
+        out["config"]["step_mfma_frac"] = flop_step * K / elapsed / (PEAK_BF16_TFLOPS * 1e12 * P)
     if rank == 0 and world == 1 and not args.no_vae and args.config == "c3":
         # the other half of BASELINE.json's metric: the DiT is released first (the VAE's activations peak at ~80 GB)
         del model, pipe, latents, embeds, kt

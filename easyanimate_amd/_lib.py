@@ -30,6 +30,7 @@ PROTOTYPES = {
     "ea_timestep_sinusoid": [_P, _P, _I, _I, _I, _P],
     "ea_gemm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _I, _P],
     "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P],
+    "ea_qkv_gemm_norm_rope_bf16": [_P] * 16 + [_I, _I, _I, _I, _L, _L, _I, _I, _F, _F, _P],
     "ea_attention_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P],
     "ea_attention_fwd_range_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -37,6 +38,7 @@ PROTOTYPES = {
     "ea_cfg_euler_step": [_P, _P, _L, _F, _F, _I, _I, _P],
     "ea_teacache_rel_l1_bf16": [_P, _P, _L, _P, _I, _P, _P],
     "ea_bf16_binary": [_P, _P, _P, _L, _I, _P],
+    "ea_gated_residual_bf16": [_P, _P, _P, _P, _I, _L, _I, _L, _P],
     "ea_conv3d_cl_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_im2col3d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_groupnorm_stats_bf16": [_P, _P, _P, _I, _L, _I, _I, _I, _F, _P],

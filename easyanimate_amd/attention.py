@@ -136,8 +136,6 @@ class EasyAnimateDiTBlock(nn.Module):
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor,
                 image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, num_frames=None, height=None,
                 width=None, sp=None) -> Tuple[torch.Tensor, torch.Tensor]:
-        if self.norm3 is not None:
-            raise NotImplementedError("after_norm=True has no fused HIP path yet (V5/V5.1 configs use after_norm: false)")
         # Norm + Attn + gated residual (attention.py:1118-1141), the residual add fused in the out-proj GEMMs
         norm_h, norm_e, gate_msa, enc_gate_msa = self.norm1(hidden_states, encoder_hidden_states, temb)
         hidden_states, encoder_hidden_states = self.attn1(
@@ -146,7 +144,14 @@ class EasyAnimateDiTBlock(nn.Module):
             sp=sp)
         # Norm + FFN + gated residual (attention.py:1144-1162), fused in the second FFN GEMM
         norm_h, norm_e, gate_ff, enc_gate_ff = self.norm2(hidden_states, encoder_hidden_states, temb)
-        hidden_states = self.ff(norm_h, residual=hidden_states, gate=gate_ff)
         txt_ff = self.txt_ff if self.txt_ff is not None else self.ff
+        if self.norm3 is not None:
+            # after_norm (attention.py:1150-1155): FP32LayerNorm between the FFN and its gated residual, so the residual
+            # cannot ride in the GEMM epilogue: FFN (plain bias epilogue) -> LayerNorm kernel -> gated-residual kernel
+            B = hidden_states.shape[0]
+            hidden_states = ops.gated_residual(self.norm3(self.ff(norm_h)), hidden_states, gate_ff.reshape(B, -1))
+            encoder_hidden_states = ops.gated_residual(self.norm3(txt_ff(norm_e)), encoder_hidden_states, enc_gate_ff.reshape(B, -1))
+            return hidden_states, encoder_hidden_states
+        hidden_states = self.ff(norm_h, residual=hidden_states, gate=gate_ff)
         encoder_hidden_states = txt_ff(norm_e, residual=encoder_hidden_states, gate=enc_gate_ff)
         return hidden_states, encoder_hidden_states

@@ -213,7 +213,42 @@ __global__ __launch_bounds__(256) void bf16_binary_kernel(const unsigned short* 
     }
 }
 
+// out[b, r, :] = res[b, r, :] + gate[b, :] * x[b, r, :]   (bf16 in/out, fp32 fma, one rounding)
+__global__ __launch_bounds__(256) void gated_residual_kernel(const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ res,
+                                                             const float* __restrict__ gate, unsigned short* __restrict__ out,
+                                                             int64_t per_batch8, int dim8, int64_t gate_bs, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / per_batch8;
+        const int c8 = (int)(i % dim8);
+        const u16x8 xv = reinterpret_cast<const u16x8*>(x)[i];
+        const u16x8 rv = reinterpret_cast<const u16x8*>(res)[i];
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + b * gate_bs + c8 * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gate + b * gate_bs + c8 * 8 + 4);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = f32_to_bf16_bits(__builtin_fmaf(g0[e], bf16_bits_to_f32(xv[e]), bf16_bits_to_f32(rv[e])));
+            o[4 + e] = f32_to_bf16_bits(__builtin_fmaf(g1[e], bf16_bits_to_f32(xv[4 + e]), bf16_bits_to_f32(rv[4 + e])));
+        }
+        reinterpret_cast<u16x8*>(out)[i] = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int ea_gated_residual_bf16(const ea_bf16* x, const ea_bf16* res, const float* gate, ea_bf16* out, int batch,
+                                      int64_t rows, int dim, int64_t gate_batch_stride, void* stream) {
+    EA_REQUIRE(x && res && gate && out, "ea_gated_residual_bf16: null tensor");
+    EA_REQUIRE(batch > 0 && rows >= 0 && dim > 0 && dim % 8 == 0 && gate_batch_stride % 4 == 0, "ea_gated_residual_bf16: bad sizes");
+    EA_REQUIRE((((uintptr_t)x | (uintptr_t)res | (uintptr_t)gate | (uintptr_t)out) & 15) == 0, "ea_gated_residual_bf16: pointers must be 16-byte aligned");
+    const int64_t n8 = (int64_t)batch * rows * dim / 8;
+    if (n8 == 0) return EA_OK;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gated_residual_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, res, gate, out,
+                       rows * dim / 8, dim / 8, gate_batch_stride, n8);
+    return ea_check_launch("ea_gated_residual_bf16");
+}
 
 extern "C" int ea_teacache_rel_l1_bf16(const ea_bf16* cur, const ea_bf16* prev, int64_t n, float* partial, int nblk,
                                        double* sums, void* stream) {

@@ -497,6 +497,75 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
+#define EA_G3_PHASE(S, P, HAS_NEXT, SWAP)                                                                     \
+    {                                                                                                         \
+        bf16x8 af[4];                                                                                         \
+        if (((P) & 1) == 0) {                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+                wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k[(P) >> 1] + (S) * OPER2 + j * 2048));    \
+        }                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+            af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[(P) >> 1] + (S) * OPER2 + (((P) & 1) * 4 + i) * 2048)); \
+        if ((P) == 0 && (HAS_NEXT)) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+                asrc[i] += BK;                                                                                \
+                glds16(asrc[i], dma_a + ((S) ^ 1) * OPER2 + i * 1024);                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+        if ((P) == 1 && (HAS_NEXT)) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+                wsrc[i] += BK;                                                                                \
+                glds16(wsrc[i], dma_w + ((S) ^ 1) * OPER2 + i * 1024);                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+        if ((P) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+                acc[((P) & 1) * 4 + i][j] = (SWAP)                                                            \
+                    ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[((P) & 1) * 4 + i][j], 0, 0, 0) \
+                    : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[((P) & 1) * 4 + i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+#define EA_G3_TILE(S, HAS_NEXT, SWAP) \
+    EA_G3_PHASE(S, 0, HAS_NEXT, SWAP) \
+    EA_G3_PHASE(S, 1, HAS_NEXT, SWAP) \
+    EA_G3_PHASE(S, 2, HAS_NEXT, SWAP) \
+    EA_G3_PHASE(S, 3, HAS_NEXT, SWAP)
+// prologue DMA of tile 0, the staggered start of the two wave groups, the K loop, and the balancing barrier.
+// SWAP = 1 exchanges the MFMA operand roles (activation fragment as A, weight fragment as B): the accumulator tile is
+// then the transpose -- a lane holds 4 consecutive output ROWS of one column (the fused QKV kernel's V^T tiles).
+#define EA_G3_MAINLOOP(SWAP)                                                                    \
+    {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+            glds16(asrc[i], dma_a + i * 1024);                                                  \
+            glds16(wsrc[i], dma_w + i * 1024);                                                  \
+        }                                                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+        __builtin_amdgcn_s_barrier();                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (wr == 1) __builtin_amdgcn_s_barrier(); /* stagger: group 1 runs one barrier behind group 0 */ \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        for (int t = 0; t < nk; t += 2) {                                                       \
+            const bool n0_ = t + 1 < nk;                                                        \
+            EA_G3_TILE(0, n0_, SWAP)                                                            \
+            if (n0_) {                                                                          \
+                const bool n1_ = t + 2 < nk;                                                    \
+                EA_G3_TILE(1, n1_, SWAP)                                                        \
+            }                                                                                   \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (wr == 0) __builtin_amdgcn_s_barrier(); /* balance the stagger */                    \
+    }
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -546,72 +615,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
     const int nk = p.K / BK;
     bf16x8 wf[4];
 
-#define EA_G3_PHASE(S, P, HAS_NEXT)                                                                           \
-    {                                                                                                         \
-        bf16x8 af[4];                                                                                         \
-        if (((P) & 1) == 0) {                                                                                 \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-                wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k[(P) >> 1] + (S) * OPER2 + j * 2048));    \
-        }                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-            af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[(P) >> 1] + (S) * OPER2 + (((P) & 1) * 4 + i) * 2048)); \
-        if ((P) == 0 && (HAS_NEXT)) {                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-                asrc[i] += BK;                                                                                \
-                glds16(asrc[i], dma_a + ((S) ^ 1) * OPER2 + i * 1024);                                        \
-            }                                                                                                 \
-        }                                                                                                     \
-        if ((P) == 1 && (HAS_NEXT)) {                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-                wsrc[i] += BK;                                                                                \
-                glds16(wsrc[i], dma_w + ((S) ^ 1) * OPER2 + i * 1024);                                        \
-            }                                                                                                 \
-        }                                                                                                     \
-        if ((P) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        __builtin_amdgcn_s_barrier();                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        __builtin_amdgcn_s_setprio(1);                                                                        \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-                acc[((P) & 1) * 4 + i][j] =                                                                   \
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[((P) & 1) * 4 + i][j], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        __builtin_amdgcn_s_barrier();                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-    }
-#define EA_G3_TILE(S, HAS_NEXT)      \
-    EA_G3_PHASE(S, 0, HAS_NEXT)      \
-    EA_G3_PHASE(S, 1, HAS_NEXT)      \
-    EA_G3_PHASE(S, 2, HAS_NEXT)      \
-    EA_G3_PHASE(S, 3, HAS_NEXT)
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        glds16(asrc[i], dma_a + i * 1024);
-        glds16(wsrc[i], dma_w + i * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
-    __builtin_amdgcn_sched_barrier(0);
-
-    for (int t = 0; t < nk; t += 2) {
-        const bool n0_ = t + 1 < nk;
-        EA_G3_TILE(0, n0_)
-        if (n0_) {
-            const bool n1_ = t + 2 < nk;
-            EA_G3_TILE(1, n1_)
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
-#undef EA_G3_TILE
-#undef EA_G3_PHASE
+    EA_G3_MAINLOOP(0)
 
     // ---- epilogue through the wave-private 16 KiB image (rows = the wave's 128 output rows, 128 B = its 64 columns,
     // 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and the read-out already use)
@@ -672,6 +676,200 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
         const int m = mrow0 + r;
         const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
         if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8) = o;
+    }
+}
+
+// =================================================================================================
+// Fused QKV projection: ONE launch computes q, k, v = Linear_{q,k,v}(x) for a token stream and finishes each
+// (128 tokens x one head) wave tile in its epilogue -- bias, qk-LayerNorm(64), interleaved RoPE, softmax scale on q,
+// head-major scatter of q / k rows, transposed scatter of v -- i.e. processor.py:244-285 without the [B,n,3d] QKV
+// round trip through HBM (1 write + 1 read of 6d bytes per token) and with the activations read once instead of three
+// times.  The weights stay three separate [d,d] checkpoint tensors: the N axis of the launch is the concatenation
+// q | k | v and an N-tile picks its weight pointer (d % 256 == 0, so a tile never straddles two weights).
+//   * main loop = gemm256_mi16_kernel's.  A wave tile is 128 tokens x 64 output features = exactly one head.
+//   * q / k tiles: C^T orientation as before (a lane holds 4 consecutive features of one token).  The epilogue rounds
+//     acc + bias to bf16 (the value the unfused path stores in the QKV buffer), reduces mean / centred variance over the
+//     64 features of a token (16 in the lane, then the 4 lanes lq = 0..3 that share the token: two xor-shuffles),
+//     rounds the LayerNorm output to bf16 (processor.py:255-258), rotates the interleaved pairs with the fp32 cos / sin
+//     rows of the token, multiplies q by q_scale, rounds once, and leaves through the wave-private LDS image as whole
+//     128-byte rows of q_out / k_out [B, H, s_pad, 64].  Same roundings, same order as ea_gemm_bf16 followed by
+//     ea_qknorm_rope_bf16 (tested: V^T bit-identical, q / k within one bf16 ulp -- the statistics are summed in another order).
+//   * v tiles: the MFMA operand roles are swapped (EA_G3_MAINLOOP(1)), so a lane holds 4 consecutive TOKENS of one
+//     feature; the image is written transposed ([64 features][128 tokens], 16-byte chunks XOR-swizzled with
+//     feature & 15) and read out as 256-byte rows of vt_out [B, H, 64, s_pad].
+struct QkvArgs {
+    const unsigned short* A;
+    const unsigned short* W[3];
+    const float* bias[3];
+    unsigned short* q_out;
+    unsigned short* k_out;
+    unsigned short* vt_out;
+    const float* nw[2];   // norm_q / norm_k weight
+    const float* nb[2];   // norm_q / norm_k bias
+    const float* cosT;
+    const float* sinT;
+    int M, K, inner, heads, seq_off, s_pad;
+    int64_t lda, abs_;
+    float eps, q_scale;
+    int tiles_m, tiles_n, rows_per_xcd;
+};
+
+__global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm, tn;
+    {
+        GemmArgs g;
+        g.tiles_m = q.tiles_m; g.tiles_n = q.tiles_n; g.rows_per_xcd = q.rows_per_xcd;
+        if (!tile_of_block(g, tm, tn)) return;
+    }
+    const int b = blockIdx.y;
+    const int row0 = tm * 256;
+    const int tiles_per_w = q.inner >> 8;
+    const int which = __builtin_amdgcn_readfirstlane(tn / tiles_per_w);   // 0 = q, 1 = k, 2 = v
+    const int col0 = (tn - which * tiles_per_w) * 256;                     // first output feature inside that weight
+    const unsigned short* Ab = q.A + b * q.abs_;
+    const unsigned short* Wb = which == 0 ? q.W[0] : (which == 1 ? q.W[1] : q.W[2]);
+    const float* biasb = which == 0 ? q.bias[0] : (which == 1 ? q.bias[1] : q.bias[2]);
+
+    const unsigned short* asrc[4];
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ (r & 7);
+        asrc[i] = Ab + (int64_t)(row0 + r) * q.lda + cs * 8;      // M % 256 == 0: no row clamp
+        wsrc[i] = Wb + (int64_t)(col0 + r) * q.K + cs * 8;
+    }
+    char* const dma_a = smem + wave * 4096;
+    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    unsigned a_k[2], w_k[2];
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+        w_k[ks2] = 2 * OPER2 + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+    }
+    const int nk = q.K / BK;
+    bf16x8 wf[4];
+
+    char* const img = smem + wave * 16384;
+    const int tok0 = row0 + wr * 128;                 // first token (row of A) of this wave tile
+    const int head = (col0 >> 6) + wc;
+    const int64_t bh = (int64_t)b * q.heads + head;
+
+    if (which == 2) {
+        EA_G3_MAINLOOP(1)
+        // ---- v: lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = j * 16 + lr;
+            const float bv = biasb ? biasb[col0 + wc * 64 + n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(acc[i][j][e] + bv);
+                const int ch = i * 2 + (lq >> 1);
+                *reinterpret_cast<u16x4*>(img + n * 256 + ((ch ^ (n & 15)) << 4) + (lq & 1) * 8) = o;
+            }
+        }
+        // wave-private image: the LDS writes above are ordered before the reads below by the waitcnt the compiler inserts
+        const int r4 = lane >> 4, c16 = lane & 15;
+        unsigned short* dst = q.vt_out + (bh * 64) * (int64_t)q.s_pad + q.seq_off + tok0 + c16 * 8;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const int n = qq * 4 + r4;
+            const u16x8 o = *reinterpret_cast<const u16x8*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
+            *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.s_pad) = o;
+        }
+        return;
+    }
+
+    EA_G3_MAINLOOP(0)
+    // ---- q / k: lane holds features j*16 + lq*4 + 0..3 of token i*16 + lr
+    const float* gw = q.nw[which];
+    const float* gb = q.nb[which];
+    f32x4_t bias4[4], gw4[4], gb4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = j * 16 + lq * 4;
+        f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        bias4[j] = biasb ? *reinterpret_cast<const f32x4_t*>(biasb + col0 + wc * 64 + n) : z;
+        gw4[j] = *reinterpret_cast<const f32x4_t*>(gw + n);
+        gb4[j] = *reinterpret_cast<const f32x4_t*>(gb + n);
+    }
+    const float osc = which == 0 ? q.q_scale : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + lr;
+        float v[4][4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] = bf16_bits_to_f32(f32_to_bf16_bits(acc[i][j][e] + bias4[j][e]));   // the stored QKV value
+                s += v[j][e];
+            }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / 64.0f);
+        float qd = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[j][e] - mean;
+                qd += d * d;
+            }
+        qd += __shfl_xor(qd, 16, 64);
+        qd += __shfl_xor(qd, 32, 64);
+        const float rstd = rsqrtf(qd * (1.0f / 64.0f) + q.eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[j][e] = bf16_bits_to_f32(f32_to_bf16_bits((v[j][e] - mean) * rstd * gw4[j][e] + gb4[j][e]));
+            u16x4 o;
+            if (q.cosT) {
+                const int64_t tr = (int64_t)(tok0 + r) * 64 + j * 16 + lq * 4;
+                const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(q.cosT + tr);
+                const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(q.sinT + tr);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float x0 = v[j][e], x1 = v[j][e + 1];
+                    o[e] = f32_to_bf16_bits((x0 * c4[e] - x1 * s4[e]) * osc);
+                    o[e + 1] = f32_to_bf16_bits((x1 * c4[e + 1] + x0 * s4[e + 1]) * osc);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[j][e] * osc);
+            }
+            const int ch = j * 2 + (lq >> 1);
+            *reinterpret_cast<u16x4*>(img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq & 1) * 8) = o;
+        }
+    }
+    const int r8 = lane >> 3, c8 = lane & 7;
+    unsigned short* dst = (which ? q.k_out : q.q_out) + (bh * q.s_pad + q.seq_off + tok0) * 64 + c8 * 8;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+        const int r = qq * 8 + r8;
+        const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
+        *reinterpret_cast<u16x8*>(dst + (int64_t)r * 64) = o;
     }
 }
 
@@ -752,6 +950,46 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
         default: launch_gemm<2>(p, batch, tile, st); break;
     }
     return ea_check_launch("ea_gemm_bf16");
+}
+
+
+extern "C" int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
+                                          const float* bq, const float* bk, const float* bv, ea_bf16* q_out,
+                                          ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
+                                          const float* nk_w, const float* nk_b, const float* cos, const float* sin,
+                                          int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
+                                          int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
+    EA_REQUIRE(A && Wq && Wk && Wv && q_out && k_out && vt_out && nq_w && nq_b && nk_w && nk_b,
+               "ea_qkv_gemm_norm_rope_bf16: null tensor");
+    EA_REQUIRE((cos == nullptr) == (sin == nullptr), "ea_qkv_gemm_norm_rope_bf16: cos and sin go together");
+    EA_REQUIRE(batch > 0 && batch <= 65535 && heads > 0 && M > 0 && K > 0, "ea_qkv_gemm_norm_rope_bf16: bad sizes");
+    EA_REQUIRE(M % 256 == 0, "ea_qkv_gemm_norm_rope_bf16: M=%d must be a multiple of 256 (use ea_gemm_bf16 + ea_qknorm_rope_bf16)", M);
+    EA_REQUIRE((heads * 64) % 256 == 0, "ea_qkv_gemm_norm_rope_bf16: heads*64 must be a multiple of 256");
+    EA_REQUIRE(K % BK == 0 && lda % 8 == 0, "ea_qkv_gemm_norm_rope_bf16: K must be a multiple of 64, lda of 8");
+    EA_REQUIRE(seq_off >= 0 && seq_off % 8 == 0 && s_pad % 8 == 0 && seq_off + M <= s_pad,
+               "ea_qkv_gemm_norm_rope_bf16: seq_off / s_pad must be multiples of 8 with seq_off + M <= s_pad");
+    EA_REQUIRE((((uintptr_t)A | (uintptr_t)Wq | (uintptr_t)Wk | (uintptr_t)Wv | (uintptr_t)q_out | (uintptr_t)k_out |
+                 (uintptr_t)vt_out | (uintptr_t)bq | (uintptr_t)bk | (uintptr_t)bv | (uintptr_t)nq_w | (uintptr_t)nq_b |
+                 (uintptr_t)nk_w | (uintptr_t)nk_b | (uintptr_t)cos | (uintptr_t)sin) & 15) == 0,
+               "ea_qkv_gemm_norm_rope_bf16: pointers must be 16-byte aligned");
+    QkvArgs q;
+    q.A = A; q.W[0] = Wq; q.W[1] = Wk; q.W[2] = Wv; q.bias[0] = bq; q.bias[1] = bk; q.bias[2] = bv;
+    q.q_out = q_out; q.k_out = k_out; q.vt_out = vt_out;
+    q.nw[0] = nq_w; q.nb[0] = nq_b; q.nw[1] = nk_w; q.nb[1] = nk_b; q.cosT = cos; q.sinT = sin;
+    q.M = M; q.K = K; q.inner = heads * 64; q.heads = heads; q.seq_off = seq_off; q.s_pad = s_pad;
+    q.lda = lda; q.abs_ = a_batch_stride; q.eps = ln_eps; q.q_scale = q_scale;
+    q.tiles_m = M / 256;
+    q.tiles_n = 3 * q.inner / 256;
+    q.rows_per_xcd = q.tiles_m >= 64 ? (q.tiles_m + 7) / 8 : 0;
+    dim3 grid(q.rows_per_xcd ? 8 * q.rows_per_xcd * q.tiles_n : q.tiles_m * q.tiles_n, batch);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)gemm256_qkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
+        attr_done = true;
+    }
+    ea_count("gemm_qkv_fused");
+    hipLaunchKernelGGL(gemm256_qkv_kernel, grid, dim3(512), GEMM2_LDS, (hipStream_t)stream, q);
+    return ea_check_launch("ea_qkv_gemm_norm_rope_bf16");
 }
 
 #ifdef EA_GEMM_TIMESTAMPS

@@ -55,3 +55,21 @@ def get_3d_rotary_pos_embed(embed_dim: int, crops_coords, grid_size, temporal_si
         return torch.cat([ft, fh, fw], dim=-1).reshape(temporal_size * gh * gw, -1).contiguous()
 
     return combine(ct, ch, cw), combine(st, sh, sw)
+
+
+def get_2d_sincos_pos_embed(embed_dim: int, grid_size, interpolation_scale: float = 1.0, base_size: int = 16) -> torch.Tensor:
+    """Fixed 2-D sin/cos table of the ref-latent branch (reference: transformer3d.py:1424 calls diffusers
+    get_2d_sincos_pos_embed; SURVEY Appendix A "[diffusers, restated]").  Returns float64 [gh*gw, embed_dim]:
+    first half of the channels encodes the coordinate that runs fastest in memory ("w goes first" in diffusers), each half
+    as [sin | cos] over embed_dim/4 frequencies 10000^(-i / (embed_dim/4)); coordinates are scaled to a 16-cell base grid."""
+    gh, gw = (grid_size, grid_size) if isinstance(grid_size, int) else grid_size
+    ch = np.arange(gh, dtype=np.float32) / (gh / base_size) / interpolation_scale
+    cw = np.arange(gw, dtype=np.float32) / (gw / base_size) / interpolation_scale
+    mesh = np.stack(np.meshgrid(cw, ch), axis=0).reshape(2, -1)            # [2, gh*gw]: row 0 = w coordinate, row 1 = h
+    quarter = embed_dim // 4
+    freq = 1.0 / 10000 ** (np.arange(quarter, dtype=np.float64) / quarter)
+    parts = []
+    for coord in mesh:                                                     # float32 coordinates x float64 frequencies
+        ang = coord.astype(np.float32)[:, None] * freq[None, :]
+        parts += [np.sin(ang), np.cos(ang)]
+    return torch.from_numpy(np.concatenate(parts, axis=1))

@@ -206,6 +206,33 @@ def qknorm_rope(qkv: torch.Tensor, q_out: torch.Tensor, k_out: torch.Tensor, vt_
               _p(nk_w), _p(nk_b), _p(cos), _p(sin), B, H, n_tok, seq_off, s_pad, float(eps), float(q_scale), _stream())
 
 
+def qkv_fused_ok(n_tok: int, inner: int, k: int, seq_off: int) -> bool:
+    """Shapes ea_qkv_gemm_norm_rope_bf16 serves (the video stream of every benchmark configuration)."""
+    return n_tok > 0 and n_tok % 256 == 0 and inner % 256 == 0 and k % 64 == 0 and seq_off % 8 == 0
+
+
+def qkv_gemm_norm_rope(x: torch.Tensor, wq, wk, wv, bq, bk, bv, q_out: torch.Tensor, k_out: torch.Tensor,
+                       vt_out: torch.Tensor, nq_w, nq_b, nk_w, nk_b, cos: Optional[torch.Tensor],
+                       sin: Optional[torch.Tensor], seq_off: int, eps: float, q_scale: float = 1.0) -> None:
+    """x bf16 [B, n_tok, K] -> rows [seq_off, seq_off+n_tok) of q_out / k_out [B,H,S_pad,64] and columns of vt_out
+    [B,H,64,S_pad]: the three projections + qk-LayerNorm + RoPE + scatter in one launch."""
+    _dev(x, wq, wk, wv, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin)
+    _chk(x, _BF16, "x")
+    B, n_tok, K = x.shape
+    _, H, s_pad, dh = q_out.shape
+    assert dh == 64 and x.stride(2) == 1 and q_out.is_contiguous() and k_out.is_contiguous() and vt_out.is_contiguous()
+    for w in (wq, wk, wv):
+        _chk(w, _BF16, "W")
+        assert w.shape == (H * 64, K) and w.is_contiguous()
+    if cos is not None:
+        _chk(cos, _F32, "cos"); _chk(sin, _F32, "sin")
+        assert cos.shape == (n_tok, 64) and cos.is_contiguous() and sin.is_contiguous()
+    _timed("gemm", lambda: _lib.call("ea_qkv_gemm_norm_rope_bf16", _p(x), _p(wq), _p(wk), _p(wv), _p(bq), _p(bk), _p(bv),
+                                     _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b), _p(nk_w), _p(nk_b), _p(cos),
+                                     _p(sin), B, n_tok, H, K, x.stride(1), x.stride(0), seq_off, s_pad, float(eps),
+                                     float(q_scale), _stream()))
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scale: float,
               out: Optional[torch.Tensor] = None, q_begin: int = 0, q_end: Optional[int] = None) -> torch.Tensor:
     """q,k bf16 [B,H,S_pad,64], vt bf16 [B,H,64,S_pad] -> out bf16 [B,seq,H*64]."""
@@ -283,6 +310,18 @@ def bf16_add_(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous()
     _lib.call("ea_bf16_binary", _p(x), _p(y), _p(x), x.numel(), 1, _stream())
     return x
+
+
+def gated_residual(x: torch.Tensor, res: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """res + gate[b, :] * x;  x/res bf16 [B, R, D] contiguous, gate fp32 [B, D] (row view of the modulation table)."""
+    _dev(x, res, gate)
+    _chk(x, _BF16, "x"); _chk(res, _BF16, "res"); _chk(gate, _F32, "gate")
+    assert x.shape == res.shape and x.dim() == 3 and x.is_contiguous() and res.is_contiguous()
+    B, R, D = x.shape
+    assert gate.shape == (B, D) and gate.stride(1) == 1
+    out = torch.empty_like(x)
+    _lib.call("ea_gated_residual_bf16", _p(x), _p(res), _p(gate), _p(out), B, R, D, gate.stride(0), _stream())
+    return out
 
 
 def patchify(latents: torch.Tensor, extra: Optional[torch.Tensor], k_pad: int) -> torch.Tensor:

@@ -9,6 +9,7 @@ filters kwargs by this signature, so the extra names are protocol-compatible.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -65,6 +66,8 @@ def _bf16c(x):
 
 
 class EasyAnimateAttnProcessor2_0:
+    fuse_qkv = os.environ.get("EA_FUSE_QKV", "1") != "0"   # False / EA_FUSE_QKV=0: always take the three-GEMM + ea_qknorm_rope_bf16 path (same roundings; tests)
+
     def __init__(self):
         pass
 
@@ -94,15 +97,7 @@ class EasyAnimateAttnProcessor2_0:
         tattn = attn2 if attn2 is not None else attn  # non-MMDiT blocks share the video weights (:241-242)
         dev = x.device
 
-        # ---- QKV projections (processor.py:244-246, 261-263): three GEMMs into one [B, n, 3d] buffer each
-        qkv_v = torch.empty(B, N, 3 * d, dtype=torch.bfloat16, device=dev)
-        qkv_t = torch.empty(B, T, 3 * d, dtype=torch.bfloat16, device=dev)
-        for i, name in enumerate(("to_q", "to_k", "to_v")):
-            lv, lt = getattr(attn, name), getattr(tattn, name)
-            ops.gemm(x, bf16_weight(lv.weight), f32(lv.bias), ops.EPI_BIAS, out=qkv_v[:, :, i * d:(i + 1) * d])
-            ops.gemm(e, bf16_weight(lt.weight), f32(lt.bias), ops.EPI_BIAS, out=qkv_t[:, :, i * d:(i + 1) * d])
-
-        # ---- qk LayerNorm + RoPE + head-major scatter; text rows first, then video (torch.cat at :277-279)
+        # ---- row layout of the attention operands: text rows first, then video (torch.cat at :277-279)
         lay = None
         if sp is not None:
             lay = sp.layout(T, N)   # per-rank rows: [text | own shard | remote shards | pad]
@@ -116,12 +111,27 @@ class EasyAnimateAttnProcessor2_0:
             cos, sin = rope_to_device(image_rotary_emb, dev)
         if attn.norm_q is None or attn.norm_k is None:
             raise NotImplementedError("qk_norm=None is not supported by the HIP processor")
-        ops.qknorm_rope(qkv_t, ws["q"], ws["k"], ws["vt"], f32(tattn.norm_q.weight), f32(tattn.norm_q.bias),
-                        f32(tattn.norm_k.weight), f32(tattn.norm_k.bias), None, None, 0, tattn.norm_q.eps,
-                        q_scale=ops.FOLDED_Q_SCALE)
-        ops.qknorm_rope(qkv_v, ws["q"], ws["k"], ws["vt"], f32(attn.norm_q.weight), f32(attn.norm_q.bias),
-                        f32(attn.norm_k.weight), f32(attn.norm_k.bias), cos, sin, v_off, attn.norm_q.eps,
-                        q_scale=ops.FOLDED_Q_SCALE)
+
+        # ---- QKV projections + qk LayerNorm + RoPE + head-major scatter (processor.py:244-285)
+        def qkv_stream(inp, mod, n_tok, seq_off, c, s_):
+            lq, lk, lv = mod.to_q, mod.to_k, mod.to_v
+            nq, nk = mod.norm_q, mod.norm_k
+            if self.fuse_qkv and ops.qkv_fused_ok(n_tok, d, inp.shape[2], seq_off):
+                # one launch: the [B, n, 3d] QKV buffer never exists (ea_qkv_gemm_norm_rope_bf16)
+                ops.qkv_gemm_norm_rope(inp, bf16_weight(lq.weight), bf16_weight(lk.weight), bf16_weight(lv.weight),
+                                       f32(lq.bias), f32(lk.bias), f32(lv.bias), ws["q"], ws["k"], ws["vt"],
+                                       f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias), c, s_, seq_off, nq.eps,
+                                       q_scale=ops.FOLDED_Q_SCALE)
+                return
+            # three GEMMs into one [B, n, 3d] buffer, then one normalise / rotate / scatter pass
+            qkv = torch.empty(B, n_tok, 3 * d, dtype=torch.bfloat16, device=dev)
+            for i, lin in enumerate((lq, lk, lv)):
+                ops.gemm(inp, bf16_weight(lin.weight), f32(lin.bias), ops.EPI_BIAS, out=qkv[:, :, i * d:(i + 1) * d])
+            ops.qknorm_rope(qkv, ws["q"], ws["k"], ws["vt"], f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias),
+                            c, s_, seq_off, nq.eps, q_scale=ops.FOLDED_Q_SCALE)
+
+        qkv_stream(e, tattn, T, 0, None, None)      # text rows: no RoPE
+        qkv_stream(x, attn, N, v_off, cos, sin)
 
         # ---- joint attention (processor.py:287-291): queries = text rows + this rank's video rows
         o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)

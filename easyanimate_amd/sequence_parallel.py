@@ -71,6 +71,11 @@ class _Axis:
 
 
 class SequenceParallel:
+    # force_exchange (hardware bring-up on a 1-GPU box, tests/test_sequence_parallel_gpu.py): a world of ONE rank still runs
+    # the whole multi-rank choreography -- local-key attention pass with stored state, asynchronous all_gather_into_tensor on
+    # the process group's stream, work.wait(), second attention pass resuming the state -- by splitting its own keys in two.
+    force_exchange = False
+
     def __init__(self, group: Optional[dist.ProcessGroup] = None, cfg_parallel: bool = True):
         self.world_group = group
         self.world = dist.get_world_size(group)
@@ -144,6 +149,11 @@ class SequenceParallel:
         n_last = last[1] - last[0]
         remote_valid = 0 if P == 1 else ((P - 1) * nl if self.rank == P - 1 else (P - 2) * nl + n_last)
         local = [(0, T + n_own)] if v_off == T else [(0, T), (v_off, v_off + n_own)]
+        if P == 1 and self.force_exchange and v_off == T and T + n_own >= 128:
+            # bring-up mode: the second half of the rank's own keys plays the part of the remote shards
+            split = (T + n_own) // 2 // 64 * 64
+            return Layout(T=T, v_off=v_off, n_own=n_own, n_loc=nl, s_pad=s_pad, q_end=v_off + n_own, local_ranges=[(0, split)],
+                          remote_begin=split, remote_end=T + n_own)
         return Layout(T=T, v_off=v_off, n_own=n_own, n_loc=nl, s_pad=s_pad, q_end=v_off + n_own, local_ranges=local,
                       remote_begin=v_off + nl, remote_end=v_off + nl + remote_valid)
 
@@ -160,7 +170,7 @@ class SequenceParallel:
         """Start the all-gather of every rank's own K rows / V^T columns (rows [v_off, v_off+n_loc) of its buffers).
         Returns a handle for exchange_finish.  With RCCL the collective runs on the process group's stream, behind
         everything already queued on the current stream, and the caller keeps launching compute."""
-        if self.size == 1:
+        if self.size == 1 and not self.force_exchange:
             return None
         k, vt = ws["k"], ws["vt"]
         B, H = k.shape[0], k.shape[1]
@@ -209,7 +219,7 @@ class SequenceParallel:
     # ---- final prediction ---------------------------------------------------------------------
     def gather_tokens(self, x: torch.Tensor) -> torch.Tensor:
         """This rank's [b_loc, n_own, C] -> the full [batch, N, C] on every rank (one world-wide all-gather)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return x
         b, n, C = x.shape
         send = torch.zeros((b, self.n_loc, C), dtype=x.dtype, device=x.device)
@@ -227,8 +237,60 @@ class SequenceParallel:
         return out[:, :self.n_total].contiguous()
 
 
-def enable(transformer, group: Optional[dist.ProcessGroup] = None, cfg_parallel: bool = True) -> SequenceParallel:
-    """Attach multi-GPU sampling to an EasyAnimateTransformer3DModel (all ranks hold identical weights)."""
+class EmulatedRank(SequenceParallel):
+    """One GPU runs exactly the per-step COMPUTE of rank `rank` in a world of `world` ranks -- its batch slice (CFG axis),
+    its token shard through every per-token kernel, its queries (text + own shard) over all keys in the two-pass
+    local / remote form -- with no communication: the remote K rows / V^T columns are random data written once, the final
+    gather returns the rank's own prediction tiled.  bench.py --emulate-rank P,r uses it to MODEL the 1 -> P scaling curve
+    (speed-up <= T_1 / T_rank) on a one-GPU box; the collectives, their overlap and the pack / unpack copies are NOT in that
+    number."""
+
+    def __init__(self, world: int, rank: int, cfg_parallel: bool = True):
+        assert 0 <= rank < world
+        self.world_group = None
+        self.world = world
+        self.world_rank = rank
+        self._flat = _Axis(world, rank, 1, None)
+        self._cfg = _Axis(world, rank, 2, None) if (cfg_parallel and world % 2 == 0) else None
+        self.axis = self._flat
+        self.n_total = 0
+        self.n_loc = 0
+        self._filled = set()
+
+    def exchange_start(self, ws: dict, v_off: int):
+        if self.size == 1:
+            return None
+        key = (ws["k"].data_ptr(), self.size, self.n_loc)
+        if key not in self._filled:   # remote slots: N(0,1) keys / values, written once (zeros would run at a higher clock)
+            lo = v_off + self.n_loc
+            hi = v_off + self.size * self.n_loc
+            ws["k"][:, :, lo:hi].normal_()
+            ws["vt"][:, :, :, lo:hi].normal_()
+            self._filled.add(key)
+        return None
+
+    def exchange_finish(self, handle, ws: dict, v_off: int) -> None:
+        return None
+
+    def all_reduce_sums(self, sums: torch.Tensor, n: int):
+        return sums.to(torch.float64) * self.world, n * self.world
+
+    def gather_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return x
+        b, n, C = x.shape
+        out = x.new_zeros((self.axis.cfg_degree * b, self.size * self.n_loc, C))
+        for c in range(self.axis.cfg_degree):
+            for r in range(self.size):
+                out[c * b:(c + 1) * b, r * self.n_loc:r * self.n_loc + n] = x
+        return out[:, :self.n_total].contiguous()
+
+
+def enable(transformer, group: Optional[dist.ProcessGroup] = None, cfg_parallel: bool = True,
+           force: bool = False) -> SequenceParallel:
+    """Attach multi-GPU sampling to an EasyAnimateTransformer3DModel (all ranks hold identical weights).
+    force=True keeps the multi-rank code path on even in a world of one rank (bring-up, see force_exchange)."""
     sp = SequenceParallel(group, cfg_parallel=cfg_parallel)
-    transformer.sequence_parallel = sp if sp.world > 1 else None
+    sp.force_exchange = bool(force)
+    transformer.sequence_parallel = sp if (sp.world > 1 or force) else None
     return sp

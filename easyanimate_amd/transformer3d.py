@@ -113,8 +113,6 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
             raise NotImplementedError("patch_size must be 2 (V5/V5.1)")
         if attention_head_dim != 64:
             raise NotImplementedError("attention_head_dim must be 64 (V5/V5.1)")
-        if ref_channels is not None or clip_channels is not None:
-            raise NotImplementedError("ref_latents / clip inputs are a SURVEY 8(f) 'next' row")
         self.num_heads = num_attention_heads
         self.inner_dim = num_attention_heads * attention_head_dim
         self.resize_inpaint_mask_directly = resize_inpaint_mask_directly
@@ -133,6 +131,14 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
             self.text_proj = nn.Sequential(EasyAnimateRMSNorm(text_embed_dim), nn.Linear(text_embed_dim, self.inner_dim))
             if text_embed_dim_t5 is not None:
                 self.text_proj_t5 = nn.Sequential(EasyAnimateRMSNorm(text_embed_dim), nn.Linear(text_embed_dim_t5, self.inner_dim))
+        if ref_channels is not None:
+            # ref-latent branch (transformer3d.py:1420-1428): its own patch embedding + a fixed 2-D sin/cos table
+            self.ref_proj = nn.Conv2d(ref_channels, self.inner_dim, kernel_size=(patch_size, patch_size), stride=patch_size, bias=True)
+            from .embeddings import get_2d_sincos_pos_embed
+            self.register_buffer("ref_pos_embedding", get_2d_sincos_pos_embed(self.inner_dim, (self.post_patch_height, self.post_patch_width)),
+                                 persistent=False)
+        if clip_channels is not None:
+            self.clip_proj = nn.Linear(clip_channels, self.inner_dim)
         self.swa_layers = swa_layers
         self.transformer_blocks = nn.ModuleList([
             EasyAnimateDiTBlock(
@@ -179,6 +185,23 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
             x = torch.nn.functional.pad(x, (0, kp - K))
         return ops.gemm(x, bf16_weight(lin.weight, kp), f32(lin.bias), ops.EPI_BIAS)
 
+    def _ref_tokens(self, ref_latents: torch.Tensor, gh: int, gw: int) -> torch.Tensor:
+        """ref_proj (Conv2d k=s=2 per frame == gather + GEMM) + the position table, trilinearly resized from the
+        (post_patch_height, post_patch_width) grid it was built on to this call's (gh, gw) grid (transformer3d.py:1538-1556).
+        The resize touches one [gh*gw, d] table per forward: host-side table construction like the RoPE tables."""
+        rb, rc, rf, rh, rw = ref_latents.shape
+        lat = ref_latents if ref_latents.dtype in (torch.bfloat16, torch.float32) else ref_latents.float()
+        k_pad = ops.round_up(rc * 4, 64)
+        tok = ops.gemm(ops.patchify(lat.contiguous(), None, k_pad), bf16_weight(self.ref_proj.weight, k_pad), f32(self.ref_proj.bias),
+                       ops.EPI_BIAS)                                        # [B, rf * rh/2 * rw/2, d]
+        d = self.inner_dim
+        pe = self.ref_pos_embedding.view(1, 1, self.post_patch_height, self.post_patch_width, d).permute(0, 4, 1, 2, 3)
+        pe = torch.nn.functional.interpolate(pe, size=[1, gh, gw], mode="trilinear", align_corners=False)
+        pe = pe.permute(0, 2, 3, 4, 1).reshape(1, -1, d).to(torch.bfloat16)
+        if pe.shape[1] != tok.shape[1]:
+            raise ValueError(f"ref_latents give {tok.shape[1]} tokens, the position table {pe.shape[1]} (one frame of {gh}x{gw} expected)")
+        return ops.bf16_add_(tok, pe.expand(rb, -1, -1).contiguous())
+
     def time_embed(self, timestep: torch.Tensor, batch_size: int, bf16_round: bool = True) -> torch.Tensor:
         """transformer3d.py:1519-1520: sinusoid (fp32, rounded to the latent dtype) -> Linear -> SiLU -> Linear."""
         t = timestep.reshape(-1).to(device=self.device, dtype=torch.float32)
@@ -209,8 +232,8 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
         added_cond_kwargs: Dict[str, torch.Tensor] = None,
         return_dict=True,
     ):
-        if ref_latents is not None or clip_encoder_hidden_states is not None:
-            raise NotImplementedError("ref_latents / clip inputs are a SURVEY 8(f) 'next' row")
+        if clip_encoder_hidden_states is not None and ref_latents is None:
+            raise ValueError("clip_encoder_hidden_states needs ref_latents (transformer3d.py:1559 concatenates the two)")
         if not hidden_states.is_cuda:
             raise RuntimeError("EasyAnimateTransformer3DModel (MI355X): inputs must be on the GPU; there is no CPU fallback")
         batch_size, channels, video_length, height, width = hidden_states.size()
@@ -225,6 +248,7 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
                 hidden_states, encoder_hidden_states = cut(hidden_states), cut(encoder_hidden_states)
                 timestep = timestep if timestep.numel() == 1 else timestep.reshape(-1)[b0:b1]
                 encoder_hidden_states_t5, inpaint_latents, control_latents = cut(encoder_hidden_states_t5), cut(inpaint_latents), cut(control_latents)
+                ref_latents, clip_encoder_hidden_states = cut(ref_latents), cut(clip_encoder_hidden_states)
                 batch_size = b1 - b0
 
         # 1. time embedding
@@ -256,6 +280,14 @@ class EasyAnimateTransformer3DModel(nn.Module, ConfigMixin):
         if encoder_hidden_states_t5 is not None:
             enc_t5 = self._text_proj(self.text_proj_t5, encoder_hidden_states_t5.to(hs.device))
             enc = torch.cat([enc, enc_t5], dim=1).contiguous()
+
+        # 3b. ref-latent / CLIP conditioning (transformer3d.py:1538-1561): the projected reference latents (+ a fixed 2-D
+        # sin/cos table resized to the latent grid) REPLACE the text stream; CLIP tokens are prepended to them
+        if ref_latents is not None:
+            enc = self._ref_tokens(ref_latents.to(hs.device), height // p, width // p)
+            if clip_encoder_hidden_states is not None:
+                clip = self._text_proj(self.clip_proj, clip_encoder_hidden_states.to(hs.device))
+                enc = torch.cat([clip, enc], dim=1).contiguous()
 
         rope = image_rotary_emb
         if rope is not None and sp is not None:

@@ -129,6 +129,24 @@ int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q
                         const float* nk_b, const float* cos, const float* sin, int batch, int heads,
                         int n_tok, int seq_off, int s_pad, float ln_eps, float q_scale, void* stream);
 
+/* The three QKV projections of one token stream and everything up to the attention operands in ONE launch:
+ *   q, k, v = A.Wq^T + bq, A.Wk^T + bk, A.Wv^T + bv   (processor.py:244-246 / 261-263)
+ * followed, in the GEMM epilogue, by exactly what ea_qknorm_rope_bf16 does to the stored QKV values (qk-LayerNorm(64),
+ * RoPE, q_scale, head-major scatter of q / k, transposed scatter of v; processor.py:251-285).  The [batch, M, 3*heads*64]
+ * QKV buffer never exists and A is read once.  Same roundings at the same points as ea_gemm_bf16 x 3 +
+ * ea_qknorm_rope_bf16: V^T is bit-identical, q / k agree up to the fp32 summation order of the LayerNorm statistics (<= 1 bf16 ulp).
+ *   A: bf16 [batch, M, K] (row stride lda);  Wq/Wk/Wv: bf16 [heads*64, K] (three separate nn.Linear weights);
+ *   bq/bk/bv: fp32 [heads*64] or NULL;  q_out/k_out: bf16 [batch, heads, s_pad, 64];  vt_out: bf16 [batch, heads, 64, s_pad];
+ *   rows / columns [seq_off, seq_off + M) are written;  cos/sin: fp32 [M, 64] or NULL.
+ * Requirements: M % 256 == 0, (heads*64) % 256 == 0, K % 64 == 0, seq_off % 8 == 0; other shapes (the 256-token text
+ * stream, test-size models) use ea_gemm_bf16 + ea_qknorm_rope_bf16. */
+int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
+                               const float* bq, const float* bk, const float* bv, ea_bf16* q_out, ea_bf16* k_out,
+                               ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
+                               const float* nk_b, const float* cos, const float* sin, int batch, int M, int heads,
+                               int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, float ln_eps,
+                               float q_scale, void* stream);
+
 /* Non-causal, unmasked softmax(Q K^T * scale) V, head_dim 64, bf16 in/out, fp32 softmax state.
  * Replaces F.scaled_dot_product_attention at processor.py:287-289 plus the transpose/reshape at :291.
  *   q,k : bf16 [batch, heads, s_pad, 64];  vt: bf16 [batch, heads, 64, s_pad]; rows/cols >= seq are
@@ -192,6 +210,13 @@ int ea_teacache_rel_l1_bf16(const ea_bf16* cur, const ea_bf16* prev, int64_t n, 
  * the cached residual `previous_residual = hidden_states - ori_hidden_states` (:1635) and its re-application
  * `hidden_states += previous_residual` (:1590).  out may alias a or b.  n % 8 == 0. */
 int ea_bf16_binary(const ea_bf16* a, const ea_bf16* b, ea_bf16* out, int64_t n, int op, void* stream);
+
+/* out[b,r,:] = res[b,r,:] + gate[b,:] * x[b,r,:]  (bf16 in/out, fp32 fma, one rounding): the gated residual of
+ * attention.py:1161-1162 as a stand-alone pass, used only by after_norm=True blocks (norm3 sits between the FFN GEMM and
+ * the residual, :1150-1155, so the add cannot ride in the GEMM epilogue).  x/res/out: [batch, rows, dim] contiguous,
+ * gate: fp32 rows of a [batch, gate_batch_stride] table.  dim % 8 == 0.  out may alias res or x. */
+int ea_gated_residual_bf16(const ea_bf16* x, const ea_bf16* res, const float* gate, ea_bf16* out, int batch,
+                           int64_t rows, int dim, int64_t gate_batch_stride, void* stream);
 
 /* Causal 3-D convolution as an im2col-free implicit GEMM (vaemodules/common.py:84-179 CausalConv3d; the
  * strided down-samplers downsamplers.py:24-94; the up-samplers upsamplers.py:21-37,123-153; the residual add of

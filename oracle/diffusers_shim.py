@@ -182,6 +182,31 @@ def get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size, t
 # ----------------------------------------------------------------------------------------------
 # attention / feed-forward / norms
 # ----------------------------------------------------------------------------------------------
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False, extra_tokens=0, interpolation_scale=1.0, base_size=16):
+    """diffusers.models.embeddings.get_2d_sincos_pos_embed (0.30/0.31) [restated]: called by the reference at
+    models/transformer3d.py:1424 (ref_pos_embedding of the ref-latent control branch).  float64 numpy, [H*W, embed_dim]."""
+    import numpy as np
+    if isinstance(grid_size, int):
+        grid_size = (grid_size, grid_size)
+    grid_h = np.arange(grid_size[0], dtype=np.float32) / (grid_size[0] / base_size) / interpolation_scale
+    grid_w = np.arange(grid_size[1], dtype=np.float32) / (grid_size[1] / base_size) / interpolation_scale
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0)          # w goes first
+    grid = grid.reshape([2, 1, grid_size[1], grid_size[0]])
+
+    def one(dim, pos):
+        omega = np.arange(dim // 2, dtype=np.float64)
+        omega /= dim / 2.0
+        omega = 1.0 / 10000 ** omega
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    emb = np.concatenate([one(embed_dim // 2, grid[0]), one(embed_dim // 2, grid[1])], axis=1)
+    if cls_token and extra_tokens > 0:
+        emb = np.concatenate([np.zeros([extra_tokens, embed_dim]), emb], axis=0)
+    return emb
+
+
 class Attention(nn.Module):
     """Holder of to_q/k/v, norm_q/k, to_out; forwards to the processor with signature-filtered kwargs."""
 
@@ -433,7 +458,8 @@ _REAL = {
                                         get_timestep_embedding=get_timestep_embedding,
                                         apply_rotary_emb=apply_rotary_emb,
                                         get_1d_rotary_pos_embed=get_1d_rotary_pos_embed,
-                                        get_3d_rotary_pos_embed=get_3d_rotary_pos_embed),
+                                        get_3d_rotary_pos_embed=get_3d_rotary_pos_embed,
+                                        get_2d_sincos_pos_embed=get_2d_sincos_pos_embed),
     "diffusers.models.normalization": dict(AdaLayerNorm=AdaLayerNorm),
     "diffusers.models.autoencoders.vae": dict(DiagonalGaussianDistribution=DiagonalGaussianDistribution,
                                               DecoderOutput=DecoderOutput),

@@ -463,7 +463,21 @@ def gen_config1(ns, shim):
         x = s.step(vu + 6.0 * (vt - vu), t, x, return_dict=False)[0]
         trace.append(x.clone())
         print(f"  step: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads", flush=True)
-    del m
+    # the reference's own bf16 run of the same loop (the noise floor of this 2-step, d_sigma = 0.5, CFG-6 configuration)
+    mb = m.to(torch.bfloat16)
+    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(2, device="cpu", mu=1)
+    xb = latents.clone().bfloat16()
+    trace_b = []
+    for t in s.timesteps:
+        t0 = time.time()
+        li = torch.cat([xb] * 2)
+        v = mb(li, torch.tensor([t] * 2).to(li.dtype), encoder_hidden_states=enc.bfloat16(), image_rotary_emb=rope, return_dict=False)[0]
+        vu, vt = v.chunk(2)
+        xb = s.step(vu + 6.0 * (vt - vu), t, xb, return_dict=False)[0]
+        trace_b.append(xb.float().clone())
+        print(f"  bf16 step: {time.time() - t0:.1f} s; reference bf16-vs-fp32 latent MSE {_mse(trace_b[-1], trace[len(trace_b) - 1]):.3e}", flush=True)
+    del m, mb
     vae, vshapes = _meta_build(lambda: ns.autoencoder_magvit.AutoencoderKLMagvit(**FULL_VAE), 2, "default_bf16")
     t0 = time.time()
     dec = vae.decode(x / 0.1825)[0]
@@ -471,7 +485,39 @@ def gen_config1(ns, shim):
     print(f"  vae decode {time.time() - t0:.1f} s; latents std {x.std().item():.3f}, frames mean {frames.mean().item():.3f}", flush=True)
     torch.save(dict(dit_cfg=DIT_7B, vae_cfg=FULL_VAE, dit_seed=0, vae_seed=2, style="default_bf16", steps=2, guidance=6.0,
                     height=256, width=256, video_length=1, latents_sum=latents.double().sum().item(),
-                    enc_sum=enc.double().sum().item(), trace=trace, frames=frames), os.path.join(OUT, "config1_7b_256.pt"))
+                    enc_sum=enc.double().sum().item(), trace=trace, trace_bf16=trace_b, frames=frames), os.path.join(OUT, "config1_7b_256.pt"))
+
+
+@section("transformer_r2b")
+def gen_transformer_r2b(ns, shim):
+    # ---- more branches of the hot forward: after_norm (attention.py:1102-1105,1150-1155) and the
+    # ref-latent / CLIP conditioning of the control checkpoints (transformer3d.py:1420-1431,1538-1561)
+    cases = (("transformer_after_norm", dict(after_norm=True), False, "stress"),
+             ("transformer_ref_clip", dict(in_channels=32, ref_channels=16, clip_channels=24, sample_height=12, sample_width=20), True, "stress"),
+             ("transformer_ref", dict(in_channels=32, ref_channels=16, sample_height=8, sample_width=12), True, "default"))
+    for name, over, use_ref, style in cases:
+        cfg = dict(TINY, **over)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval().to(torch.float32)   # (the sin/cos buffer is float64 until cast)
+        shapes = _load_sd(m, 3, style)
+        g = _g(19)
+        B, Fr, H, W, T = 2, 3, 8, 12, 9
+        lat = torch.randn(B, 16, Fr, H, W, generator=g)
+        ctrl = torch.randn(B, cfg["in_channels"] - 16, Fr, H, W, generator=g) if cfg["in_channels"] > 16 else None
+        enc = torch.randn(B, T, cfg["text_embed_dim"], generator=g) * 3
+        ref = torch.randn(B, 16, 1, H, W, generator=g) if use_ref else None
+        clip = torch.randn(B, 5, cfg["clip_channels"], generator=g) if cfg.get("clip_channels") else None
+        t = torch.tensor([411.0, 411.0]).to(torch.bfloat16).float()
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        bf = lambda x: None if x is None else x.bfloat16()
+        out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), control_latents=ctrl, ref_latents=ref,
+                clip_encoder_hidden_states=clip, return_dict=False)[0]
+        mb = copy.deepcopy(m).to(torch.bfloat16)
+        outb = mb(bf(lat), t.bfloat16(), encoder_hidden_states=bf(enc), image_rotary_emb=(cos, sin), control_latents=bf(ctrl),
+                  ref_latents=bf(ref), clip_encoder_hidden_states=bf(clip), return_dict=False)[0]
+        print(f"  {name}: out std {out.std().item():.3f}, floor {_mse(outb.float(), out):.3e}")
+        torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, latents=lat, control=ctrl, enc=enc, ref=ref, clip=clip, t=t,
+                        cos=cos, sin=sin, out=out, out_bf16=outb.float()), os.path.join(OUT, f"{name}.pt"))
 
 
 @torch.no_grad()

@@ -164,8 +164,10 @@ def feed_forward(sd: SD, pre: str, x):
     return F.linear(x, sd[pre + "net.2.weight"], sd[pre + "net.2.bias"])
 
 
-def dit_block(sd: SD, pre: str, h, e, temb, rope, heads: int, norm_eps: float, return_parts: bool = False):
-    """EasyAnimateDiTBlock.forward, easyanimate/models/attention.py:1107-1163 (after_norm=False, not SWA)."""
+def dit_block(sd: SD, pre: str, h, e, temb, rope, heads: int, norm_eps: float, return_parts: bool = False,
+              after_norm: bool = False):
+    """EasyAnimateDiTBlock.forward, easyanimate/models/attention.py:1107-1163 (not SWA; after_norm is detected from the
+    norm3.* keys, or forced for an affine-free norm3)."""
     mmdit = (pre + "attn2.to_q.weight") in sd
     nh, ne, gate, egate = layernorm_zero(sd, pre + "norm1.", h, e, temb, norm_eps)
     ah, ae = attn_processor(sd, pre + "attn1.", pre + "attn2." if mmdit else None, nh, ne, rope, heads)
@@ -174,6 +176,9 @@ def dit_block(sd: SD, pre: str, h, e, temb, rope, heads: int, norm_eps: float, r
     nh, ne, gate_ff, egate_ff = layernorm_zero(sd, pre + "norm2.", h, e, temb, norm_eps)
     fh = feed_forward(sd, pre + "ff.", nh)
     fe = feed_forward(sd, pre + ("txt_ff." if (pre + "txt_ff.net.2.weight") in sd else "ff."), ne)
+    if (pre + "norm3.weight") in sd or after_norm:      # after_norm, attention.py:1150-1155 (FP32LayerNorm)
+        fh = fp32_layernorm(fh, sd.get(pre + "norm3.weight"), sd.get(pre + "norm3.bias"), norm_eps)
+        fe = fp32_layernorm(fe, sd.get(pre + "norm3.weight"), sd.get(pre + "norm3.bias"), norm_eps)
     h2 = h + gate_ff * fh
     e2 = e + egate_ff * fe
     if return_parts:
@@ -228,9 +233,39 @@ def text_projection(sd: SD, pre: str, enc):
     return F.linear(enc, sd[pre + ".weight"], sd[pre + ".bias"])
 
 
+def sincos_2d(embed_dim: int, gh: int, gw: int, base_size: int = 16):
+    """diffusers get_2d_sincos_pos_embed [restated] as called at transformer3d.py:1424: float64 [gh*gw, embed_dim]."""
+    ch = np.arange(gh, dtype=np.float32) / (gh / base_size)
+    cw = np.arange(gw, dtype=np.float32) / (gw / base_size)
+    grid = np.stack(np.meshgrid(cw, ch), axis=0).reshape(2, -1)
+
+    def one(dim, pos):
+        omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+        out = np.einsum("m,d->md", pos, omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    return torch.from_numpy(np.concatenate([one(embed_dim // 2, grid[0]), one(embed_dim // 2, grid[1])], axis=1))
+
+
+def ref_clip_tokens(sd: SD, cfg: dict, ref_latents, clip_states, gh: int, gw: int, dtype):
+    """transformer3d.py:1538-1561: ref_proj patch embedding + the 2-D sin/cos table resized (trilinear) to the latent grid;
+    CLIP tokens (clip_proj) are prepended.  The result REPLACES the text stream."""
+    inner = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    p = cfg["patch_size"]
+    B, C, Fr, H, W = ref_latents.shape
+    r = F.conv2d(ref_latents.permute(0, 2, 1, 3, 4).reshape(B * Fr, C, H, W), sd["ref_proj.weight"], sd["ref_proj.bias"], stride=p)
+    r = r.reshape(B, Fr, inner, H // p, W // p).permute(0, 2, 1, 3, 4).flatten(2).transpose(1, 2)
+    pph, ppw = cfg.get("sample_height", 60) // p, cfg.get("sample_width", 90) // p
+    pe = sincos_2d(inner, pph, ppw).to(dtype).view(1, 1, pph, ppw, inner).permute(0, 4, 1, 2, 3)
+    pe = F.interpolate(pe, size=[1, gh, gw], mode="trilinear", align_corners=False).permute(0, 2, 3, 4, 1).reshape(1, -1, inner)
+    e = r + pe
+    if clip_states is not None:
+        e = torch.cat([F.linear(clip_states, sd["clip_proj.weight"], sd["clip_proj.bias"]), e], dim=1)
+    return e
+
+
 def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint_latents=None, teacache=None,
-                        control_latents=None, enc_t5=None):
-    """EasyAnimateTransformer3DModel.forward, transformer3d.py:1496-1689 (no ref/clip inputs)."""
+                        control_latents=None, enc_t5=None, ref_latents=None, clip_states=None):
+    """EasyAnimateTransformer3DModel.forward, transformer3d.py:1496-1689."""
     heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
     inner = heads * dh
     p = cfg["patch_size"]
@@ -246,6 +281,8 @@ def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint
     e = text_projection(sd, "text_proj", enc)
     if enc_t5 is not None:                                                                      # :1534-1536
         e = torch.cat([e, text_projection(sd, "text_proj_t5", enc_t5)], dim=1)
+    if ref_latents is not None:
+        e = ref_clip_tokens(sd, cfg, ref_latents, clip_states, H // p, W // p, dtype)
     calc = True
     if teacache is not None:
         mod_in, _, _, _ = layernorm_zero(sd, "transformer_blocks.0.norm1.", x, e, temb, cfg["norm_eps"])
@@ -256,7 +293,8 @@ def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint
     if calc:
         x_in = x
         for i in range(cfg["num_layers"]):
-            x, e = dit_block(sd, f"transformer_blocks.{i}.", x, e, temb, rope, heads, cfg["norm_eps"])
+            x, e = dit_block(sd, f"transformer_blocks.{i}.", x, e, temb, rope, heads, cfg["norm_eps"],
+                             after_norm=bool(cfg.get("after_norm", False)))
         T = e.shape[1]
         x = torch.cat([e, x], dim=1)
         x = F.layer_norm(x, (inner,), sd.get("norm_final.weight"), sd.get("norm_final.bias"), cfg["norm_eps"])

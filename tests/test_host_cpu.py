@@ -130,3 +130,53 @@ def test_i2v_conditioning_host_logic():
     mv, mc = EasyAnimateInpaintPipeline.masked_video_and_mask(video, mask)
     assert torch.equal(mv[0, :, 0], img * 2 - 1) and (mv[0, :, 1:] == -1).all()
     assert mc[0, 0, 0].max() == 0 and mc[0, 0, 1:].min() == 1
+
+
+def test_loaders_round_trip_synthetic_checkpoint(tmp_path):
+    """from_pretrained_2d / from_pretrained / scheduler.from_pretrained on an HF-layout directory (SURVEY 5.4;
+    reference: transformer3d.py:1692-1809, autoencoder_magvit.py:478-505, predict_t2v.py:91-142,219-231), incl. the YAML
+    kwargs merge and the `proj.weight` input-channel padding 16 -> 33 (:1775-1787).  Host logic only: no GPU."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import predict_t2v_mi355x as ex
+    from easyanimate_amd import (FlowMatchEulerDiscreteScheduler, name_to_autoencoder_magvit, name_to_transformer3d)
+    from easyanimate_amd.config import load_yaml
+    from easyanimate_amd.synthetic import synth_tensor
+    d = ex.make_synthetic_checkpoint(str(tmp_path / "ckpt"), "tiny", shard_bytes=200_000)   # forces the multi-shard glob branch
+    assert len([f for f in os.listdir(os.path.join(d, "transformer")) if f.endswith(".safetensors")]) > 1
+    cfg = load_yaml(ex.write_yaml(str(tmp_path / "v51.yaml")))
+    assert cfg["transformer_additional_kwargs"]["transformer_type"] == "EasyAnimateTransformer3DModel"
+    assert cfg["vae_kwargs"]["vae_type"] == "AutoencoderKLMagvit" and cfg["vae_kwargs"]["mini_batch_encoder"] == 4
+    T = name_to_transformer3d[cfg["transformer_additional_kwargs"]["transformer_type"]]
+    m = T.from_pretrained_2d(d, subfolder="transformer", transformer_additional_kwargs=dict(cfg["transformer_additional_kwargs"]),
+                             torch_dtype=torch.bfloat16, low_cpu_mem_usage=True)
+    assert m.dtype == torch.bfloat16 and m.config.resize_inpaint_mask_directly is True and m.resize_inpaint_mask_directly is True
+    assert m.config.add_ref_latent_in_control_model is True and m.config.in_channels == 16
+    for k, v in m.state_dict().items():   # every tensor is the synthetic one that was written
+        assert torch.equal(v.float(), synth_tensor(k, tuple(v.shape), 0, "default_bf16")), k
+    # T2V checkpoint into an InP architecture: extra input channels of proj.weight are zero, the first 16 are the checkpoint's
+    kw = dict(cfg["transformer_additional_kwargs"], in_channels=33)
+    m33 = T.from_pretrained_2d(d, subfolder="transformer", transformer_additional_kwargs=kw)
+    w = m33.state_dict()["proj.weight"]
+    assert w.shape[1] == 33 and torch.equal(w[:, :16], m.state_dict()["proj.weight"]) and w[:, 16:].abs().max() == 0
+    assert torch.equal(m33.state_dict()["proj_out.weight"], m.state_dict()["proj_out.weight"])
+    # ... and the other way round (InP checkpoint into a 16-channel model keeps the first 16 channels)
+    d33 = ex.make_synthetic_checkpoint(str(tmp_path / "ckpt33"), "tiny", in_channels=33)
+    m16 = T.from_pretrained_2d(d33, subfolder="transformer", transformer_additional_kwargs=dict(cfg["transformer_additional_kwargs"], in_channels=16))
+    w33 = synth_tensor("proj.weight", (128, 33, 2, 2), 0, "default_bf16")
+    assert torch.equal(m16.state_dict()["proj.weight"].float(), w33[:, :16])
+    # fp8 storage mode of predict_t2v.py:37,104 (every parameter stored as float8_e4m3fn)
+    m8 = T.from_pretrained_2d(d, subfolder="transformer", transformer_additional_kwargs=dict(cfg["transformer_additional_kwargs"]),
+                              torch_dtype=torch.float8_e4m3fn, low_cpu_mem_usage=True)
+    assert m8.proj_out.weight.dtype == torch.float8_e4m3fn
+    # VAE: predict_t2v.py passes the YAML dict as ONE keyword (vae_additional_kwargs=...), which from_config ignores
+    V = name_to_autoencoder_magvit[cfg["vae_kwargs"]["vae_type"]]
+    vae = V.from_pretrained(d, subfolder="vae", vae_additional_kwargs=dict(cfg["vae_kwargs"])).to(torch.bfloat16)
+    assert vae.config.scaling_factor == 0.1825 and vae.config.latent_channels == 16 and vae.quant_conv.weight.ndim == 5
+    assert vae.cache_mag_vae is True and vae.mini_batch_encoder == 4 and vae.mini_batch_decoder == 1
+    for k, v in vae.state_dict().items():
+        assert torch.equal(v.float(), synth_tensor(k, tuple(v.shape), 2, "default_bf16")), k
+    s = FlowMatchEulerDiscreteScheduler.from_pretrained(d, subfolder="scheduler")
+    assert s.config.shift == 1.0 and s.config.use_dynamic_shifting is False
+    with pytest.raises(RuntimeError, match="does not exist"):
+        T.from_pretrained_2d(str(tmp_path / "nope"), subfolder="transformer")

@@ -260,6 +260,75 @@ def test_qknorm_rope(B, H, n_tok, seq_off, use_rope):
     assert vt[:, :, :, seq_off + n_tok:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("B,H,M,K,seq_off,use_rope", [(2, 4, 512, 128, 8, True), (1, 4, 256, 64, 0, False), (2, 48, 768, 3072, 256, True),
+                                                     (1, 8, 1024, 192, 320, True)])
+def test_qkv_fused_matches_unfused(B, H, M, K, seq_off, use_rope):
+    """ea_qkv_gemm_norm_rope_bf16 (one launch: three projections + qk-LayerNorm + RoPE + scatter in the GEMM epilogue,
+    V^T through the operand-swapped main loop) against ea_gemm_bf16 x 3 (same 256^2 16x16x32 main loop) followed by
+    ea_qknorm_rope_bf16: same roundings at the same points (V^T bit-identical; q / k up to the summation order of the
+    LayerNorm statistics) -- and the unfused pieces are checked against fp64 elsewhere in this file."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(17)
+    d = H * 64
+    x = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+    ws = [_bf(torch.randn(d, K, generator=g) / K ** 0.5).to(DEV) for _ in range(3)]
+    bs = [(0.3 * torch.randn(d, generator=g)).to(DEV) for _ in range(3)]
+    nq_w, nk_w = [(1 + 0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    nq_b, nk_b = [(0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    ang = torch.rand(M, 32, generator=g) * 6.28
+    cos = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV) if use_rope else None
+    sin = ang.sin().repeat_interleave(2, 1).contiguous().to(DEV) if use_rope else None
+    s_pad = ops.round_up(seq_off + M, 256) + 256
+    def bufs():
+        # poison: the fused kernel must write exactly rows / columns [seq_off, seq_off + M) and nothing else
+        return (torch.full((B, H, s_pad, 64), 7.0, dtype=torch.bfloat16, device=DEV), torch.full((B, H, s_pad, 64), 7.0, dtype=torch.bfloat16, device=DEV),
+                torch.full((B, H, 64, s_pad), 7.0, dtype=torch.bfloat16, device=DEV))
+    q1, k1, vt1 = bufs()
+    assert ops.qkv_fused_ok(M, d, K, seq_off)
+    _lib.reset_counters()
+    ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q1, k1, vt1, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off,
+                           1e-6, q_scale=ops.FOLDED_Q_SCALE)
+    assert _lib.counters() == {"gemm_qkv_fused": 1}
+    q2, k2, vt2 = bufs()
+    qkv = torch.empty(B, M, 3 * d, dtype=torch.bfloat16, device=DEV)
+    _lib.set_option("gemm_tile", 256)
+    try:
+        for i in range(3):
+            ops.gemm(x, ws[i], bs[i], ops.EPI_BIAS, out=qkv[:, :, i * d:(i + 1) * d])
+    finally:
+        _lib.set_option("gemm_tile", 0)
+    ops.qknorm_rope(qkv, q2, k2, vt2, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off, 1e-6, q_scale=ops.FOLDED_Q_SCALE)
+    torch.cuda.synchronize()
+    # V: no reduction in its epilogue -> every bit agrees.  q / k: the 64-wide LayerNorm statistics are summed in a
+    # different fp32 order (16 values per lane + 2 shuffles here, 8 + 3 there), so a few results land on the neighbouring
+    # bf16 value: at most one ulp apart, and only a small fraction of them
+    assert torch.equal(vt1, vt2)
+    sl0 = slice(seq_off, seq_off + M)
+    for name, a, b in (("q", q1[:, :, sl0], q2[:, :, sl0]), ("k", k1[:, :, sl0], k2[:, :, sl0])):
+        af, bf_ = a.float(), b.float()
+        diff = (af - bf_).abs()
+        # one bf16 ulp of the row's largest value: a rotated pair x0*c - x1*s can cancel to ~0 while a last-bit change of
+        # the normalised x0 still moves it by an ulp of x0
+        tol = af.abs().amax(dim=-1, keepdim=True) * 2.0 ** -7 + 1e-30
+        frac = (diff > 0).float().mean().item()
+        print(f"[parity] fused qkv {name} B{B}H{H}M{M}K{K}: {frac * 100:.4f} % of the values differ from the unfused path, max "
+              f"{(diff / tol).max().item():.2f} ulp of the row maximum")
+        assert (diff <= tol).all() and frac < 0.02, name
+    sl = slice(seq_off, seq_off + M)
+    assert (q1[:, :, :seq_off] == 7).all() and (q1[:, :, seq_off + M:] == 7).all() and (vt1[:, :, :, seq_off + M:] == 7).all()
+    # and against fp64 directly (loose: this is what the unfused tests pin tightly)
+    ref_v = (x.double() @ ws[2].double().t() + bs[2].double())
+    got_v = vt1[:, :, :, sl].permute(0, 3, 1, 2).reshape(B, M, d)
+    err, rel = _report(f"fused qkv V B{B}H{H}M{M}K{K}", got_v, ref_v)
+    assert rel < 4e-3
+    # repeated launches are bit-identical (race screen)
+    q3, k3, vt3 = bufs()
+    ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q3, k3, vt3, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off,
+                           1e-6, q_scale=ops.FOLDED_Q_SCALE)
+    assert torch.equal(q3, q1) and torch.equal(k3, k1) and torch.equal(vt3, vt1)
+
+
 def _attn_inputs(B, H, S, seed, scale_q=1.0):
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(seed)

@@ -213,3 +213,13 @@ def test_restatement_vae_full_width_vs_golden_chunked_reference():
         d = RV.vae_decode(sd, z, 32)
     _close(m, g["moments"], 2e-5, "full-width vae moments")
     _close(d, g["dec_f16"].float(), 1.5e-3, "full-width vae decode (fixture stored fp16)")
+
+
+@pytest.mark.parametrize("name", ["transformer_after_norm", "transformer_ref_clip", "transformer_ref"])
+def test_restatement_after_norm_ref_clip_vs_golden(name):
+    """after_norm (attention.py:1150-1155) and the ref-latent / CLIP conditioning (transformer3d.py:1538-1561)."""
+    g = _load(name + ".pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    out = R.transformer_forward(sd, g["cfg"], g["latents"], g["t"], g["enc"], (g["cos"], g["sin"]), control_latents=g["control"],
+                                ref_latents=g["ref"], clip_states=g["clip"])
+    _close(out, g["out"], 5e-6, name)

@@ -96,6 +96,23 @@ def test_transformer_branches_vs_golden(name):
     assert mse < BAR
 
 
+@pytest.mark.parametrize("name", ["transformer_after_norm", "transformer_ref_clip", "transformer_ref"])
+def test_transformer_after_norm_ref_clip_vs_golden(name):
+    """after_norm blocks (FFN -> FP32LayerNorm -> gated residual) and the ref-latent / CLIP conditioning
+    that replaces the text stream (transformer3d.py:1538-1561), against the unchanged reference."""
+    g = _load(name + ".pt")
+    m = _model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    dev = lambda x: None if x is None else x.to(DEV).bfloat16()
+    with torch.no_grad():
+        out = m(dev(g["latents"]), dev(g["t"]), encoder_hidden_states=dev(g["enc"]), image_rotary_emb=(g["cos"], g["sin"]),
+                control_latents=dev(g["control"]), ref_latents=dev(g["ref"]), clip_encoder_hidden_states=dev(g["clip"]),
+                return_dict=False)[0]
+    mse, floor = _mse(out.float(), g["out"]), _mse(g["out_bf16"], g["out"])
+    print(f"[parity] {name}: new-bf16 vs ref-fp32 MSE={mse:.3e} | ref-bf16 floor {floor:.3e} | new vs ref-bf16 "
+          f"{_mse(out.float(), g['out_bf16']):.3e} | ref std {g['out'].std().item():.3f}")
+    assert out.shape == g["out"].shape and mse < BAR
+
+
 # ---------------------------------------------------------------------------------------------------------
 # (c) full-width two-layer forwards (SURVEY 8d-(i))
 # ---------------------------------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ def test_t2v_pipeline_end_to_end():
                latents=latents.to(torch.bfloat16), prompt_embeds=pos, negative_prompt_embeds=neg, output_type="np")
     frames = out.frames
     assert frames.shape == (1, 3, F_, H, W) and frames.min() >= 0 and frames.max() <= 1
-    rope = pipe.rotary_embedding(H, W, 3)
+    rope = tuple(t.cpu() for t in pipe.rotary_embedding(H, W, 3))   # resident on the device in the product; the oracle runs on the host
     vcfg = dict(cfg_v, scaling_factor=vae.config.scaling_factor)
     ref = _oracle_frames(sd_t, cfg_t, sd_v, vcfg, latents.bfloat16().float(), torch.cat([neg, pos]).bfloat16().float(), rope,
                          steps, guidance)
@@ -96,7 +96,7 @@ def test_i2v_pipeline_end_to_end():
     mask_lat = resize_mask(1 - mask_c, masked_lat, True) * s
     inpaint = torch.cat([mask_lat, masked_lat], 1)
     inpaint = torch.cat([inpaint] * 2)
-    rope = pipe.rotary_embedding(H, W, 3)
+    rope = tuple(t.cpu() for t in pipe.rotary_embedding(H, W, 3))   # resident on the device in the product; the oracle runs on the host
     vcfg = dict(cfg_v, scaling_factor=s)
     ref = _oracle_frames(sd_t, cfg_t, sd_v, vcfg, latents.bfloat16().float(), torch.cat([neg, pos]).bfloat16().float(), rope,
                          steps, guidance, inpaint=inpaint.bfloat16().float())

@@ -118,3 +118,98 @@ def test_sp_teacache_decisions_equal_single_rank(world):
         c1, c2, err, scale = ret[r]
         assert c1 == c2 == [True, False, False, True, False, False, True, True]
         assert err <= 0.06 * max(1.0, scale)
+
+
+# ---- the RCCL branch on real hardware --------------------------------------------------------
+def _nccl_world1_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from easyanimate_amd import EasyAnimateTransformer3DModel, sequence_parallel
+        from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
+        from easyanimate_amd.synthetic import synth_state_dict
+        g = torch.load(os.path.join(GOLD, "transformer_t2v.pt"), weights_only=False)
+        m = EasyAnimateTransformer3DModel.from_config(g["cfg"])
+        m.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+        m = m.to(torch.bfloat16).to("cuda:0").eval()
+        gen = torch.Generator().manual_seed(5)
+        lat = torch.randn(2, 16, 5, 32, 24, generator=gen).to("cuda:0").bfloat16()
+        enc = torch.randn(2, 64, g["cfg"]["text_embed_dim"], generator=gen).to("cuda:0").bfloat16()   # T % 64 == 0
+        t = torch.tensor([500.0, 500.0], device="cuda:0").bfloat16()
+        rope = get_3d_rotary_pos_embed(64, ((0, 8), (30, 38)), (16, 12), 5)
+        with torch.no_grad():
+            ref = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+            sp = sequence_parallel.enable(m, force=True)
+            assert m.sequence_parallel is sp and sp.world == 1 and dist.get_backend() == "nccl"
+            # the collective layer by itself: async all-gather of the K rows / V^T columns, stream-level wait
+            sp.begin(2)
+            sp.plan(960)
+            lay = sp.layout(64, 960)
+            assert lay.remote_end > lay.remote_begin and lay.local_ranges == [(0, 512)]
+            ws = dict(k=torch.randn(2, 2, lay.s_pad, 64, device="cuda:0").bfloat16(),
+                      vt=torch.randn(2, 2, 64, lay.s_pad, device="cuda:0").bfloat16())
+            h = sp.exchange_start(ws, lay.v_off)
+            assert h is not None and h[0] is not None            # a real c10d Work object: async_op=True on the RCCL stream
+            burn = torch.randn(2048, 2048, device="cuda:0") @ torch.randn(2048, 2048, device="cuda:0")   # compute queued meanwhile
+            sp.exchange_finish(h, ws, lay.v_off)
+            work, recv, send = h
+            torch.cuda.synchronize()
+            gathered_ok = torch.equal(recv.view(1, *send.shape)[0], send)
+            outs = [m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0] for _ in range(3)]
+            s2, n2 = sp.all_reduce_sums(torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda:0"), 10)
+        err = max((o.float() - ref.float()).abs().max().item() for o in outs)
+        ret[0] = (err, ref.float().abs().max().item(), gathered_ok, all(torch.equal(outs[0], o) for o in outs[1:]),
+                  s2.tolist(), n2, float(burn[0, 0].item()) == float(burn[0, 0].item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branch_world_of_one():
+    """`init_process_group("nccl")` with one rank and SequenceParallel forced on: the asynchronous
+    all_gather_into_tensor on RCCL's stream, work.wait(), the allocator handing out send / recv buffers while the
+    collective is in flight, and the two-pass (state-carrying) attention around it all execute on the MI355X; the result
+    must equal the plain single-pass forward to summation-order noise."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_world1_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    err, ref_max, gathered_ok, repeat_ok, sums, n, _ = ret[0]
+    print(f"[parity] RCCL world-1 forced sequence-parallel forward vs plain forward: max|d| {err:.3e} (|ref| max {ref_max:.2f}); "
+          f"gathered == sent: {gathered_ok}; repeated forwards bit-identical: {repeat_ok}")
+    assert gathered_ok and repeat_ok and sums == [1.5, 2.5] and n == 10
+    assert err <= 2e-2 * max(1.0, ref_max)
+
+
+def test_emulated_rank_runs_the_rank_local_work():
+    """EmulatedRank(P, r) (bench.py --emulate-rank): the per-rank compute of a P-rank world on one GPU.  For P = 1 it is the
+    plain forward; for P > 1 the own-shard rows of the prediction depend on the random remote keys, so only shapes,
+    finiteness and the launch pattern (per block: local-key pass + remote-key pass over the rank's queries) are checked."""
+    from easyanimate_amd import EasyAnimateTransformer3DModel, _lib
+    from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
+    from easyanimate_amd.sequence_parallel import EmulatedRank
+    from easyanimate_amd.synthetic import synth_state_dict
+    g = torch.load(os.path.join(GOLD, "transformer_t2v.pt"), weights_only=False)
+    m = EasyAnimateTransformer3DModel.from_config(g["cfg"])
+    m.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    m = m.to(torch.bfloat16).to("cuda:0").eval()
+    gen = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 16, 5, 32, 24, generator=gen).to("cuda:0").bfloat16()
+    enc = torch.randn(2, 64, g["cfg"]["text_embed_dim"], generator=gen).to("cuda:0").bfloat16()
+    t = torch.tensor([500.0, 500.0], device="cuda:0").bfloat16()
+    rope = get_3d_rotary_pos_embed(64, ((0, 8), (30, 38)), (16, 12), 5)
+    with torch.no_grad():
+        ref = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+        m.sequence_parallel = EmulatedRank(1, 0)
+        assert torch.equal(m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0], ref)
+        for P, r in ((2, 1), (4, 0), (4, 3), (8, 5)):
+            m.sequence_parallel = EmulatedRank(P, r)
+            _lib.reset_counters()
+            out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+            torch.cuda.synchronize()
+            cnt = _lib.counters()
+            assert out.shape == ref.shape and torch.isfinite(out.float()).all()
+            sp = m.sequence_parallel
+            assert sp.axis.cfg_degree == 2 and sp.size == P // 2
+            expect = g["cfg"]["num_layers"] * (1 if sp.size == 1 else 2)
+            assert cnt.get("attention_v3", 0) == expect, (P, r, cnt)
+    m.sequence_parallel = None
