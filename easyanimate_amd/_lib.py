@@ -36,6 +36,7 @@ PROTOTYPES = {
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_unpatchify": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ea_cfg_euler_step": [_P, _P, _L, _F, _F, _I, _I, _P],
+    "ea_cfg_rescale_euler_step": [_P, _P, _L, _F, _F, _F, _P, _I, _P, _I, _P],
     "ea_teacache_rel_l1_bf16": [_P, _P, _L, _P, _I, _P, _P],
     "ea_bf16_binary": [_P, _P, _P, _L, _I, _P],
     "ea_gated_residual_bf16": [_P, _P, _P, _P, _I, _L, _I, _L, _P],

@@ -97,6 +97,61 @@ __global__ void cfg_euler_kernel(const void* __restrict__ v, void* __restrict__ 
         reinterpret_cast<float*>(x)[i] = xn;
 }
 
+// ---- guidance_rescale (rescale_noise_cfg, pipeline_easyanimate.py:100-112,1106-1108): the guided prediction is scaled
+// by  r * std(v_text) / std(v_cfg) + (1 - r)  (unbiased std over all elements of the one sample) before the Euler step.
+// Stage 1: per-block partial sums (sum t, sum t^2, sum c, sum c^2), fixed order; stage 2: one thread adds them in fp64;
+// stage 3: the Euler kernel derives the factor from the four sums on the device (no host synchronisation).
+template <bool BF16>
+__global__ __launch_bounds__(256) void cfg_stats_partial_kernel(const void* __restrict__ v, int64_t n, float g,
+                                                                float* __restrict__ partial) {
+    __shared__ float red[4][4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float vu = load_lat<BF16>(v, i), vt = load_lat<BF16>(v, n + i);
+        float c = vu + g * (vt - vu);
+        if (BF16) c = bf16_bits_to_f32(f32_to_bf16_bits(c));
+        s[0] += vt;
+        s[1] += vt * vt;
+        s[2] += c;
+        s[3] += c * c;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s[k] = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) partial[4 * blockIdx.x + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void cfg_stats_final_kernel(const float* __restrict__ partial, int nblk, double* __restrict__ sums) {
+    if (threadIdx.x < 4 && blockIdx.x == 0) {
+        double a = 0.0;
+        for (int i = 0; i < nblk; ++i) a += (double)partial[4 * i + threadIdx.x];
+        sums[threadIdx.x] = a;
+    }
+}
+
+template <bool BF16>
+__global__ void cfg_rescale_euler_kernel(const void* __restrict__ v, void* __restrict__ x, int64_t n, float g, float dsigma,
+                                         float rescale, const double* __restrict__ sums) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dn = (double)n;
+    const double var_t = (sums[1] - sums[0] * sums[0] / dn) / (dn - 1.0);
+    const double var_c = (sums[3] - sums[2] * sums[2] / dn) / (dn - 1.0);
+    const float factor = rescale * (float)sqrt(var_t / var_c) + (1.0f - rescale);
+    const float vu = load_lat<BF16>(v, i), vt = load_lat<BF16>(v, n + i);
+    float c = vu + g * (vt - vu);
+    if (BF16) c = bf16_bits_to_f32(f32_to_bf16_bits(c));
+    const float xn = load_lat<BF16>(x, i) + dsigma * (factor * c);
+    if (BF16)
+        reinterpret_cast<unsigned short*>(x)[i] = f32_to_bf16_bits(xn);
+    else
+        reinterpret_cast<float*>(x)[i] = xn;
+}
+
 }  // namespace
 
 extern "C" int ea_patchify(const void* latents, const void* extra, ea_bf16* cols, int batch, int c_lat, int c_extra,
@@ -140,6 +195,24 @@ extern "C" int ea_cfg_euler_step(const void* v, void* latents, int64_t n, float 
     else
         hipLaunchKernelGGL(cfg_euler_kernel<false>, grid, dim3(256), 0, st, v, latents, n, guidance, dsigma, do_cfg);
     return ea_check_launch("ea_cfg_euler_step");
+}
+
+extern "C" int ea_cfg_rescale_euler_step(const void* v, void* latents, int64_t n, float guidance, float dsigma,
+                                         float guidance_rescale, float* partial, int nblk, double* sums, int is_bf16,
+                                         void* stream) {
+    EA_REQUIRE(v && latents && partial && sums && n > 1 && nblk > 0 && nblk <= 4096, "ea_cfg_rescale_euler_step: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (is_bf16) {
+        hipLaunchKernelGGL(cfg_stats_partial_kernel<true>, dim3(nblk), dim3(256), 0, st, v, n, guidance, partial);
+        hipLaunchKernelGGL(cfg_stats_final_kernel, dim3(1), dim3(64), 0, st, partial, nblk, sums);
+        hipLaunchKernelGGL(cfg_rescale_euler_kernel<true>, grid, dim3(256), 0, st, v, latents, n, guidance, dsigma, guidance_rescale, sums);
+    } else {
+        hipLaunchKernelGGL(cfg_stats_partial_kernel<false>, dim3(nblk), dim3(256), 0, st, v, n, guidance, partial);
+        hipLaunchKernelGGL(cfg_stats_final_kernel, dim3(1), dim3(64), 0, st, partial, nblk, sums);
+        hipLaunchKernelGGL(cfg_rescale_euler_kernel<false>, grid, dim3(256), 0, st, v, latents, n, guidance, dsigma, guidance_rescale, sums);
+    }
+    return ea_check_launch("ea_cfg_rescale_euler_step");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -359,6 +359,19 @@ def cfg_euler_step(v: torch.Tensor, latents: torch.Tensor, guidance: float, dsig
               int(latents.dtype == _BF16), _stream())
 
 
+def cfg_rescale_euler_step(v: torch.Tensor, latents: torch.Tensor, guidance: float, dsigma: float, rescale: float) -> None:
+    """In-place: latents <- latents + dsigma * rescale_noise_cfg(cfg(v), v_text, rescale).  v [2, ...], one sample."""
+    _dev(v, latents)
+    assert v.is_contiguous() and latents.is_contiguous() and v.dtype == latents.dtype
+    n = latents.numel()
+    assert v.numel() == 2 * n and latents.shape[0] == 1, "guidance_rescale: one sample (a CFG pair) per call"
+    nblk = max(1, min(1024, n // 4096))
+    partial = torch.empty(4 * nblk, dtype=_F32, device=v.device)
+    sums = torch.empty(4, dtype=torch.float64, device=v.device)
+    _lib.call("ea_cfg_rescale_euler_step", _p(v), _p(latents), n, float(guidance), float(dsigma), float(rescale), _p(partial),
+              nblk, _p(sums), int(latents.dtype == _BF16), _stream())
+
+
 # ---------------------------------------------------------------------------------------------------
 # VAE ops: channels-last activations [T, H, W, C] bf16 (one sample)
 # ---------------------------------------------------------------------------------------------------

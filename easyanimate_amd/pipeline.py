@@ -171,7 +171,7 @@ class EasyAnimatePipeline:
         return pe
 
     def denoise(self, latents, prompt_embeds, image_rotary_emb, timesteps, guidance_scale, inpaint_latents=None,
-                prompt_embeds_2=None, callback_on_step_end=None):
+                prompt_embeds_2=None, callback_on_step_end=None, guidance_rescale: float = 0.0):
         """The hot loop (reference :1069-1134): CFG duplicate, bf16 timestep, transformer, CFG combine + Euler
         update fused in one kernel.  No host synchronisation inside the loop."""
         do_cfg = guidance_scale > 1
@@ -191,7 +191,8 @@ class EasyAnimatePipeline:
                 noise_pred, _ = noise_pred.chunk(2, dim=1)
                 noise_pred = noise_pred.contiguous()
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False,
-                                          guidance_scale=guidance_scale if do_cfg else None)[0]
+                                          guidance_scale=guidance_scale if do_cfg else None,
+                                          guidance_rescale=guidance_rescale if do_cfg else 0.0)[0]
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": latents})
                 latents = out.pop("latents", latents) if out else latents
@@ -208,11 +209,12 @@ class EasyAnimatePipeline:
                  callback_on_step_end: Optional[Callable] = None, callback_on_step_end_tensor_inputs: List[str] = ["latents"],
                  guidance_rescale: float = 0.0, original_size=None, target_size=None, crops_coords_top_left=(0, 0),
                  clip_image=None, clip_apply_ratio=0.40, comfyui_progressbar=False, timesteps=None):
-        if guidance_rescale != 0.0:
-            raise NotImplementedError("guidance_rescale > 0")
+        if num_images_per_prompt != 1:
+            raise NotImplementedError("num_images_per_prompt > 1 (one video per call)")
         height = int(height // 16 * 16)
         width = int(width // 16 * 16)
         self._guidance_scale = guidance_scale
+        self._guidance_rescale = guidance_rescale
         self._interrupt = False
         device = self.transformer.device
         dtype = self.transformer.dtype
@@ -223,8 +225,17 @@ class EasyAnimatePipeline:
         latents = self.prepare_latents(1 * num_images_per_prompt, nc, video_length, height, width, dtype, device,
                                        generator, latents)
         rope = self.rotary_embedding(height, width, latents.size(2))
-        latents = self.denoise(latents, pe, rope, timesteps, guidance_scale, callback_on_step_end=callback_on_step_end)
-        if output_type == "latent" and self.vae is None:
+        pe2 = None
+        if prompt_embeds_2 is not None:   # V5 two-encoder checkpoints (text_proj_t5)
+            pe2 = self._embeds(prompt_embeds_2, negative_prompt_embeds_2, device, dtype)
+        latents = self.denoise(latents, pe, rope, timesteps, guidance_scale, prompt_embeds_2=pe2,
+                               callback_on_step_end=callback_on_step_end, guidance_rescale=guidance_rescale)
+        return self._output(latents, output_type, return_dict)
+
+    def _output(self, latents, output_type, return_dict):
+        """reference :1136-1149 (both pipelines): always decode; output_type "latent" means "a torch tensor" (of the decoded
+        video), anything else the numpy array.  Without a VAE (benchmarks / tests of the loop alone) the latents come back."""
+        if self.vae is None:
             video = latents
         else:
             video = self.decode_latents(latents)
@@ -235,14 +246,47 @@ class EasyAnimatePipeline:
         return EasyAnimatePipelineOutput(frames=video)
 
 
-class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
-    """I2V / inpaint variant (reference: pipeline_easyanimate_inpaint.py:978-1606): VAE-encode the masked video,
-    resize the mask to latent resolution, feed cat[mask(1), masked_latents(16)] as `inpaint_latents`."""
+def add_noise_to_reference_video(image, ratio=None, generator=None):
+    """reference: pipeline_easyanimate_inpaint.py:153-167 (noise augmentation of the conditioning video, pixels that are
+    exactly -1 -- the masked ones -- stay untouched).  Input preparation on the conditioning video, like randn_tensor."""
+    if ratio is None:
+        sigma = torch.exp(torch.normal(mean=-3.0, std=0.5, size=(image.shape[0],)).to(image.device)).to(image.dtype)
+    else:
+        sigma = torch.ones((image.shape[0],)).to(image.device, image.dtype) * ratio
+    if generator is not None:
+        noise = torch.randn(image.size(), generator=generator, dtype=image.dtype, device=generator.device).to(image.device)
+    else:
+        noise = torch.randn_like(image)
+    noise = noise * sigma[:, None, None, None, None]
+    noise = torch.where(image == -1, torch.zeros_like(image), noise)
+    return image + noise
 
-    def prepare_mask_latents(self, mask_video, masked_video, dtype, device):
-        """reference: :769-826 (.mode() * scaling_factor)"""
-        lat = self.vae.encode(masked_video.to(device=device, dtype=self.vae.dtype))[0].mode()
+
+class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
+    """I2V / inpaint / V2V variant (reference: pipeline_easyanimate_inpaint.py:978-1606): VAE-encode the masked video,
+    bring the mask to latent resolution, feed cat[mask, masked_latents] as `inpaint_latents` (1 + 16 channels with
+    resize_inpaint_mask_directly, 16 + 16 with the VAE-encoded mask)."""
+
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, text_encoder_2=None, tokenizer_2=None, transformer=None,
+                 scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None, clip_image_encoder=None, clip_image_processor=None):
+        super().__init__(vae, text_encoder, tokenizer, text_encoder_2, tokenizer_2, transformer, scheduler)
+        self.clip_image_encoder, self.clip_image_processor = clip_image_encoder, clip_image_processor
+
+    def _encode(self, x, dtype, device):
+        """.mode() * scaling_factor of the VAE posterior (:777-789, :797-810, :868-878)"""
+        lat = self.vae.encode(x.to(device=device, dtype=self.vae.dtype))[0].mode()
         return lat.to(dtype) * self.vae.config.scaling_factor
+
+    def prepare_mask_latents(self, mask, masked_image, dtype, device, generator=None, noise_aug_strength=None):
+        """reference: :769-826 -> (mask latents or None, masked-video latents or None)"""
+        mask_lat = self._encode(mask, dtype, device) if mask is not None else None
+        masked_lat = None
+        if masked_image is not None:
+            masked_image = masked_image.to(device=device, dtype=dtype)
+            if self.transformer.config.get("add_noise_in_inpaint_model", False):
+                masked_image = add_noise_to_reference_video(masked_image, ratio=noise_aug_strength, generator=generator)
+            masked_lat = self._encode(masked_image, dtype, device)
+        return mask_lat, masked_lat
 
     @staticmethod
     def masked_video_and_mask(video: torch.Tensor, mask_video: torch.Tensor):
@@ -255,44 +299,87 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
         masked_video = init_video * (tile < 0.5) + torch.ones_like(init_video) * (tile > 0.5) * -1
         return masked_video, mask_condition
 
-    def inpaint_conditioning(self, video, mask_video, dtype, device, do_cfg=True):
-        """reference: pipeline_easyanimate_inpaint.py:1321-1383 with resize_inpaint_mask_directly=True (V5.1 yaml):
-        inpaint_latents = cat[ resize_mask(1 - mask) * s , VAE.encode(masked_video).mode() * s ]  (1 + 16 channels)."""
-        if not self.transformer.resize_inpaint_mask_directly:
-            raise NotImplementedError("resize_inpaint_mask_directly=False (mask encoded by the VAE) is not built")
-        masked_video, mask_condition = self.masked_video_and_mask(video.cpu(), mask_video.cpu())
-        masked_latents = self.prepare_mask_latents(None, masked_video, dtype, device)
-        mask_latents = resize_mask(1 - mask_condition, masked_latents, getattr(self.vae, "cache_mag_vae", True))
-        mask_latents = mask_latents.to(device, dtype) * self.vae.config.scaling_factor
+    def inpaint_conditioning(self, video, mask_video, dtype, device, do_cfg=True, latent_shape=None, generator=None,
+                             noise_aug_strength=0.0563, masked_video_latents=None):
+        """reference: pipeline_easyanimate_inpaint.py:1321-1383."""
+        direct = self.transformer.resize_inpaint_mask_directly
+        if mask_video is None or (self.transformer.config.get("enable_zero_in_inpaint", True) and bool((mask_video == 255).all())):
+            # nothing is kept from the input video (plain T2V through an InP checkpoint): zero conditioning (:1322-1336)
+            shp = tuple(latent_shape)
+            mask_latents = torch.zeros((shp[0], 1 if direct else shp[1]) + shp[2:], dtype=dtype, device=device)
+            masked_latents = torch.zeros(shp, dtype=dtype, device=device)
+        else:
+            masked_video, mask_condition = self.masked_video_and_mask(video.cpu(), mask_video.cpu())
+            if masked_video_latents is not None:
+                masked_video = masked_video_latents
+            if direct:
+                _, masked_latents = self.prepare_mask_latents(None, masked_video, dtype, device, generator, noise_aug_strength)
+                mask_latents = resize_mask(1 - mask_condition, masked_latents, getattr(self.vae, "cache_mag_vae", True))
+                mask_latents = mask_latents.to(device, dtype) * self.vae.config.scaling_factor
+            else:
+                mask_latents, masked_latents = self.prepare_mask_latents(torch.tile(mask_condition, [1, 3, 1, 1, 1]), masked_video,
+                                                                         dtype, device, generator, noise_aug_strength)
         inpaint = torch.cat([mask_latents, masked_latents], dim=1).to(dtype)
         return torch.cat([inpaint] * 2) if do_cfg else inpaint
 
+    def get_timesteps(self, num_inference_steps, strength, device):
+        """reference: :760-767"""
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        return self.scheduler.timesteps[t_start * self.scheduler.order:], num_inference_steps - t_start
+
     @torch.no_grad()
     def __call__(self, prompt=None, video_length=None, video=None, mask_video=None, masked_video_latents=None,
-                 height=None, width=None, num_inference_steps: int = 50, guidance_scale: float = 5.0, generator=None,
-                 latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "latent",
-                 return_dict: bool = True, strength: float = 1.0, timesteps=None, **unused):
-        if strength != 1.0:
-            raise NotImplementedError("strength < 1 (V2V re-noising)")
+                 height=None, width=None, num_inference_steps: int = 50, guidance_scale: float = 5.0, negative_prompt=None,
+                 num_images_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None, prompt_embeds=None,
+                 prompt_embeds_2=None, negative_prompt_embeds=None, negative_prompt_embeds_2=None, prompt_attention_mask=None,
+                 prompt_attention_mask_2=None, negative_prompt_attention_mask=None, negative_prompt_attention_mask_2=None,
+                 output_type: str = "latent", return_dict: bool = True, callback_on_step_end: Optional[Callable] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], guidance_rescale: float = 0.0,
+                 original_size=(1024, 1024), target_size=None, crops_coords_top_left=(0, 0), clip_image=None,
+                 clip_apply_ratio=0.40, strength: float = 1.0, noise_aug_strength: float = 0.0563, comfyui_progressbar=False,
+                 timesteps=None):
+        if num_images_per_prompt != 1:
+            raise NotImplementedError("num_images_per_prompt > 1 (one video per call)")
+        if clip_image is not None and self.transformer.config.get("enable_clip_in_inpaint", True) and self.clip_image_encoder is not None:
+            raise NotImplementedError("the CLIP image encoder is a transformers model outside this build's scope; the V5.1 YAML sets "
+                                      "enable_clip_in_inpaint: false")
         height = int(height // 16 * 16)
         width = int(width // 16 * 16)
         self._guidance_scale = guidance_scale
+        self._guidance_rescale = guidance_rescale
         self._interrupt = False
         device = self.transformer.device
         dtype = self.transformer.dtype
         pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype)
+        pe2 = self._embeds(prompt_embeds_2, negative_prompt_embeds_2, device, dtype) if prompt_embeds_2 is not None else None
         timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, mu=1)
+        timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
+        self._num_timesteps = len(timesteps)
+        if video is not None:
+            video_length = video.shape[2]
         nc = self.vae.config.latent_channels if self.vae is not None else 16
-        latents = self.prepare_latents(1, nc, video_length, height, width, dtype, device, generator, latents)
-        rope = self.rotary_embedding(height, width, latents.size(2))
-        if video is not None and mask_video is not None:
-            inpaint = self.inpaint_conditioning(video, mask_video, dtype, device, self.do_classifier_free_guidance)
+        noise_or_latents = self.prepare_latents(1, nc, video_length, height, width, dtype, device, generator, latents)
+        if strength < 1.0 and latents is None:
+            # V2V re-noising (:862-893): start from the encoded input video at the first kept timestep
+            if video is None:
+                raise ValueError("strength < 1 needs `video`")
+            video_latents = self._encode(video.to(torch.float32) * 2.0 - 1.0, dtype, device)
+            latents = self.scheduler.scale_noise(video_latents, timesteps[:1], noise_or_latents)
         else:
-            n_extra = self.transformer.config.in_channels - nc
-            inpaint = torch.zeros((2 if self.do_classifier_free_guidance else 1, n_extra) + tuple(latents.shape[2:]),
-                                  dtype=dtype, device=device)
-        latents = self.denoise(latents, pe, rope, timesteps, guidance_scale, inpaint_latents=inpaint)
-        video_out = latents if (output_type == "latent" and self.vae is None) else self.decode_latents(latents)
-        if not return_dict:
-            return video_out
-        return EasyAnimatePipelineOutput(frames=video_out)
+            latents = noise_or_latents
+        rope = self.rotary_embedding(height, width, latents.size(2))
+        inpaint = None
+        if self.transformer.config.in_channels != nc:
+            inpaint = self.inpaint_conditioning(video, mask_video, dtype, device, self.do_classifier_free_guidance,
+                                                latent_shape=latents.shape, generator=generator,
+                                                noise_aug_strength=noise_aug_strength, masked_video_latents=masked_video_latents)
+            if inpaint.shape[1] + nc != self.transformer.config.in_channels:
+                raise ValueError(f"the transformer expects {self.transformer.config.in_channels} input channels, latents + "
+                                 f"inpaint conditioning give {nc + inpaint.shape[1]} (resize_inpaint_mask_directly mismatch?)")
+        elif video is not None and mask_video is not None:
+            raise NotImplementedError("latent-space blending for a T2V checkpoint inside the inpaint pipeline (the reference's own "
+                                      "branch, :1562-1575, does not run: scale_noise is called with a mis-placed parenthesis)")
+        latents = self.denoise(latents, pe, rope, timesteps, guidance_scale, inpaint_latents=inpaint, prompt_embeds_2=pe2,
+                               callback_on_step_end=callback_on_step_end, guidance_rescale=guidance_rescale)
+        return self._output(latents, output_type, return_dict)

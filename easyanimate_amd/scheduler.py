@@ -108,16 +108,20 @@ class FlowMatchEulerDiscreteScheduler(ConfigMixin):
         return sig * noise + (1.0 - sig) * sample
 
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, generator=None, return_dict: bool = True,
-             guidance_scale: Optional[float] = None, **unused):
+             guidance_scale: Optional[float] = None, guidance_rescale: float = 0.0, **unused):
         """x_prev = float(x) + (sigma_next - sigma) * v, cast to v.dtype.  If `guidance_scale` is given,
-        model_output holds the [uncond, text] pair and the CFG combine is fused into the same kernel."""
+        model_output holds the [uncond, text] pair and the CFG combine (and, with guidance_rescale > 0, rescale_noise_cfg)
+        is fused into the same launch sequence."""
         from . import ops
         if self._step_index is None:
             self._init_step_index(timestep)
         ds = self.dsigma()
         v = model_output.contiguous()
         prev = sample.to(v.dtype).contiguous().clone()
-        ops.cfg_euler_step(v, prev, guidance_scale if guidance_scale is not None else 0.0, ds,
-                           guidance_scale is not None)
+        if guidance_scale is not None and guidance_rescale > 0.0:
+            ops.cfg_rescale_euler_step(v, prev, guidance_scale, ds, guidance_rescale)
+        else:
+            ops.cfg_euler_step(v, prev, guidance_scale if guidance_scale is not None else 0.0, ds,
+                               guidance_scale is not None)
         self._step_index += 1
         return (prev,) if not return_dict else FrozenDict(prev_sample=prev)

@@ -193,6 +193,13 @@ int ea_unpatchify(const ea_bf16* tokens, void* out, int batch, int channels, int
 int ea_cfg_euler_step(const void* v, void* latents, int64_t n, float guidance, float dsigma, int do_cfg,
                       int is_bf16, void* stream);
 
+/* The same step with guidance_rescale > 0 (rescale_noise_cfg, pipeline_easyanimate.py:100-112,1106-1108):
+ *   v_cfg = v_uncond + g*(v_text - v_uncond);  v = v_cfg * (r * std(v_text)/std(v_cfg) + 1 - r);  x <- x + dsigma * v
+ * with the unbiased standard deviations over the n elements of the (single) sample, reduced on the device in a fixed
+ * order (partial: fp32 workspace of 4*nblk floats; sums: 4 doubles; nothing is read back to the host). */
+int ea_cfg_rescale_euler_step(const void* v, void* latents, int64_t n, float guidance, float dsigma,
+                              float guidance_rescale, float* partial, int nblk, double* sums, int is_bf16, void* stream);
+
 /* ---- VAE (AutoencoderKLMagvit), channels-last (NDHWC) activations of ONE sample -------------------- */
 
 /* ---- TeaCache (transformer3d.py:90-121, 1564-1590, 1635) -------------------------------------- */

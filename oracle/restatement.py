@@ -337,17 +337,30 @@ def euler_step(v, x, sigma, sigma_next):
     return (x.to(torch.float32) + (sigma_next - sigma) * v).to(v.dtype)
 
 
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """pipeline_easyanimate.py:100-112"""
+    std_text = noise_pred_text.std(dim=list(range(1, noise_pred_text.ndim)), keepdim=True)
+    std_cfg = noise_cfg.std(dim=list(range(1, noise_cfg.ndim)), keepdim=True)
+    return guidance_rescale * (noise_cfg * (std_text / std_cfg)) + (1 - guidance_rescale) * noise_cfg
+
+
 def denoise_loop(sd: SD, cfg: dict, latents, enc_neg_pos, rope, num_steps: int, guidance_scale: float,
-                 inpaint_latents=None, shift: float = 1.0, return_all: bool = False, teacache=None):
-    """EasyAnimatePipeline.__call__ hot loop, pipeline_easyanimate.py:1069-1111 (CFG on, guidance_rescale 0)."""
+                 inpaint_latents=None, shift: float = 1.0, return_all: bool = False, teacache=None,
+                 guidance_rescale: float = 0.0, first_step: int = 0):
+    """EasyAnimatePipeline.__call__ hot loop, pipeline_easyanimate.py:1069-1111 (CFG on).  first_step > 0 runs the tail of
+    the schedule only (the strength < 1 path of the inpaint pipeline, pipeline_easyanimate_inpaint.py:760-767)."""
     timesteps, sigmas = flow_sigmas(num_steps, shift=shift)
     trace = []
     for i, t in enumerate(timesteps):
+        if i < first_step:
+            continue
         lat_in = torch.cat([latents] * 2)
         t_expand = torch.tensor([t] * lat_in.shape[0]).to(dtype=lat_in.dtype)
         v = transformer_forward(sd, cfg, lat_in, t_expand, enc_neg_pos, rope, inpaint_latents, teacache=teacache)
         vu, vt = v.chunk(2)
         v = vu + guidance_scale * (vt - vu)
+        if guidance_rescale > 0.0:                      # :1106-1108
+            v = rescale_noise_cfg(v, vt, guidance_rescale)
         latents = euler_step(v, latents, sigmas[i], sigmas[i + 1])
         if return_all:
             trace.append(latents.clone())

@@ -108,3 +108,116 @@ def test_i2v_pipeline_end_to_end():
     assert cm < 1e-4
     mse, mx = _report("i2v pipeline 9f x 64^2, 3 steps, CFG 6", frames, ref)
     assert mse < 2e-4
+
+
+# ---- the remaining branches of the two pipelines (VERDICT r1 "missing" 7) ---------------------------------
+def test_guidance_rescale_kernel_and_loop():
+    """rescale_noise_cfg (pipeline_easyanimate.py:100-112,1106-1108): the fused device reduction + step against fp64, and
+    the whole loop with guidance_rescale = 0.7 against the oracle loop."""
+    from easyanimate_amd import EasyAnimatePipeline, FlowMatchEulerDiscreteScheduler, ops
+    from oracle import restatement as R
+    g = torch.Generator().manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        v = torch.randn(2, 16, 3, 16, 24, generator=g).to(dt)
+        x = torch.randn(1, 16, 3, 16, 24, generator=g).to(dt)
+        vd, xd = v.double(), x.double()
+        cfg = vd[0:1] + 6.0 * (vd[1:2] - vd[0:1])
+        if dt == torch.bfloat16:
+            cfg = cfg.to(dt).double()
+        ref = xd + (-0.25) * R.rescale_noise_cfg(cfg, vd[1:2], 0.7)
+        xg = x.to(DEV).contiguous()
+        ops.cfg_rescale_euler_step(v.to(DEV).contiguous(), xg, 6.0, -0.25, 0.7)
+        err = (xg.double().cpu() - ref).abs().max().item()
+        print(f"[parity] cfg_rescale_euler_step {dt}: max abs err {err:.3e}")
+        assert err < (2e-2 if dt == torch.bfloat16 else 2e-5)
+    m, vae, sd_t, sd_v, cfg_t, cfg_v = _models(16)
+    pipe = EasyAnimatePipeline(vae=None, transformer=m, scheduler=FlowMatchEulerDiscreteScheduler(shift=1.0))
+    latents = torch.randn(1, 16, 3, 8, 8, generator=g).bfloat16().float()
+    enc = torch.randn(2, 7, cfg_t["text_embed_dim"], generator=g).bfloat16().float()
+    out = pipe(video_length=9, height=64, width=64, num_inference_steps=6, guidance_scale=6.0, guidance_rescale=0.7,
+               latents=latents.clone(), prompt_embeds=enc[1:2], negative_prompt_embeds=enc[0:1]).frames
+    rope = tuple(t.cpu() for t in pipe.rotary_embedding(64, 64, 3))
+    with torch.no_grad():
+        ref = R.denoise_loop(sd_t, cfg_t, latents, enc, rope, 6, 6.0, guidance_rescale=0.7)
+        ref0 = R.denoise_loop(sd_t, cfg_t, latents, enc, rope, 6, 6.0)
+    mse = ((out.float().cpu() - ref) ** 2).mean().item()
+    print(f"[parity] 6-step loop with guidance_rescale 0.7: latent MSE vs oracle {mse:.3e} (the rescale moves the result by "
+          f"{((ref - ref0) ** 2).mean().item():.3e})")
+    assert mse < 1e-4 and ((ref - ref0) ** 2).mean().item() > 10 * mse
+
+
+def test_inpaint_pipeline_branches():
+    """EasyAnimateInpaintPipeline: the all-255 mask zero-latent shortcut (:1322-1336), add_noise_in_inpaint_model
+    (:153-167,799), the VAE-encoded mask of resize_inpaint_mask_directly=False (:1364-1377), strength < 1 (:760-767,
+    :862-893), callbacks and the output_type convention (:1592-1606)."""
+    from easyanimate_amd import EasyAnimateInpaintPipeline, FlowMatchEulerDiscreteScheduler
+    from easyanimate_amd.pipeline import add_noise_to_reference_video, get_image_to_video_latent
+    from oracle import restatement as R
+    from oracle import restatement_vae as RV
+    m, vae, sd_t, sd_v, cfg_t, cfg_v = _models(33)
+    m.resize_inpaint_mask_directly = True
+    pipe = EasyAnimateInpaintPipeline(vae=vae, transformer=m, scheduler=FlowMatchEulerDiscreteScheduler(shift=1.0))
+    g = torch.Generator().manual_seed(29)
+    F_, H, W = 9, 64, 64
+    s = vae.config.scaling_factor
+    video, mask = get_image_to_video_latent(torch.rand(3, H, W, generator=g), F_)
+    # 1. all-255 mask (T2V through an InP checkpoint): zero conditioning, no VAE call
+    c0 = pipe.inpaint_conditioning(video, torch.full_like(mask, 255.0), torch.bfloat16, DEV, True, latent_shape=(1, 16, 3, 8, 8))
+    assert c0.shape == (2, 17, 3, 8, 8) and c0.abs().max().item() == 0
+    c1 = pipe.inpaint_conditioning(None, None, torch.bfloat16, DEV, False, latent_shape=(1, 16, 3, 8, 8))
+    assert c1.shape == (1, 17, 3, 8, 8) and c1.abs().max().item() == 0
+    # 2. noise augmentation: same generator -> same noise as the reference formula; masked (-1) pixels untouched
+    masked_video, mask_c = EasyAnimateInpaintPipeline.masked_video_and_mask(video, mask)
+    aug = add_noise_to_reference_video(masked_video, ratio=0.0563, generator=torch.Generator().manual_seed(5))
+    noise = torch.randn(masked_video.size(), generator=torch.Generator().manual_seed(5)) * 0.0563
+    assert torch.equal(aug, masked_video + torch.where(masked_video == -1, torch.zeros_like(noise), noise))
+    assert torch.equal(aug[:, :, 1:], masked_video[:, :, 1:]) and not torch.equal(aug[:, :, 0], masked_video[:, :, 0])
+    object.__setattr__(m, "_internal_dict", type(m.config)(dict(m.config, add_noise_in_inpaint_model=True)))
+    c_aug = pipe.inpaint_conditioning(video, mask, torch.bfloat16, DEV, False, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        ref_aug = RV.vae_encode_moments(sd_v, aug.bfloat16().float(), cfg_v["norm_num_groups"])[:, :16] * s
+    mse = ((c_aug[:, 1:].float().cpu() - ref_aug) ** 2).mean().item()
+    print(f"[parity] add_noise_in_inpaint_model: masked-video latents MSE vs oracle {mse:.3e}")
+    assert mse < 1e-4
+    object.__setattr__(m, "_internal_dict", type(m.config)(dict(m.config, add_noise_in_inpaint_model=False)))
+    # 3. resize_inpaint_mask_directly = False: the (tiled, binarised) mask goes through the VAE: 16 + 16 channels
+    m.resize_inpaint_mask_directly = False
+    c2 = pipe.inpaint_conditioning(video, mask, torch.bfloat16, DEV, False)
+    with torch.no_grad():
+        ref_m = RV.vae_encode_moments(sd_v, torch.tile(mask_c, [1, 3, 1, 1, 1]), cfg_v["norm_num_groups"])[:, :16] * s
+        ref_v = RV.vae_encode_moments(sd_v, masked_video.bfloat16().float(), cfg_v["norm_num_groups"])[:, :16] * s
+    assert c2.shape == (1, 32, 3, 8, 8)
+    mse = ((c2.float().cpu() - torch.cat([ref_m, ref_v], 1)) ** 2).mean().item()
+    print(f"[parity] VAE-encoded mask conditioning (resize_inpaint_mask_directly=False): MSE vs oracle {mse:.3e}")
+    assert mse < 1e-4
+    with pytest.raises(ValueError, match="input channels"):   # 16 + 32 != 33
+        pipe(video_length=F_, video=video, mask_video=mask, height=H, width=W, num_inference_steps=2, guidance_scale=6.0,
+             prompt_embeds=torch.zeros(1, 7, cfg_t["text_embed_dim"]), negative_prompt_embeds=torch.zeros(1, 7, cfg_t["text_embed_dim"]))
+    m.resize_inpaint_mask_directly = True
+    # 4. strength 0.5: the last half of the schedule, starting from scale_noise(encoded video, t_start, noise)
+    pos = torch.randn(1, 7, cfg_t["text_embed_dim"], generator=g).bfloat16().float()
+    neg = torch.randn(1, 7, cfg_t["text_embed_dim"], generator=g).bfloat16().float()
+    seen = []
+    vae_keep, pipe.vae = pipe.vae, vae
+    out = pipe(video_length=F_, video=video, mask_video=mask, height=H, width=W, num_inference_steps=6, guidance_scale=6.0, strength=0.5,
+               generator=torch.Generator().manual_seed(41), prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent",
+               callback_on_step_end=lambda p, i, t, kw: seen.append((i, float(t), kw["latents"].float().cpu())) or {})
+    assert isinstance(out.frames, torch.Tensor) and out.frames.shape == (1, 3, F_, H, W)     # "latent" = a tensor of the decoded video
+    assert [i for i, _, _ in seen] == [0, 1, 2] and pipe.num_timesteps == 3
+    ts, sig = R.flow_sigmas(6)
+    assert [round(t, 3) for _, t, _ in seen] == [round(float(x), 3) for x in ts[3:]]
+    noise = torch.randn((1, 16, 3, 8, 8), generator=torch.Generator().manual_seed(41), dtype=torch.bfloat16).float()
+    with torch.no_grad():
+        vlat = (RV.vae_encode_moments(sd_v, (video * 2 - 1).bfloat16().float(), cfg_v["norm_num_groups"])[:, :16] * s)
+        x0 = (sig[3] * noise + (1 - sig[3]) * vlat).bfloat16().float()
+        inp = torch.cat([torch.cat([pipe_resize(1 - mask_c, vlat) * s, ref_v], 1)] * 2).bfloat16().float()
+        rope = tuple(t.cpu() for t in pipe.rotary_embedding(H, W, 3))
+        ref = R.denoise_loop(sd_t, cfg_t, x0, torch.cat([neg, pos]), rope, 6, 6.0, inpaint_latents=inp, first_step=3)
+    mse = ((seen[-1][2] - ref) ** 2).mean().item()
+    print(f"[parity] strength 0.5 (V2V re-noising, 3 of 6 steps): final latent MSE vs oracle {mse:.3e}")
+    assert mse < 2e-4
+
+
+def pipe_resize(mask, latent):
+    from easyanimate_amd.pipeline import resize_mask
+    return resize_mask(mask, latent, True)
