@@ -41,6 +41,9 @@ PROTOTYPES = {
     "ea_bf16_binary": [_P, _P, _P, _L, _I, _P],
     "ea_gated_residual_bf16": [_P, _P, _P, _P, _I, _L, _I, _L, _P],
     "ea_conv3d_cl_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ea_conv3d_cl_stats_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
+    "ea_groupnorm_finalize_bf16": [_P, _P, _I, _L, _I, _I, _I, _F, _P],
+    "ea_conv3d_tap_gather_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ea_im2col3d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_groupnorm_stats_bf16": [_P, _P, _P, _I, _L, _I, _I, _I, _F, _P],
     "ea_groupnorm_apply_bf16": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P],

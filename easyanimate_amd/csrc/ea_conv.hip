@@ -35,6 +35,8 @@ struct ConvArgs {
     int kt, kh, kw, st, ss, pad, ups, tdup;
     int tiles_m, tiles_n;
     int64_t M;
+    float* gn_partial;   // optional (row-slab 16x16x32 kernel): per-(frame, row tile, wave row, 4-channel bundle) (sum, sumsq)
+    int gn_nblk;         // partial blocks per output frame = (H_out * W_out / 256) * (waves along M)
 };
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
@@ -881,6 +883,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
 
     // ---- epilogue: lane owns voxel m (one per M tile), channels n0 .. n0+3 of every N tile
     const int64_t frame = (int64_t)p.H_out * p.W_out;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int64_t m = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + i * 16 + lr;
@@ -912,6 +915,34 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
             *reinterpret_cast<bf16x4*>(p.y + m_dst0 * p.C_out + n0) = o;
             if (m_dst1 >= 0) *reinterpret_cast<bf16x4*>(p.y + m_dst1 * p.C_out + n0) = o;
+            if (p.gn_partial) {   // GroupNorm statistics of the NEXT layer, over the values it will read (the rounded ones)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = (float)o[e];
+                    gs[j] += r;
+                    gq[j] += r * r;
+                }
+            }
+        }
+    }
+    if (p.gn_partial) {
+        // lanes lr = 0..15 hold the 16 voxels of every M tile: fixed-order butterfly over them, then one (sum, sumsq) pair
+        // per 4-channel bundle and wave -- the layout ea_groupnorm_finalize_bf16 reads (deterministic, no atomics)
+        const int64_t blk = ((int64_t)t_out * (p.gn_nblk / WM) + ((int64_t)h_out * tiles_w + (tm % tiles_w))) * WM + wr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s_ = gs[j], q_ = gq[j];
+#pragma unroll
+            for (int o_ = 1; o_ < 16; o_ <<= 1) {
+                s_ += __shfl_xor(s_, o_, 64);
+                q_ += __shfl_xor(q_, o_, 64);
+            }
+            const int n0 = col0 + wc * 64 + j * 16 + lq * 4;
+            if (lr == 0 && n0 < p.C_out) {
+                float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
+                dst[0] = s_;
+                dst[1] = q_;
+            }
         }
     }
 }
@@ -959,9 +990,11 @@ int ea_conv_tile_set(int v) {
 
 static int conv_out_dim(int in, int k, int s, int pad_lo, int pad_hi) { return (in + pad_lo + pad_hi - k) / s + 1; }
 
-extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
-                                 const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
-                                 int kw, int st, int ss, int pad, int ups, int tdup, void* stream) {
+static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
+                          const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
+                          int kw, int st, int ss, int pad, int ups, int tdup, float* gn_partial, int64_t gn_capacity,
+                          int* gn_nblk_out, void* stream) {
+    if (gn_nblk_out) *gn_nblk_out = 0;
     EA_REQUIRE(x && w && y && zeros, "ea_conv3d_cl_bf16: null tensor");
     EA_REQUIRE(C_in > 0 && C_in % BK == 0, "ea_conv3d_cl_bf16: C_in=%d must be a multiple of 64 (use ea_im2col3d_bf16 + ea_gemm_bf16)", C_in);
     EA_REQUIRE(C_out > 0 && C_out % 8 == 0, "ea_conv3d_cl_bf16: C_out must be a multiple of 8");
@@ -972,6 +1005,7 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
     EA_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)res | (uintptr_t)bias | (uintptr_t)zeros) & 15) == 0,
                "ea_conv3d_cl_bf16: pointers must be 16-byte aligned");
     ConvArgs p;
+    p.gn_partial = nullptr; p.gn_nblk = 0;
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y; p.zeros = zeros;
     p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.C_in = C_in; p.C_out = C_out;
     p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.ss = ss; p.pad = pad; p.ups = ups; p.tdup = tdup;
@@ -1009,6 +1043,17 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
             attr3_done = true;
         }
         const dim3 g3((unsigned)grid3), b3(512);
+        if (g_conv_mfma == 16 && gn_partial && !tdup) {
+            // fused GroupNorm statistics: one (sum, sumsq) pair per (frame, row tile, wave row, 4-channel bundle)
+            const int wm = 8 / (bn / 64);
+            const int64_t nblk = (int64_t)p.H_out * (p.W_out / 256) * wm;
+            const int64_t need = (int64_t)p.T_out * nblk * (C_out / 4) * 2;
+            if (need <= gn_capacity && nblk < (1 << 30) && ((uintptr_t)gn_partial & 7) == 0) {
+                p.gn_partial = gn_partial;
+                p.gn_nblk = (int)nblk;
+                if (gn_nblk_out) *gn_nblk_out = (int)nblk;
+            }
+        }
         if (g_conv_mfma == 16) {
             static bool attr4_done = false;
             if (!attr4_done) {
@@ -1078,6 +1123,21 @@ extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float
     ea_count("conv_128x128");
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)grid), dim3(256), CONV_LDS, (hipStream_t)stream, p);
     return ea_check_launch("ea_conv3d_cl_bf16");
+}
+
+extern "C" int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
+                                 const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
+                                 int kw, int st, int ss, int pad, int ups, int tdup, void* stream) {
+    return conv3d_cl_impl(x, w, bias, res, y, zeros, T_in, H_in, W_in, C_in, C_out, kt, kh, kw, st, ss, pad, ups, tdup, nullptr, 0,
+                          nullptr, stream);
+}
+
+extern "C" int ea_conv3d_cl_stats_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
+                                       const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt,
+                                       int kh, int kw, int st, int ss, int pad, int ups, int tdup, float* gn_partial,
+                                       int64_t gn_capacity_floats, int* gn_nblk_out, void* stream) {
+    return conv3d_cl_impl(x, w, bias, res, y, zeros, T_in, H_in, W_in, C_in, C_out, kt, kh, kw, st, ss, pad, ups, tdup, gn_partial,
+                          gn_capacity_floats, gn_nblk_out, stream);
 }
 
 extern "C" int ea_im2col3d_bf16(const ea_bf16* x, ea_bf16* cols, int T_in, int H_in, int W_in, int C_in, int kt, int kh,

@@ -69,6 +69,41 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __r
     stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// The same for the many small partial blocks a convolution epilogue writes (ea_conv3d_cl_stats_bf16: nblk is in the
+// thousands): one workgroup per (t, g); thread i adds blocks i, i + 256, ... in that order (fp64), then a fixed tree.
+__global__ __launch_bounds__(256) void gn_finalize_wide_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                               int groups, int C, int nblk, int64_t hw, float eps) {
+    __shared__ double rs[256], rq[256];
+    const int t = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups, bundles = cpg >> 2;
+    double s = 0.0, q = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const float* src = partial + (((int64_t)t * nblk + b) * (C >> 2) + g * bundles) * 2;
+        for (int u = 0; u < bundles; ++u) {
+            s += src[u * 2];
+            q += src[u * 2 + 1];
+        }
+    }
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            rs[threadIdx.x] += rs[threadIdx.x + o];
+            rq[threadIdx.x] += rq[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)hw * cpg;
+        const double mean = rs[0] / n;
+        double var = rq[0] / n - mean * mean;
+        var = var < 0 ? 0 : var;
+        stats[blockIdx.x * 2] = (float)mean;
+        stats[blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // y = act((x - mean) * rstd * gamma + beta), act 1 = SiLU
 __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -237,6 +272,50 @@ __global__ void ndhwc_to_ncdhw_kernel(const unsigned short* __restrict__ src, vo
     else reinterpret_cast<float*>(dst)[i] = f;
 }
 
+// ---- narrow-N 3x3x3 convolution, second half (decoder conv_out 128 -> 3) ---------------------------------------
+// A 3x3x3 convolution with C_out <= 8 wastes a 128-wide MFMA tile on 3 columns.  It is split instead into
+//   (1) ONE plain GEMM over the input voxels: z[v, tap*C_out + co] = sum_ci x[v, ci] * w[co, ci, tap]  (27*C_out columns,
+//       K = C_in: 27x fewer MFMA flops than the tile-per-tap form, HBM-bound), fp32 out;
+//   (2) this kernel: y[v, co] = bias[co] + sum_tap z[v + offset(tap), tap*C_out + co] with the causal replicate padding
+//       in time (frame index clamped at 0) and zero padding in space -- every z element is consumed exactly once.
+// One thread per output voxel; neighbouring threads read neighbouring z rows, the (dh, dw) reuse stays in L1 / L2.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_tap_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                              unsigned short* __restrict__ y, int T, int H, int W, int ld,
+                                                              int c_pad) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)T * H * W;
+    if (v >= total) return;
+    const int w = (int)(v % W);
+    const int h = (int)((v / W) % H);
+    const int t = (int)(v / ((int64_t)W * H));
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        int ti = t + dt - 2;
+        ti = ti < 0 ? 0 : ti;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hh = h + dh - 1;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int ww = w + dw - 1;
+                if (ww < 0 || ww >= W) continue;
+                const float* src = z + (((int64_t)ti * H + hh) * W + ww) * ld + ((dt * 3 + dh) * 3 + dw) * CO;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) acc[c] += src[c];
+            }
+        }
+    }
+    unsigned short* dst = y + v * c_pad;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) dst[c] = f32_to_bf16_bits(acc[c]);
+    for (int c = CO; c < c_pad; ++c) dst[c] = 0;
+}
+
 }  // namespace
 
 extern "C" int ea_groupnorm_stats_bf16(const ea_bf16* x, float* partial, float* stats, int T, int64_t hw, int C,
@@ -252,6 +331,16 @@ extern "C" int ea_groupnorm_stats_bf16(const ea_bf16* x, float* partial, float* 
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((T * groups + 127) / 128), dim3(128), 0, st, partial, stats, T, groups, C,
                        nblk, hw, eps);
     return ea_check_launch("ea_groupnorm_stats_bf16(finalize)");
+}
+
+extern "C" int ea_groupnorm_finalize_bf16(const float* partial, float* stats, int T, int64_t hw, int C, int groups, int nblk,
+                                          float eps, void* stream) {
+    EA_REQUIRE(partial && stats, "ea_groupnorm_finalize_bf16: null tensor");
+    EA_REQUIRE(groups > 0 && C % groups == 0 && (C / groups) % 4 == 0 && T > 0 && nblk > 0 && hw > 0 && (int64_t)T * groups < (1ll << 31),
+               "ea_groupnorm_finalize_bf16: bad sizes");
+    hipLaunchKernelGGL(gn_finalize_wide_kernel, dim3((unsigned)(T * groups)), dim3(256), 0, (hipStream_t)stream, partial, stats,
+                       groups, C, nblk, hw, eps);
+    return ea_check_launch("ea_groupnorm_finalize_bf16");
 }
 
 extern "C" int ea_groupnorm_apply_bf16(const ea_bf16* x, ea_bf16* y, const float* stats, const float* gamma,
@@ -315,4 +404,23 @@ extern "C" int ea_ndhwc_to_ncdhw(const ea_bf16* src, void* dst, int C, int C_src
     if (dst_is_bf16) hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, C, C_src, voxels, post);
     else hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, C, C_src, voxels, post);
     return ea_check_launch("ea_ndhwc_to_ncdhw");
+}
+
+extern "C" int ea_conv3d_tap_gather_f32(const float* z, const float* bias, ea_bf16* y, int T, int H, int W, int ld, int C_out,
+                                        int C_pad, void* stream) {
+    EA_REQUIRE(z && y, "ea_conv3d_tap_gather_f32: null tensor");
+    EA_REQUIRE(T > 0 && H > 0 && W > 0 && C_out >= 1 && C_out <= 4 && C_pad >= C_out && ld >= 27 * C_out,
+               "ea_conv3d_tap_gather_f32: C_out must be 1..4, ld >= 27*C_out");
+    const int64_t total = (int64_t)T * H * W;
+    EA_REQUIRE((total + 255) / 256 < (1ll << 31), "ea_conv3d_tap_gather_f32: grid too large");
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (C_out) {
+        case 1: hipLaunchKernelGGL(conv_tap_gather_kernel<1>, grid, dim3(256), 0, st, z, bias, y, T, H, W, ld, C_pad); break;
+        case 2: hipLaunchKernelGGL(conv_tap_gather_kernel<2>, grid, dim3(256), 0, st, z, bias, y, T, H, W, ld, C_pad); break;
+        case 3: hipLaunchKernelGGL(conv_tap_gather_kernel<3>, grid, dim3(256), 0, st, z, bias, y, T, H, W, ld, C_pad); break;
+        default: hipLaunchKernelGGL(conv_tap_gather_kernel<4>, grid, dim3(256), 0, st, z, bias, y, T, H, W, ld, C_pad); break;
+    }
+    ea_count("conv_narrow_gemm_tap_gather");
+    return ea_check_launch("ea_conv3d_tap_gather_f32");
 }

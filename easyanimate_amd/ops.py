@@ -396,8 +396,11 @@ def conv_out_shape(T, H, W, k: int, st: int, ss: int, pad: int, ups: bool = Fals
 
 
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], k: int, st: int = 1, ss: int = 1,
-              pad: int = 1, ups: bool = False, tdup: bool = False, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x bf16 [T,H,W,Cin] (Cin % 64 == 0), w_packed bf16 [Cout, k^3*Cin] -> bf16 [T',H',W',Cout]."""
+              pad: int = 1, ups: bool = False, tdup: bool = False, res: Optional[torch.Tensor] = None,
+              want_stats: bool = True) -> torch.Tensor:
+    """x bf16 [T,H,W,Cin] (Cin % 64 == 0), w_packed bf16 [Cout, k^3*Cin] -> bf16 [T',H',W',Cout].
+    If the row-slab kernel serves the call it also leaves the per-frame GroupNorm partial sums of its output on the
+    returned tensor (`y.gn_partial = (partial, nblk)`): groupnorm_silu() then skips its statistics pass."""
     _dev(x, w_packed, bias, res)
     _chk(x, _BF16, "x"); _chk(w_packed, _BF16, "w")
     assert x.is_contiguous() and w_packed.is_contiguous() and x.dim() == 4
@@ -409,9 +412,33 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     y = torch.empty((Ty, Ho, Wo, Cout), dtype=_BF16, device=x.device)
     if res is not None:
         assert res.is_contiguous() and res.shape == (To, Ho, Wo, Cout) and res.dtype == _BF16
+    dup = int(tdup and To > 1)
+    if want_stats and k == 3 and st == 1 and ss == 1 and pad == 1 and Wo % 256 == 0 and Cout % 128 == 0 and not dup:
+        cap = To * Ho * (Wo // 256) * 4 * (Cout // 4) * 2       # the largest layout the kernel may choose
+        partial = torch.empty(cap, dtype=_F32, device=x.device)
+        nblk = ctypes.c_int(0)
+        _timed("conv3d", lambda: _lib.call("ea_conv3d_cl_stats_bf16", _p(x), _p(w_packed), _p(bias), _p(res), _p(y),
+                                           _p(_zeros_page(x.device)), T, H, W, Cin, Cout, k, k, k, st, ss, pad, int(ups), dup,
+                                           _p(partial), cap, ctypes.byref(nblk), _stream()))
+        if nblk.value:
+            y.gn_partial = (partial, nblk.value)
+        return y
     _timed("conv3d", lambda: _lib.call("ea_conv3d_cl_bf16", _p(x), _p(w_packed), _p(bias), _p(res), _p(y),
                                        _p(_zeros_page(x.device)), T, H, W, Cin, Cout, k, k, k, st, ss, pad, int(ups),
-                                       int(tdup and To > 1), _stream()))
+                                       dup, _stream()))
+    return y
+
+
+def conv3d_narrow(x: torch.Tensor, wz: torch.Tensor, bias: Optional[torch.Tensor], c_out: int, c_pad: int) -> torch.Tensor:
+    """3x3x3 / stride 1 / pad 1 causal convolution with C_out <= 4 as one GEMM + a tap-gather pass
+    (ea_conv3d_tap_gather_f32).  x bf16 [T,H,W,Cin]; wz bf16 [round_up(27*c_out, 8), Cin] -> bf16 [T,H,W,c_pad]."""
+    _dev(x, wz, bias)
+    _chk(x, _BF16, "x"); _chk(wz, _BF16, "wz")
+    assert x.is_contiguous() and x.dim() == 4 and wz.is_contiguous() and wz.shape[1] == x.shape[-1]
+    T, H, W, Cin = x.shape
+    z = gemm(x.view(T * H * W, Cin), wz, None, EPI_F32_OUT)              # fp32 [M, ld]
+    y = torch.empty((T, H, W, c_pad), dtype=_BF16, device=x.device)
+    _timed("conv3d", lambda: _lib.call("ea_conv3d_tap_gather_f32", _p(z), _p(bias), _p(y), T, H, W, z.shape[1], c_out, c_pad, _stream()))
     return y
 
 
@@ -429,19 +456,28 @@ def im2col3d(x: torch.Tensor, k: int, st: int, ss: int, pad: int, k_pad: int):
 
 def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
                    act: bool = True) -> torch.Tensor:
-    """Per-frame GroupNorm (+SiLU) of x bf16 [T, H, W, C] (or [T, HW, C])."""
+    """Per-frame GroupNorm (+SiLU) of x bf16 [T, H, W, C] (or [T, HW, C]).  When x came out of a convolution that already
+    reduced its output (x.gn_partial, see conv3d_cl) only the finalize kernel runs; otherwise the statistics pass."""
     _dev(x, gamma, beta)
     _chk(x, _BF16, "x"); _chk(gamma, _F32, "gamma"); _chk(beta, _F32, "beta")
     assert x.is_contiguous()
     T, C = x.shape[0], x.shape[-1]
     hw = x.numel() // (T * C)
-    nblk = max(1, min(256, hw // 2048))
-    partial = torch.empty((T, nblk, C // 4, 2), dtype=_F32, device=x.device)
     stats = torch.empty((T, groups, 2), dtype=_F32, device=x.device)
-    _lib.call("ea_groupnorm_stats_bf16", _p(x), _p(partial), _p(stats), T, hw, C, groups, nblk, float(eps), _stream())
+    fused = getattr(x, "gn_partial", None)
+    if fused is not None and FUSED_GN_STATS:
+        partial, nblk = fused
+        _lib.call("ea_groupnorm_finalize_bf16", _p(partial), _p(stats), T, hw, C, groups, nblk, float(eps), _stream())
+    else:
+        nblk = max(1, min(256, hw // 2048))
+        partial = torch.empty((T, nblk, C // 4, 2), dtype=_F32, device=x.device)
+        _lib.call("ea_groupnorm_stats_bf16", _p(x), _p(partial), _p(stats), T, hw, C, groups, nblk, float(eps), _stream())
     y = torch.empty_like(x)
     _lib.call("ea_groupnorm_apply_bf16", _p(x), _p(y), _p(stats), _p(gamma), _p(beta), T, hw, C, groups, int(act), _stream())
     return y
+
+
+FUSED_GN_STATS = True   # False: always run the separate statistics pass (A/B, tests)
 
 
 def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -243,6 +243,31 @@ int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, con
                       const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
                       int kw, int st, int ss, int pad, int ups, int tdup, void* stream);
 
+/* ea_conv3d_cl_bf16 that also emits the per-frame GroupNorm statistics of ITS OUTPUT -- what the next layer's
+ * GroupNorm (common.py:301-305,318) needs -- from the convolution epilogue, instead of a separate pass over the
+ * activation (3.5 % of a 49 x 1024^2 decode).  Deterministic two-level form: the epilogue writes one (sum, sumsq) pair per
+ * (frame, 256-voxel row tile, wave row, 4-channel bundle) into gn_partial (capacity in floats); ea_groupnorm_finalize_bf16
+ * reduces them in a fixed order.  Only the row-slab kernel does this (3x3x3 / stride 1 / pad 1 layers whose output rows
+ * are a multiple of 256 voxels wide, not with tdup): *gn_nblk_out (HOST int) is the number of partial blocks per frame
+ * that were written, or 0 -- then the caller runs ea_groupnorm_stats_bf16 as before. */
+int ea_conv3d_cl_stats_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
+                            const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
+                            int kw, int st, int ss, int pad, int ups, int tdup, float* gn_partial,
+                            int64_t gn_capacity_floats, int* gn_nblk_out, void* stream);
+/* stats fp32 [T, groups, 2] = (mean, rstd) from partial [T, nblk, C/4, 2] (sum, sumsq per 4-channel bundle), fp64,
+ * fixed order; hw = voxels per frame. */
+int ea_groupnorm_finalize_bf16(const float* partial, float* stats, int T, int64_t hw, int C, int groups, int nblk,
+                               float eps, void* stream);
+
+/* Second half of a narrow-N (C_out <= 4) 3x3x3 / stride 1 / pad 1 causal convolution -- the decoder's conv_out 128 -> 3
+ * (omnigen_enc_dec.py:611): the first half is ONE ea_gemm_bf16 (EA_EPI_F32_OUT) over the input voxels with the weight
+ * re-packed to [27*C_out (padded to a multiple of 8), C_in], z[v, tap*C_out + co] = sum_ci x[v,ci] * w[co,ci,tap]
+ * (tap = (dt*3+dh)*3+dw); this kernel sums the 27 taps:  y[v, co] = bias[co] + sum_tap z[v + offset(tap), tap*C_out + co],
+ * frame index clamped at 0 (causal replicate padding), zero padding in space.  27x fewer MFMA flops than running the
+ * 3-column problem through a 128-wide implicit-GEMM tile.  z: fp32 [T*H*W, ld]; y: bf16 [T,H,W,C_pad] (channels >= C_out zero). */
+int ea_conv3d_tap_gather_f32(const float* z, const float* bias, ea_bf16* y, int T, int H, int W, int ld, int C_out,
+                             int C_pad, void* stream);
+
 /* Explicit im2col for the few convolutions with C_in % 64 != 0 (conv_in 3->128, decoder conv_in 16->512, the
  * 1x1x1 quant convs autoencoder_magvit.py:181-182): cols bf16 [T_out*H_out*W_out, k_pad],
  * cols[m, tap*C_in + c], zero padded; the product is ea_gemm_bf16. */

@@ -69,6 +69,63 @@ def test_conv3d_cl(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res):
     assert rel < 4e-3
 
 
+@pytest.mark.parametrize("T,H,W,Ci,Co", [(3, 10, 12, 64, 3), (1, 7, 9, 128, 3), (5, 33, 20, 128, 3), (2, 8, 8, 64, 1), (4, 6, 5, 192, 4)])
+def test_conv3d_narrow_n(T, H, W, Ci, Co):
+    """Decoder conv_out (128 -> 3, omnigen_enc_dec.py:611): one GEMM over the input voxels + the 27-tap gather
+    (ea_conv3d_tap_gather_f32) against fp64 F.conv3d with causal replicate padding -- through the module's own dispatch."""
+    from easyanimate_amd import _lib
+    from easyanimate_amd.vae_modules import CausalConv3d
+    g = torch.Generator().manual_seed(11)
+    conv = CausalConv3d(Ci, Co, kernel_size=3)
+    with torch.no_grad():
+        conv.weight.copy_(_bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5).float())
+        conv.bias.copy_(torch.randn(Co, generator=g))
+    x = _bf(torch.randn(1, Ci, T, H, W, generator=g))
+    ref = F.conv3d(F.pad(x.double(), (0, 0, 0, 0, 2, 0), mode="replicate"), conv.weight.double(), conv.bias.double(), padding=(0, 1, 1))
+    conv = conv.to(DEV)
+    _lib.reset_counters()
+    y = conv(x[0].permute(1, 2, 3, 0).contiguous().to(DEV))
+    assert _lib.counters().get("conv_narrow_gemm_tap_gather", 0) == 1
+    assert y.shape == (T, H, W, 8) and y[..., Co:].abs().max().item() == 0
+    err, rel = _rep(f"conv3d narrow-N T{T} {H}x{W} {Ci}->{Co}", y[..., :Co].permute(3, 0, 1, 2)[None], ref)
+    assert rel < 4e-3
+
+
+@pytest.mark.parametrize("Ci,Co,ups,res", [(128, 128, False, True), (64, 256, False, False), (128, 128, True, False)])
+def test_groupnorm_stats_fused_in_conv_epilogue(Ci, Co, ups, res):
+    """The row-slab convolution leaves the per-frame (sum, sumsq) partials of its output behind (ea_conv3d_cl_stats_bf16);
+    GroupNorm + SiLU from those partials (finalize only) must equal GroupNorm + SiLU with its own statistics pass."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight
+    g = torch.Generator().manual_seed(23)
+    T, H, W = 3, (128 if ups else 256), (128 if ups else 256)
+    x = _bf(torch.randn(T, H, W, Ci, generator=g)).to(DEV)
+    w = _pack_conv_weight(_bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    r = _bf(torch.randn(T, 256, 256, Co, generator=g)).to(DEV) if res else None
+    gamma, beta = (1 + 0.3 * torch.randn(Co, generator=g)).to(DEV), (0.3 * torch.randn(Co, generator=g)).to(DEV)
+    _lib.reset_counters()
+    y = ops.conv3d_cl(x, w, b, 3, ups=ups, res=r)
+    assert sum(v for k, v in _lib.counters().items() if k.startswith("conv_row16")) == 1
+    assert hasattr(y, "gn_partial"), "the row-slab kernel served the call but left no partial sums"
+    y_plain = ops.conv3d_cl(x, w, b, 3, ups=ups, res=r, want_stats=False)
+    assert torch.equal(y, y_plain) and not hasattr(y_plain, "gn_partial")
+    a = ops.groupnorm_silu(y, gamma, beta, 32, 1e-6)
+    ops.FUSED_GN_STATS = False
+    try:
+        c = ops.groupnorm_silu(y, gamma, beta, 32, 1e-6)
+    finally:
+        ops.FUSED_GN_STATS = True
+    ref = F.silu(F.group_norm(y.double().permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), 1e-6)).permute(0, 2, 3, 1)
+    d = (a.float() - c.float()).abs()
+    frac = (d > 0).float().mean().item()
+    print(f"[parity] GroupNorm from conv-epilogue partials vs own statistics pass ({Ci}->{Co}, ups {ups}, res {res}): "
+          f"{frac * 100:.4f} % of the outputs differ, max |d| {d.max().item():.3e}")
+    assert frac < 1e-3 and d.max().item() <= 2.0 ** -6 * max(1.0, c.float().abs().max().item())
+    err, rel = _rep("GroupNorm(fused stats)+SiLU vs fp64", a, ref)
+    assert rel < 5e-3
+
+
 PP_CASES = [
     # the 256 x {128,256} ping-pong kernels, forced: ragged M, taps crossing every border, strides, folded up-sampling,
     # temporal dup, residual, 1x1x1, odd / even K-tile counts (C_in 64 -> 27 tiles, 128 -> 54, 192 -> 81)
