@@ -32,6 +32,7 @@ PROTOTYPES = {
     "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P],
     "ea_qkv_gemm_norm_rope_bf16": [_P] * 16 + [_I, _I, _I, _I, _L, _L, _I, _I, _F, _F, _P],
     "ea_attention_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P],
+    "ea_attention_window_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "ea_attention_fwd_range_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_unpatchify": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -43,7 +44,7 @@ PROTOTYPES = {
     "ea_conv3d_cl_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_conv3d_cl_stats_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
     "ea_groupnorm_finalize_bf16": [_P, _P, _I, _L, _I, _I, _I, _F, _P],
-    "ea_conv3d_tap_gather_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ea_conv3d_tap_gather_f32": [_P, _P, _P, _I, _I, _I, _L, _I, _I, _P],
     "ea_im2col3d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_groupnorm_stats_bf16": [_P, _P, _P, _I, _L, _I, _I, _I, _F, _P],
     "ea_groupnorm_apply_bf16": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P],

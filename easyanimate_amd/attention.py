@@ -12,7 +12,7 @@ from torch import nn
 from . import ops
 from ._params import bf16_weight, f32
 from .norm import EasyAnimateLayerNormZero, FP32LayerNorm
-from .processor import EasyAnimateAttnProcessor2_0
+from .processor import EasyAnimateAttnProcessor2_0, EasyAnimateSWAttnProcessor2_0
 
 
 class Attention(nn.Module):
@@ -105,18 +105,16 @@ class EasyAnimateDiTBlock(nn.Module):
                  ff_bias: bool = True, qk_norm: bool = True, after_norm: bool = False,
                  norm_type: str = "fp32_layer_norm", is_mmdit_block: bool = True, is_swa: bool = False):
         super().__init__()
-        if is_swa:
-            raise NotImplementedError("sliding-window attention layers (swa_layers) are a SURVEY 8(f) 'next' row")
         self.norm1 = EasyAnimateLayerNormZero(time_embed_dim, dim, norm_elementwise_affine, norm_eps,
                                               norm_type=norm_type, bias=True)
         self.is_swa = is_swa
         self.attn1 = Attention(query_dim=dim, dim_head=attention_head_dim, heads=num_attention_heads,
                                qk_norm="layer_norm" if qk_norm else None, eps=1e-6, bias=True,
-                               processor=EasyAnimateAttnProcessor2_0())
+                               processor=EasyAnimateSWAttnProcessor2_0() if is_swa else EasyAnimateAttnProcessor2_0())
         if is_mmdit_block:
             self.attn2 = Attention(query_dim=dim, dim_head=attention_head_dim, heads=num_attention_heads,
                                    qk_norm="layer_norm" if qk_norm else None, eps=1e-6, bias=True,
-                                   processor=EasyAnimateAttnProcessor2_0())
+                                   processor=EasyAnimateSWAttnProcessor2_0() if is_swa else EasyAnimateAttnProcessor2_0())
         else:
             self.attn2 = None
         self.norm2 = EasyAnimateLayerNormZero(time_embed_dim, dim, norm_elementwise_affine, norm_eps,
@@ -141,7 +139,7 @@ class EasyAnimateDiTBlock(nn.Module):
         hidden_states, encoder_hidden_states = self.attn1(
             hidden_states=norm_h, encoder_hidden_states=norm_e, image_rotary_emb=image_rotary_emb, attn2=self.attn2,
             residual=hidden_states, encoder_residual=encoder_hidden_states, gate=gate_msa, encoder_gate=enc_gate_msa,
-            sp=sp)
+            sp=sp, num_frames=num_frames, height=height, width=width)
         # Norm + FFN + gated residual (attention.py:1144-1162), fused in the second FFN GEMM
         norm_h, norm_e, gate_ff, enc_gate_ff = self.norm2(hidden_states, encoder_hidden_states, temb)
         txt_ff = self.txt_ff if self.txt_ff is not None else self.ff

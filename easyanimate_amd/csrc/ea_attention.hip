@@ -160,10 +160,16 @@ constexpr int ATT_TILE = ATT_KV * 64 * 2;   // 8 KiB (K tile; V^T tile has the s
 constexpr int ATT_STAGE = 2 * ATT_TILE;     // 16 KiB
 constexpr int ATT_LDS = 2 * ATT_STAGE;      // 32 KiB
 
+// WINDOW: sliding-window (band) attention of the SWA processor (processor.py:420, flash_attn_func(window_size=(w, w))):
+// query i sees key j iff |i - j| <= window.  Only the key tiles that intersect the band of the workgroup's 256 queries
+// are visited; inside them the band (and the sequence tail) is masked with a large FINITE negative score, so that a
+// query whose first visited tile holds none of its keys carries a finite running maximum (its garbage partial sums are
+// multiplied by exp2(-huge) = 0 as soon as its first real key arrives; every query sees at least itself).
+template <bool WINDOW>
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K, const unsigned short* __restrict__ Vt,
     unsigned short* __restrict__ O, int64_t o_bs, int heads, int bh_total, int seq, int s_pad, int q_begin,
-    int q_end, int nqb, float scale_log2e) {
+    int q_end, int nqb, float scale_log2e, int window) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -236,9 +242,18 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     float m_run[2] = {-INFINITY, -INFINITY};
     float l_run[2] = {0.f, 0.f};
 
-    const int nt = (seq + ATT_KV - 1) / ATT_KV;
-    issue(0, 0);
-    for (int t = 0; t < nt; ++t) {
+    int nt = (seq + ATT_KV - 1) / ATT_KV;
+    int t_lo = 0;
+    const float MASKED = WINDOW ? -1.0e30f : -INFINITY;
+    if (WINDOW) {
+        const int qblk0 = q_begin + qb * ATT_QB;          // the four waves share the K / V^T tiles: workgroup-wide band
+        const int lo = qblk0 - window, hi_key = qblk0 + ATT_QB - 1 + window;
+        t_lo = lo > 0 ? lo / ATT_KV : 0;
+        const int t_hi = hi_key / ATT_KV + 1;
+        nt = t_hi < nt ? t_hi : nt;
+    }
+    issue(t_lo, t_lo & 1);
+    for (int t = t_lo; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -270,8 +285,20 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
                     if (key >= seq) {
-                        s[0][r] = -INFINITY;
-                        s[1][r] = -INFINITY;
+                        s[0][r] = MASKED;
+                        s[1][r] = MASKED;
+                    }
+                }
+            }
+            if (WINDOW) {
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) {
+                    const int qrow = q0 + qi * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                        const int d = key - qrow;
+                        if (d > window || d < -window) s[qi][r] = MASKED;
                     }
                 }
             }
@@ -387,8 +414,8 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     f32x4* st4 = reinterpret_cast<f32x4*>(state);
     if (variant == 1) {
         ea_count("attention_v1");
-        hipLaunchKernelGGL(attention_fwd_kernel, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh, kv_end,
-                           s_pad, q_begin, q_end, nqb, scale_log2e);
+        hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh, kv_end,
+                           s_pad, q_begin, q_end, nqb, scale_log2e, 0);
     } else {
         // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
         const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;
@@ -421,6 +448,23 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
     EA_REQUIRE(q_end <= seq, "ea_attention_fwd_bf16: bad query range");
     return attention_launch(q, k, vt, out, out_batch_stride, batch, heads, s_pad, q_begin, q_end, 0, seq, scale, nullptr, 0,
                             stream);
+}
+
+extern "C" int ea_attention_window_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                            int64_t out_batch_stride, int batch, int heads, int seq, int s_pad, int window,
+                                            float scale, void* stream) {
+    EA_REQUIRE(q && k && vt && out, "ea_attention_window_fwd_bf16: null tensor");
+    EA_REQUIRE(batch > 0 && heads > 0 && seq > 0 && window >= 0, "ea_attention_window_fwd_bf16: bad sizes");
+    EA_REQUIRE(s_pad % ATT_QB == 0 && s_pad >= seq, "ea_attention_window_fwd_bf16: s_pad must be a multiple of 256 and >= seq");
+    const int nqb = (seq + ATT_QB - 1) / ATT_QB;
+    const int bh = batch * heads;
+    const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
+    EA_REQUIRE(blocks < (1ll << 31), "ea_attention_window_fwd_bf16: grid too large");
+    ea_count("attention_window");
+    hipLaunchKernelGGL(attention_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt,
+                       (unsigned short*)out, out_batch_stride, heads, bh, seq, s_pad, 0, seq, nqb,
+                       scale * 1.4426950408889634f, window);
+    return ea_check_launch("ea_attention_window_fwd_bf16");
 }
 
 extern "C" int64_t ea_attention_state_bytes(int batch, int heads, int q_begin, int q_end) {

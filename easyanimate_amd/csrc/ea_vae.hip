@@ -274,14 +274,16 @@ __global__ void ndhwc_to_ncdhw_kernel(const unsigned short* __restrict__ src, vo
 
 // ---- narrow-N 3x3x3 convolution, second half (decoder conv_out 128 -> 3) ---------------------------------------
 // A 3x3x3 convolution with C_out <= 8 wastes a 128-wide MFMA tile on 3 columns.  It is split instead into
-//   (1) ONE plain GEMM over the input voxels: z[v, tap*C_out + co] = sum_ci x[v, ci] * w[co, ci, tap]  (27*C_out columns,
-//       K = C_in: 27x fewer MFMA flops than the tile-per-tap form, HBM-bound), fp32 out;
-//   (2) this kernel: y[v, co] = bias[co] + sum_tap z[v + offset(tap), tap*C_out + co] with the causal replicate padding
+//   (1) ONE plain GEMM with the re-packed weight as the row operand: z[tap*C_out + co, v] = sum_ci w[co, ci, tap] * x[v, ci]
+//       (27*C_out rows, K = C_in: 27x fewer MFMA flops than the tile-per-tap form, HBM-bound), fp32 out, VOXEL-MINOR:
+//       one plane of `voxels` floats per (tap, co);
+//   (2) this kernel: y[v, co] = bias[co] + sum_tap z[tap*C_out + co, v + offset(tap)] with the causal replicate padding
 //       in time (frame index clamped at 0) and zero padding in space -- every z element is consumed exactly once.
-// One thread per output voxel; neighbouring threads read neighbouring z rows, the (dh, dw) reuse stays in L1 / L2.
+// One thread per output voxel: the lanes of a wave read 64 consecutive floats of a plane per (tap, co) -- coalesced (the
+// first version kept z voxel-major and spent 21 ms moving 128-byte lines for 12 useful bytes each).
 template <int CO>
 __global__ __launch_bounds__(256) void conv_tap_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias,
-                                                              unsigned short* __restrict__ y, int T, int H, int W, int ld,
+                                                              unsigned short* __restrict__ y, int T, int H, int W, int64_t ld,
                                                               int c_pad) {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)T * H * W;
@@ -304,9 +306,9 @@ __global__ __launch_bounds__(256) void conv_tap_gather_kernel(const float* __res
             for (int dw = 0; dw < 3; ++dw) {
                 const int ww = w + dw - 1;
                 if (ww < 0 || ww >= W) continue;
-                const float* src = z + (((int64_t)ti * H + hh) * W + ww) * ld + ((dt * 3 + dh) * 3 + dw) * CO;
+                const float* src = z + (int64_t)(((dt * 3 + dh) * 3 + dw) * CO) * ld + (((int64_t)ti * H + hh) * W + ww);
 #pragma unroll
-                for (int c = 0; c < CO; ++c) acc[c] += src[c];
+                for (int c = 0; c < CO; ++c) acc[c] += src[c * ld];
             }
         }
     }
@@ -406,12 +408,12 @@ extern "C" int ea_ndhwc_to_ncdhw(const ea_bf16* src, void* dst, int C, int C_src
     return ea_check_launch("ea_ndhwc_to_ncdhw");
 }
 
-extern "C" int ea_conv3d_tap_gather_f32(const float* z, const float* bias, ea_bf16* y, int T, int H, int W, int ld, int C_out,
-                                        int C_pad, void* stream) {
+extern "C" int ea_conv3d_tap_gather_f32(const float* z, const float* bias, ea_bf16* y, int T, int H, int W, int64_t ld,
+                                        int C_out, int C_pad, void* stream) {
     EA_REQUIRE(z && y, "ea_conv3d_tap_gather_f32: null tensor");
-    EA_REQUIRE(T > 0 && H > 0 && W > 0 && C_out >= 1 && C_out <= 4 && C_pad >= C_out && ld >= 27 * C_out,
-               "ea_conv3d_tap_gather_f32: C_out must be 1..4, ld >= 27*C_out");
     const int64_t total = (int64_t)T * H * W;
+    EA_REQUIRE(T > 0 && H > 0 && W > 0 && C_out >= 1 && C_out <= 4 && C_pad >= C_out && ld >= total,
+               "ea_conv3d_tap_gather_f32: C_out must be 1..4, ld >= T*H*W");
     EA_REQUIRE((total + 255) / 256 < (1ll << 31), "ea_conv3d_tap_gather_f32: grid too large");
     const dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;

@@ -249,6 +249,20 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scal
     return out
 
 
+def attention_window(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, window: int, scale: float,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Band attention |i - j| <= window over rows [0, seq): q,k bf16 [B,H,S_pad,64], vt [B,H,64,S_pad] -> [B,seq,H*64]."""
+    _dev(q, k, vt, out)
+    B, H, s_pad, dh = q.shape
+    assert dh == 64 and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and k.shape == q.shape
+    if out is None:
+        out = torch.empty((B, seq, H * 64), dtype=_BF16, device=q.device)
+    assert out.stride(2) == 1 and out.stride(1) == H * 64
+    _timed("attention", lambda: _lib.call("ea_attention_window_fwd_bf16", _p(q), _p(k), _p(vt), _p(out), out.stride(0), B, H,
+                                          seq, s_pad, int(window), float(scale), _stream()))
+    return out
+
+
 def attention_state(B: int, H: int, q_begin: int, q_end: int, device) -> torch.Tensor:
     """fp32 scratch for the resumable attention (ea_attention_state_bytes)."""
     n = _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)
@@ -430,15 +444,15 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
 
 
 def conv3d_narrow(x: torch.Tensor, wz: torch.Tensor, bias: Optional[torch.Tensor], c_out: int, c_pad: int) -> torch.Tensor:
-    """3x3x3 / stride 1 / pad 1 causal convolution with C_out <= 4 as one GEMM + a tap-gather pass
-    (ea_conv3d_tap_gather_f32).  x bf16 [T,H,W,Cin]; wz bf16 [round_up(27*c_out, 8), Cin] -> bf16 [T,H,W,c_pad]."""
+    """3x3x3 / stride 1 / pad 1 causal convolution with C_out <= 4 as one GEMM (weight rows x voxels, fp32, voxel-minor) + a
+    tap-gather pass (ea_conv3d_tap_gather_f32).  x bf16 [T,H,W,Cin]; wz bf16 [27*c_out, Cin] -> bf16 [T,H,W,c_pad]."""
     _dev(x, wz, bias)
     _chk(x, _BF16, "x"); _chk(wz, _BF16, "wz")
-    assert x.is_contiguous() and x.dim() == 4 and wz.is_contiguous() and wz.shape[1] == x.shape[-1]
+    assert x.is_contiguous() and x.dim() == 4 and wz.is_contiguous() and wz.shape == (27 * c_out, x.shape[-1])
     T, H, W, Cin = x.shape
-    z = gemm(x.view(T * H * W, Cin), wz, None, EPI_F32_OUT)              # fp32 [M, ld]
+    z = gemm(wz, x.view(T * H * W, Cin), None, EPI_F32_OUT)              # fp32 [27*c_out, voxels]
     y = torch.empty((T, H, W, c_pad), dtype=_BF16, device=x.device)
-    _timed("conv3d", lambda: _lib.call("ea_conv3d_tap_gather_f32", _p(z), _p(bias), _p(y), T, H, W, z.shape[1], c_out, c_pad, _stream()))
+    _timed("conv3d", lambda: _lib.call("ea_conv3d_tap_gather_f32", _p(z), _p(bias), _p(y), T, H, W, z.stride(0), c_out, c_pad, _stream()))
     return y
 
 

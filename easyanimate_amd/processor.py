@@ -71,6 +71,30 @@ class EasyAnimateAttnProcessor2_0:
     def __init__(self):
         pass
 
+    def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid):
+        """softmax(QK^T)V over the rows staged in ws -> bf16 [B, S, d]."""
+        # ---- joint attention (processor.py:287-291): queries = text rows + this rank's video rows
+        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        if lay is not None and lay.remote_end > lay.remote_begin:
+            # sequence-parallel: attend the local keys while the K / V^T all-gather is in flight, then resume the
+            # online-softmax state over the remote keys (ea_attention_fwd_range_bf16)
+            pending = sp.exchange_start(ws, v_off)
+            state = _attention_state(B, H, S, dev)
+            for i, (lo, hi) in enumerate(lay.local_ranges):
+                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
+                                    store_state=True)
+            sp.exchange_finish(pending, ws, v_off)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lay.remote_begin, lay.remote_end,
+                                state=state, load_state=True, out=o)
+        elif v_off != T:
+            # single sequence rank with unaligned text: rows [T, v_off) are padding between the two key ranges
+            state = _attention_state(B, H, S, dev)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, 0, T, state=state, store_state=True)
+            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, v_off, S, state=state, load_state=True, out=o)
+        else:
+            ops.attention(ws["q"], ws["k"], ws["vt"], S, ops.FOLDED_ATTN_SCALE, out=o)
+        return o
+
     def __call__(
         self,
         attn,
@@ -84,6 +108,9 @@ class EasyAnimateAttnProcessor2_0:
         gate: Optional[torch.Tensor] = None,
         encoder_gate: Optional[torch.Tensor] = None,
         sp=None,
+        num_frames: Optional[int] = None,
+        height: Optional[int] = None,
+        width: Optional[int] = None,
     ) -> Tuple[torch.Tensor, torch.Tensor]:
         if attention_mask is not None:
             # the V5.1 path never passes a mask (transformer3d.py:1502 drops text_embedding_mask)
@@ -133,26 +160,7 @@ class EasyAnimateAttnProcessor2_0:
         qkv_stream(e, tattn, T, 0, None, None)      # text rows: no RoPE
         qkv_stream(x, attn, N, v_off, cos, sin)
 
-        # ---- joint attention (processor.py:287-291): queries = text rows + this rank's video rows
-        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
-        if lay is not None and lay.remote_end > lay.remote_begin:
-            # sequence-parallel: attend the local keys while the K / V^T all-gather is in flight, then resume the
-            # online-softmax state over the remote keys (ea_attention_fwd_range_bf16)
-            pending = sp.exchange_start(ws, v_off)
-            state = _attention_state(B, H, S, dev)
-            for i, (lo, hi) in enumerate(lay.local_ranges):
-                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
-                                    store_state=True)
-            sp.exchange_finish(pending, ws, v_off)
-            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lay.remote_begin, lay.remote_end,
-                                state=state, load_state=True, out=o)
-        elif v_off != T:
-            # single sequence rank with unaligned text: rows [T, v_off) are padding between the two key ranges
-            state = _attention_state(B, H, S, dev)
-            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, 0, T, state=state, store_state=True)
-            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, v_off, S, state=state, load_state=True, out=o)
-        else:
-            ops.attention(ws["q"], ws["k"], ws["vt"], S, ops.FOLDED_ATTN_SCALE, out=o)
+        o = self._attend(ws, B, H, T, N, S, v_off, d, dev, lay, sp, (num_frames, height, width))
         o_t, o_v = o[:, :T], o[:, v_off:]
 
         # ---- output projections (:293-311), optionally with the gated residual fused (attention.py:1140-1141)
@@ -168,3 +176,71 @@ class EasyAnimateAttnProcessor2_0:
             h_out = ops.gemm(o_v, bf16_weight(lo_v.weight), f32(lo_v.bias), ops.EPI_BIAS)
             e_out = ops.gemm(o_t, bf16_weight(lo_t.weight), f32(lo_t.bias), ops.EPI_BIAS)
         return h_out, e_out
+
+
+class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
+    """Sliding-window variant (reference: processor.py:320-459; selected per block by `swa_layers`, attention.py:1065).
+    Same projections / qk-norm / RoPE as the full processor; the attention itself is the sum of
+
+      * a *cross* pass: every query (text + video) over the text keys and every `interval`-th video key
+        (interval = max(N // (cross_attention_size - T), 1), :393-397), and
+      * a *window* pass over the video tokens only: the heads are split into six groups, group g sees the video tokens in
+        its own scan order ((f h w), (f w h), (h f w), (h w f), (w f h), (w h f), :400-417) and each query attends the keys
+        within +-(height*width) positions of that order (flash_attn_func window_size, :420); the result is brought back to
+        (f h w) order (:422-434);
+
+    text rows leave as cross + cross, video rows as window + cross (:435 adds `cross` to a tensor whose text rows already
+    are `cross`).  Each pass rounds to bf16 like the two flash_attn_func calls do.  The strided key gather and the scan-order
+    permutations are index copies (torch indexing); the two attention passes are ea_attention_fwd_range_bf16 and
+    ea_attention_window_fwd_bf16."""
+
+    _ORDERS = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+
+    def __init__(self, cross_attention_size: int = 1024):
+        super().__init__()
+        self.cross_attention_size = cross_attention_size
+        self._perm = {}
+
+    def _scan_orders(self, F_: int, Hh: int, Ww: int, heads: int, dev):
+        key = (F_, Hh, Ww, heads, str(dev))
+        if key not in self._perm:
+            base = torch.arange(F_ * Hh * Ww, device=dev).view(F_, Hh, Ww)
+            groups = torch.tensor_split(torch.arange(heads, device=dev), 6)
+            self._perm = {key: [(hs, base.permute(*o).reshape(-1).contiguous()) for hs, o in zip(groups, self._ORDERS) if hs.numel()]}
+        return self._perm[key]
+
+    def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid):
+        if sp is not None:
+            raise NotImplementedError("sliding-window attention blocks under sequence parallelism")
+        F_, Hh, Ww = grid
+        if F_ is None or F_ * Hh * Ww != N:
+            raise ValueError("EasyAnimateSWAttnProcessor2_0 needs num_frames / height / width of the token grid")
+        q, k, vt = ws["q"], ws["k"], ws["vt"]
+        # ---- cross pass
+        interval = max(N // (self.cross_attention_size - T), 1)
+        idx = torch.cat([torch.arange(T, device=dev), T + torch.arange(0, N, interval, device=dev)])
+        kc, vtc = torch.zeros_like(k), torch.zeros_like(vt)
+        kc[:, :, :idx.numel()] = k[:, :, idx]
+        vtc[:, :, :, :idx.numel()] = vt[:, :, :, idx]
+        cross = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        ops.attention_range(q, kc, vtc, ops.FOLDED_ATTN_SCALE, 0, S, 0, idx.numel(), out=cross)
+        # ---- window pass over the re-ordered video tokens
+        n_pad = ops.round_up(N, 256)
+        qp = torch.zeros(B, H, n_pad, 64, dtype=torch.bfloat16, device=dev)
+        kp = torch.zeros_like(qp)
+        vtp = torch.zeros(B, H, 64, n_pad, dtype=torch.bfloat16, device=dev)
+        orders = self._scan_orders(F_, Hh, Ww, H, dev)
+        for hs, src in orders:
+            rows = T + src
+            qp[:, hs, :N] = q[:, hs][:, :, rows]
+            kp[:, hs, :N] = k[:, hs][:, :, rows]
+            vtp[:, hs, :, :N] = vt[:, hs][:, :, :, rows]
+        win = ops.attention_window(qp, kp, vtp, N, Hh * Ww, ops.FOLDED_ATTN_SCALE).view(B, N, H, 64)
+        back = torch.empty_like(win)
+        for hs, src in orders:
+            back[:, src[:, None], hs[None, :]] = win[:, :, hs]
+        # ---- text rows: cross + cross; video rows: window + cross
+        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        o[:, :T] = ops.bf16_add_(cross[:, :T].contiguous(), cross[:, :T].contiguous())
+        o[:, T:] = ops.bf16_add_(back.view(B, N, d), cross[:, T:].contiguous())
+        return o

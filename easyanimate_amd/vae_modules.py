@@ -49,11 +49,10 @@ def conv_cl(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None
     n_pad = ops.round_up(co, 8)
     if x.shape[-1] != ci:
         raise ValueError(f"conv expects {ci} input channels, got {x.shape[-1]}")
-    if ci % 64 == 0 and co <= 4 and kt == 3 and (st, sh, pad) == (1, 1, 1) and res is None and not ups and not tdup:
+    if (ci % 64 == 0 and co <= 4 and kt == 3 and (st, sh, pad) == (1, 1, 1) and res is None and not ups and not tdup
+            and (x.shape[0] * x.shape[1] * x.shape[2]) % 8 == 0):
         # narrow-N convolution (decoder conv_out 128 -> 3): one GEMM over the input voxels + a 27-tap gather
-        ld = ops.round_up(27 * co, 8)
-        wz = derived(conv.weight, f"narrow{ld}", lambda t: torch.nn.functional.pad(
-            t.permute(2, 3, 4, 0, 1).reshape(27 * co, ci).to(torch.bfloat16), (0, 0, 0, ld - 27 * co)).contiguous())
+        wz = derived(conv.weight, "narrow", lambda t: t.permute(2, 3, 4, 0, 1).reshape(27 * co, ci).to(torch.bfloat16).contiguous())
         b = derived(conv.bias, "f32c", lambda t: t.float().contiguous()) if conv.bias is not None else None
         return ops.conv3d_narrow(x, wz, b, co, n_pad)
     if ci % 64 == 0:

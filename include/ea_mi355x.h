@@ -158,6 +158,14 @@ int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt,
                           int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
                           int q_begin, int q_end, float scale, void* stream);
 
+/* Sliding-window (band) attention of EasyAnimateSWAttnProcessor2_0 (processor.py:420: flash_attn_func(q, k, v,
+ * window_size=(w, w)) on the six re-ordered head groups): query row i attends key rows j with |i - j| <= window, rows
+ * [0, seq) of q / k / vt (same layouts as ea_attention_fwd_bf16), softmax(QK^T * scale) V.  Only key tiles intersecting
+ * the band are visited. */
+int ea_attention_window_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                 int64_t out_batch_stride, int batch, int heads, int seq, int s_pad, int window,
+                                 float scale, void* stream);
+
 /* The same attention, resumable over key ranges: keys [kv_begin, kv_end) only (kv_begin % 64 == 0, kv_end
  * arbitrary), with the online-softmax state (un-normalised O, running max, partial row sums; fp32) carried in a
  * caller-owned `state` buffer of ea_attention_state_bytes(batch, heads, q_begin, q_end) bytes:
@@ -260,12 +268,13 @@ int ea_groupnorm_finalize_bf16(const float* partial, float* stats, int T, int64_
                                float eps, void* stream);
 
 /* Second half of a narrow-N (C_out <= 4) 3x3x3 / stride 1 / pad 1 causal convolution -- the decoder's conv_out 128 -> 3
- * (omnigen_enc_dec.py:611): the first half is ONE ea_gemm_bf16 (EA_EPI_F32_OUT) over the input voxels with the weight
- * re-packed to [27*C_out (padded to a multiple of 8), C_in], z[v, tap*C_out + co] = sum_ci x[v,ci] * w[co,ci,tap]
- * (tap = (dt*3+dh)*3+dw); this kernel sums the 27 taps:  y[v, co] = bias[co] + sum_tap z[v + offset(tap), tap*C_out + co],
- * frame index clamped at 0 (causal replicate padding), zero padding in space.  27x fewer MFMA flops than running the
- * 3-column problem through a 128-wide implicit-GEMM tile.  z: fp32 [T*H*W, ld]; y: bf16 [T,H,W,C_pad] (channels >= C_out zero). */
-int ea_conv3d_tap_gather_f32(const float* z, const float* bias, ea_bf16* y, int T, int H, int W, int ld, int C_out,
+ * (omnigen_enc_dec.py:611): the first half is ONE ea_gemm_bf16 (EA_EPI_F32_OUT) with the weight, re-packed to
+ * [27*C_out, C_in] (row tap*C_out + co, tap = (dt*3+dh)*3+dw), as the ROW operand and the activation voxels as the column
+ * operand: z[tap*C_out + co, v] = sum_ci w[co,ci,tap] * x[v,ci] -- one plane of voxels per (tap, co).  This kernel sums
+ * the 27 taps:  y[v, co] = bias[co] + sum_tap z[tap*C_out + co, v + offset(tap)], frame index clamped at 0 (causal
+ * replicate padding), zero padding in space.  27x fewer MFMA flops than running the 3-column problem through a 128-wide
+ * implicit-GEMM tile.  z: fp32 [27*C_out, ld], ld >= T*H*W; y: bf16 [T,H,W,C_pad] (channels >= C_out zero). */
+int ea_conv3d_tap_gather_f32(const float* z, const float* bias, ea_bf16* y, int T, int H, int W, int64_t ld, int C_out,
                              int C_pad, void* stream);
 
 /* Explicit im2col for the few convolutions with C_in % 64 != 0 (conv_in 3->128, decoder conv_in 16->512, the

@@ -520,6 +520,42 @@ def gen_transformer_r2b(ns, shim):
                         cos=cos, sin=sin, out=out, out_bf16=outb.float()), os.path.join(OUT, f"{name}.pt"))
 
 
+@section("swa")
+def gen_swa(ns, shim):
+    # ---- sliding-window attention blocks (processor.py:320-459, attention.py:1045-1046,1065,1124-1132):
+    # the reference's own EasyAnimateSWAttnProcessor2_0 with flash_attn_func restated (oracle/flash_attn_shim.py).
+    # 3 x 16 x 48 patches = 2304 video tokens > 2 * (1024 - T): the strided cross keys use interval 2; window = 768.
+    from oracle import flash_attn_shim
+    ns.processor.flash_attn_func = flash_attn_shim.flash_attn_func
+    for name, over, style in (("transformer_swa", dict(num_attention_heads=6, num_layers=2, swa_layers=[0, 1]), "stress"),
+                              ("transformer_swa_mixed", dict(num_attention_heads=6, num_layers=3, swa_layers=[1], mmdit_layers=2), "default")):
+        cfg = dict(TINY, **over)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+        assert sum(type(b.attn1.processor).__name__ == "EasyAnimateSWAttnProcessor2_0" for b in m.transformer_blocks) == len(cfg["swa_layers"])
+        shapes = _load_sd(m, 3, style)
+        g = _g(31)
+        B, Fr, H, W, T = 2, 3, 32, 96, 24
+        lat = torch.randn(B, 16, Fr, H, W, generator=g)
+        enc = torch.randn(B, T, cfg["text_embed_dim"], generator=g) * 3
+        t = torch.tensor([707.0, 707.0]).to(torch.bfloat16).float()
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), return_dict=False)[0]
+        mb = copy.deepcopy(m).to(torch.bfloat16)
+        outb = mb(lat.bfloat16(), t.bfloat16(), encoder_hidden_states=enc.bfloat16(), image_rotary_emb=(cos, sin), return_dict=False)[0]
+        print(f"  {name}: out std {out.std().item():.3f}, floor {_mse(outb.float(), out):.3e}")
+        torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style=style, input_seed=31, dims=(B, Fr, H, W, T), t=t, crops=cc,
+                        lat_sum=lat.double().sum().item(), out=out.to(torch.float16), out_std=out.std().item(),
+                        floor_mse=_mse(outb.float(), out)), os.path.join(OUT, f"{name}.pt"))
+
+
+def swa_inputs(cfg, seed, B, Fr, H, W, T):
+    g = _g(seed)
+    lat = torch.randn(B, 16, Fr, H, W, generator=g)
+    enc = torch.randn(B, T, cfg["text_embed_dim"], generator=g) * 3
+    return lat, enc
+
+
 @torch.no_grad()
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)

@@ -158,6 +158,57 @@ def attn_processor(sd: SD, pre1: str, pre2: Optional[str], h, e, rope, heads: in
     return oh, oe
 
 
+_SWA_ORDERS = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))   # (f h w) -> the six scan orders, :405-411
+
+
+def swa_attn_processor(sd: SD, pre1: str, pre2: Optional[str], h, e, rope, heads: int, grid, qk_eps: float = 1e-6,
+                       cross_attention_size: int = 1024):
+    """EasyAnimateSWAttnProcessor2_0.__call__, processor.py:326-459, with flash_attn_func as restated in
+    oracle/flash_attn_shim.py (the package is absent: that call is "parity unpinned")."""
+    from .flash_attn_shim import flash_attn_func
+    Fr, Hh, Ww = grid
+    T, B = e.shape[1], h.shape[0]
+    if pre2 is None:
+        h = torch.cat([e, h], dim=1)
+
+    def qkv(pre, x):
+        q = F.linear(x, sd[pre + "to_q.weight"], sd[pre + "to_q.bias"]).view(B, -1, heads, 64).transpose(1, 2)
+        k = F.linear(x, sd[pre + "to_k.weight"], sd[pre + "to_k.bias"]).view(B, -1, heads, 64).transpose(1, 2)
+        v = F.linear(x, sd[pre + "to_v.weight"], sd[pre + "to_v.bias"]).view(B, -1, heads, 64)
+        q = F.layer_norm(q, (64,), sd[pre + "norm_q.weight"], sd[pre + "norm_q.bias"], qk_eps)
+        k = F.layer_norm(k, (64,), sd[pre + "norm_k.weight"], sd[pre + "norm_k.bias"], qk_eps)
+        return q, k, v
+
+    q, k, v = qkv(pre1, h)
+    if pre2 is not None:
+        qt, kt, vt = qkv(pre2, e)
+        q, k, v = torch.cat([qt, q], 2), torch.cat([kt, k], 2), torch.cat([vt, v], 1)
+    if rope is not None:
+        q = torch.cat([q[:, :, :T], apply_rotary_emb(q[:, :, T:], *rope)], 2)
+        k = torch.cat([k[:, :, :T], apply_rotary_emb(k[:, :, T:], *rope)], 2)
+    q, k = q.transpose(1, 2).to(v.dtype), k.transpose(1, 2).to(v.dtype)          # [B, S, heads, 64]
+    N = q.shape[1] - T
+    interval = max(N // (cross_attention_size - T), 1)                             # :393
+    cross = flash_attn_func(q, torch.cat([k[:, :T], k[:, T::interval]], 1), torch.cat([v[:, :T], v[:, T::interval]], 1))
+    base = torch.arange(N).view(Fr, Hh, Ww)
+    qs, ks, vs = [torch.tensor_split(t[:, T:], 6, 2) for t in (q, k, v)]
+    srcs = [base.permute(*o).reshape(-1) for o in _SWA_ORDERS]
+    qn, kn, vn = [torch.cat([part[:, src] for part, src in zip(parts, srcs)], dim=2) for parts in (qs, ks, vs)]
+    win = flash_attn_func(qn, kn, vn, window_size=(Hh * Ww, Hh * Ww))              # :420
+    outs = []
+    for part, src in zip(torch.tensor_split(win, 6, 2), srcs):
+        back = torch.empty_like(part)
+        back[:, src] = part
+        outs.append(back)
+    o = torch.cat([cross[:, :T], torch.cat(outs, dim=2)], dim=1) + cross            # :435
+    o = o.reshape(B, -1, heads * 64)
+    if pre2 is None:
+        o = F.linear(o, sd[pre1 + "to_out.0.weight"], sd[pre1 + "to_out.0.bias"])
+        return o[:, T:], o[:, :T]
+    return (F.linear(o[:, T:], sd[pre1 + "to_out.0.weight"], sd[pre1 + "to_out.0.bias"]),
+            F.linear(o[:, :T], sd[pre2 + "to_out.0.weight"], sd[pre2 + "to_out.0.bias"]))
+
+
 def feed_forward(sd: SD, pre: str, x):
     """diffusers FeedForward('gelu-approximate'): net.0.proj -> gelu(tanh) -> net.2 (attention.py:1082-1098)"""
     x = F.gelu(F.linear(x, sd[pre + "net.0.proj.weight"], sd[pre + "net.0.proj.bias"]), approximate="tanh")
@@ -165,12 +216,15 @@ def feed_forward(sd: SD, pre: str, x):
 
 
 def dit_block(sd: SD, pre: str, h, e, temb, rope, heads: int, norm_eps: float, return_parts: bool = False,
-              after_norm: bool = False):
+              after_norm: bool = False, swa_grid=None):
     """EasyAnimateDiTBlock.forward, easyanimate/models/attention.py:1107-1163 (not SWA; after_norm is detected from the
     norm3.* keys, or forced for an affine-free norm3)."""
     mmdit = (pre + "attn2.to_q.weight") in sd
     nh, ne, gate, egate = layernorm_zero(sd, pre + "norm1.", h, e, temb, norm_eps)
-    ah, ae = attn_processor(sd, pre + "attn1.", pre + "attn2." if mmdit else None, nh, ne, rope, heads)
+    if swa_grid is not None:      # is_swa block (attention.py:1124-1132)
+        ah, ae = swa_attn_processor(sd, pre + "attn1.", pre + "attn2." if mmdit else None, nh, ne, rope, heads, swa_grid)
+    else:
+        ah, ae = attn_processor(sd, pre + "attn1.", pre + "attn2." if mmdit else None, nh, ne, rope, heads)
     h = h + gate * ah
     e = e + egate * ae
     nh, ne, gate_ff, egate_ff = layernorm_zero(sd, pre + "norm2.", h, e, temb, norm_eps)
@@ -294,7 +348,8 @@ def transformer_forward(sd: SD, cfg: dict, latents, timestep, enc, rope, inpaint
         x_in = x
         for i in range(cfg["num_layers"]):
             x, e = dit_block(sd, f"transformer_blocks.{i}.", x, e, temb, rope, heads, cfg["norm_eps"],
-                             after_norm=bool(cfg.get("after_norm", False)))
+                             after_norm=bool(cfg.get("after_norm", False)),
+                             swa_grid=(Fr, H // p, W // p) if i in (cfg.get("swa_layers") or ()) else None)
         T = e.shape[1]
         x = torch.cat([e, x], dim=1)
         x = F.layer_norm(x, (inner,), sd.get("norm_final.weight"), sd.get("norm_final.bias"), cfg["norm_eps"])

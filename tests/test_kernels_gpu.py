@@ -385,6 +385,22 @@ def test_attention(B, H, S, folded, attn_kernel):
     assert rel < 8e-3 and err < 0.05, (err, rel)
 
 
+@pytest.mark.parametrize("B,H,S,window", [(1, 2, 1000, 64), (2, 3, 2304, 768), (1, 1, 300, 5), (1, 2, 520, 4000), (1, 1, 777, 0)])
+def test_attention_window(B, H, S, window):
+    """ea_attention_window_fwd_bf16 (the SWA processor's band attention, processor.py:420): |i - j| <= window, against an
+    fp64 masked softmax.  Covers bands narrower than a key tile, wider than the sequence, and window 0 (self only)."""
+    ops = _ops()
+    q, k, vt, v = _attn_inputs(B, H, S, 21)
+    out = ops.attention_window(q, k, vt, S, window, 0.125)
+    qd, kd, vd = q[:, :, :S].double(), k[:, :, :S].double(), v.double()
+    s = qd @ kd.transpose(2, 3) * 0.125
+    i = torch.arange(S, device=s.device)
+    s = s.masked_fill(((i[:, None] - i[None, :]).abs() > window)[None, None], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vd).transpose(1, 2).reshape(B, S, H * 64)
+    err, rel = _report(f"attention window B{B}H{H}S{S}w{window}", out, ref)
+    assert rel < 5e-3 and torch.isfinite(out.float()).all()
+
+
 def test_attention_forced_rescale_and_padding_garbage():
     """Spike keys late in the sequence so the running max jumps in a late tile (online-softmax rescale branch),
     and poison the padded tail of q/k to prove masked keys cannot leak (vt tail must stay finite by contract)."""

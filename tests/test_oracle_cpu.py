@@ -223,3 +223,19 @@ def test_restatement_after_norm_ref_clip_vs_golden(name):
     out = R.transformer_forward(sd, g["cfg"], g["latents"], g["t"], g["enc"], (g["cos"], g["sin"]), control_latents=g["control"],
                                 ref_latents=g["ref"], clip_states=g["clip"])
     _close(out, g["out"], 5e-6, name)
+
+
+@pytest.mark.parametrize("name", ["transformer_swa_mixed"])
+def test_restatement_swa_vs_golden(name):
+    """Sliding-window blocks (processor.py:320-459): the restatement against the reference's own processor run with the
+    restated flash_attn_func (oracle/flash_attn_shim.py).  (transformer_swa.pt, two SWA layers, is left to the GPU test.)"""
+    from oracle.gen_golden import swa_inputs
+    g = _load(name + ".pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    B, Fr, H, W, T = g["dims"]
+    lat, enc = swa_inputs(g["cfg"], g["input_seed"], *g["dims"])
+    assert abs(lat.double().sum().item() - g["lat_sum"]) < 1e-6
+    rope = R.rope_3d(64, g["crops"], (H // 2, W // 2), Fr)
+    with torch.no_grad():
+        out = R.transformer_forward(sd, g["cfg"], lat, g["t"], enc, rope)
+    _close(out, g["out"].float(), 1.5e-3, "swa transformer (fixture stored fp16)")

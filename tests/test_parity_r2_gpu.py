@@ -113,6 +113,31 @@ def test_transformer_after_norm_ref_clip_vs_golden(name):
     assert out.shape == g["out"].shape and mse < BAR
 
 
+@pytest.mark.parametrize("name", ["transformer_swa", "transformer_swa_mixed"])
+def test_transformer_swa_vs_golden(name):
+    """sliding-window attention blocks (swa_layers; processor.py:320-459) -- strided cross keys (interval 2
+    here), six scan orders over the head groups, band attention of +-(h*w) positions -- against the reference's own
+    processor (flash_attn_func restated, oracle/flash_attn_shim.py)."""
+    from easyanimate_amd import _lib
+    from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
+    from oracle.gen_golden import swa_inputs
+    g = _load(name + ".pt")
+    B, Fr, H, W, T = g["dims"]
+    lat, enc = swa_inputs(g["cfg"], g["input_seed"], *g["dims"])
+    assert abs(lat.double().sum().item() - g["lat_sum"]) < 1e-6
+    rope = get_3d_rotary_pos_embed(64, g["crops"], grid_size=(H // 2, W // 2), temporal_size=Fr, use_real=True)
+    m = _model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    _lib.reset_counters()
+    with torch.no_grad():
+        out = m(lat.to(DEV).bfloat16(), g["t"].to(DEV).bfloat16(), encoder_hidden_states=enc.to(DEV).bfloat16(),
+                image_rotary_emb=rope, return_dict=False)[0]
+    torch.cuda.synchronize()
+    cnt = _lib.counters()
+    mse = _mse(out.float(), g["out"].float())
+    print(f"[parity] {name}: new-bf16 vs ref-fp32 MSE={mse:.3e} | ref-bf16 floor {g['floor_mse']:.3e} | ref std {g['out_std']:.3f} | kernels {cnt}")
+    assert mse < BAR and cnt.get("attention_window", 0) == len(g["cfg"]["swa_layers"])
+
+
 # ---------------------------------------------------------------------------------------------------------
 # (c) full-width two-layer forwards (SURVEY 8d-(i))
 # ---------------------------------------------------------------------------------------------------------

@@ -69,7 +69,7 @@ def test_conv3d_cl(T, H, W, Ci, Co, k, st, ss, pad, ups, tdup, res):
     assert rel < 4e-3
 
 
-@pytest.mark.parametrize("T,H,W,Ci,Co", [(3, 10, 12, 64, 3), (1, 7, 9, 128, 3), (5, 33, 20, 128, 3), (2, 8, 8, 64, 1), (4, 6, 5, 192, 4)])
+@pytest.mark.parametrize("T,H,W,Ci,Co", [(3, 10, 12, 64, 3), (1, 7, 9, 128, 3), (5, 33, 24, 128, 3), (2, 8, 8, 64, 1), (4, 6, 5, 192, 4)])
 def test_conv3d_narrow_n(T, H, W, Ci, Co):
     """Decoder conv_out (128 -> 3, omnigen_enc_dec.py:611): one GEMM over the input voxels + the 27-tap gather
     (ea_conv3d_tap_gather_f32) against fp64 F.conv3d with causal replicate padding -- through the module's own dispatch."""
@@ -85,7 +85,8 @@ def test_conv3d_narrow_n(T, H, W, Ci, Co):
     conv = conv.to(DEV)
     _lib.reset_counters()
     y = conv(x[0].permute(1, 2, 3, 0).contiguous().to(DEV))
-    assert _lib.counters().get("conv_narrow_gemm_tap_gather", 0) == 1
+    # voxel counts that are not a multiple of 8 (the GEMM's column granularity) keep the padded tile-per-tap kernel
+    assert _lib.counters().get("conv_narrow_gemm_tap_gather", 0) == (1 if (T * H * W) % 8 == 0 else 0)
     assert y.shape == (T, H, W, 8) and y[..., Co:].abs().max().item() == 0
     err, rel = _rep(f"conv3d narrow-N T{T} {H}x{W} {Ci}->{Co}", y[..., :Co].permute(3, 0, 1, 2)[None], ref)
     assert rel < 4e-3
