@@ -163,6 +163,15 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
                 "AutoencoderKLMagvit (MI355X) implements the V5/V5.1 setting spatial_group_norm=True (per-frame "
                 "GroupNorm, nearest temporal up-sampling); only then is whole-clip evaluation equal to the reference's "
                 "chunked evaluation")
+        if not cache_mag_vae or mini_batch_decoder != 1 or mini_batch_encoder % 2 != 0:
+            # whole-clip causal evaluation equals the reference's chunked evaluation only for its cached mode with an even
+            # encoder chunk and one latent frame per decoder chunk (SURVEY 8c property 1; the V5 / V5.1 YAML values are
+            # cache_mag_vae: true, mini_batch_encoder 4, mini_batch_decoder 1): other settings chunk differently there
+            # (stride-2 misalignment, per-chunk attention) and would silently differ
+            raise NotImplementedError(
+                f"AutoencoderKLMagvit (MI355X): cache_mag_vae={cache_mag_vae}, mini_batch_encoder={mini_batch_encoder}, "
+                f"mini_batch_decoder={mini_batch_decoder} -- only cache_mag_vae=True with an even mini_batch_encoder and "
+                "mini_batch_decoder=1 (the V5 / V5.1 configuration) is evaluated identically to the reference")
         if use_tiling or use_tiling_encoder or use_tiling_decoder:
             raise NotImplementedError("spatial tiling changes results (blended overlaps) and is never enabled by the "
                                       "reference's entry points; not needed with 288 GB of HBM")
@@ -219,8 +228,9 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
 
     def encode(self, x: torch.Tensor, return_dict: bool = True) -> Union[AutoencoderKLOutput, Tuple[DiagonalGaussianDistribution]]:
         self._check(x)
-        if x.shape[2] != 1 and (x.shape[2] - 1) % self.mini_batch_encoder != 0 and self.cache_mag_vae:
-            pass  # the reference accepts ragged tails; whole-clip causal evaluation handles any length
+        if x.shape[2] != 1 and (x.shape[2] - 1) % self.mini_batch_encoder != 0:
+            raise ValueError(f"encode: {x.shape[2]} frames -- the reference's chunked encoder only matches whole-clip evaluation for "
+                             f"1 + k * mini_batch_encoder ({self.mini_batch_encoder}) frames (predict_t2v.py:288-291 trims the video to that)")
         in_dtype = x.dtype
         moments = []
         for b in range(x.shape[0]):

@@ -162,9 +162,9 @@ constexpr int ATT_LDS = 2 * ATT_STAGE;      // 32 KiB
 
 // WINDOW: sliding-window (band) attention of the SWA processor (processor.py:420, flash_attn_func(window_size=(w, w))):
 // query i sees key j iff |i - j| <= window.  Only the key tiles that intersect the band of the workgroup's 256 queries
-// are visited; inside them the band (and the sequence tail) is masked with a large FINITE negative score, so that a
-// query whose first visited tile holds none of its keys carries a finite running maximum (its garbage partial sums are
-// multiplied by exp2(-huge) = 0 as soon as its first real key arrives; every query sees at least itself).
+// are visited; inside them the band is masked with -inf.  A query whose visited tiles so far held none of its keys has a
+// running maximum of -inf: the exponent shift is then taken as 0 (every p = exp2(-inf) = 0, alpha = exp2(-inf) = 0 on
+// all-zero state) instead of forming -inf - (-inf); every query sees at least itself, so the final row sum is > 0.
 template <bool WINDOW>
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K, const unsigned short* __restrict__ Vt,
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
 
     int nt = (seq + ATT_KV - 1) / ATT_KV;
     int t_lo = 0;
-    const float MASKED = WINDOW ? -1.0e30f : -INFINITY;
+    const float MASKED = -INFINITY;
     if (WINDOW) {
         const int qblk0 = q_begin + qb * ATT_QB;          // the four waves share the K / V^T tiles: workgroup-wide band
         const int lo = qblk0 - window, hi_key = qblk0 + ATT_QB - 1 + window;
@@ -311,12 +311,13 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qi][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run[qi], mx * scale_log2e);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+                const float m_use = (WINDOW && m_new == -INFINITY) ? 0.f : m_new;   // no key of this query seen yet
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_use);
                 m_run[qi] = m_new;
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][r], scale_log2e, -m_new));
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][r], scale_log2e, -m_use));
                     psum += p;
                     pf[qi][r >> 3][r & 7] = (bf16_t)p;
                 }

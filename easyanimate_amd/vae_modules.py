@@ -304,8 +304,17 @@ class SpatialAttention(nn.Module):
         n = H * W
         xr = x.view(T, n, C)
         xn = _gn(self.group_norm, xr, act=False)
+        # the P.V product runs over K = n keys and the GEMMs want K % 64 == 0 / N % 8 == 0: 576x1008 gives n = 9072, 480x720
+        # gives 5400.  Keys / values are then padded to n_pad rows of zeros; the pad columns of the logits are set
+        # to -inf before the row softmax (probability exactly 0) and the pad columns of V^T are zero (to_v's bias is folded out).
+        n_pad = ops.round_up(n, 64)
+        if n_pad != n:
+            xk = torch.zeros((T, n_pad, C), dtype=xn.dtype, device=xn.device)
+            xk[:, :n] = xn
+        else:
+            xk = xn
         q = ops.gemm(xn, bf16_weight(self.to_q.weight), f32(self.to_q.bias), ops.EPI_BIAS)
-        k = ops.gemm(xn, bf16_weight(self.to_k.weight), f32(self.to_k.bias), ops.EPI_BIAS)
+        k = ops.gemm(xk, bf16_weight(self.to_k.weight), f32(self.to_k.bias), ops.EPI_BIAS)
         wv = bf16_weight(self.to_v.weight)
         # softmax rows sum to 1, so the value bias passes straight through attention: fold it into the out bias
         wo = bf16_weight(self.to_out.weight)
@@ -314,10 +323,12 @@ class SpatialAttention(nn.Module):
             b_eff = ops.linear_small_m(f32(self.to_v.bias).view(1, -1), wo, b_eff).view(-1)
         ones = derived(self.to_out.bias, "ones", lambda t: torch.ones(1, t.shape[0], dtype=torch.float32, device=t.device))
         out = torch.empty_like(xr)
-        logits = torch.empty((n, n), dtype=torch.float32, device=x.device)
+        logits = torch.empty((n, n_pad), dtype=torch.float32, device=x.device)
         for f in range(T):  # one frame at a time: [n, n] fp32 logits (1 GiB at 1024^2) stay a reusable buffer
-            vt = ops.gemm(wv, xn[f], None, ops.EPI_BIAS)                      # V^T [C, n]
+            vt = ops.gemm(wv, xk[f], None, ops.EPI_BIAS)                      # V^T [C, n_pad]
             ops.gemm(q[f], k[f], None, ops.EPI_F32_OUT, out=logits)           # Q K^T
+            if n_pad != n:
+                logits[:, n:] = float("-inf")
             p = ops.softmax_rows(logits, self.scale)
             o = ops.gemm(p, vt, None, ops.EPI_BIAS)                            # P V  [n, C]
             ops.gemm(o, wo, b_eff, ops.EPI_BIAS_GATE_RES, out=out[f], res=xr[f], gate=ones)

@@ -556,6 +556,38 @@ def swa_inputs(cfg, seed, B, Fr, H, W, T):
     return lat, enc
 
 
+@section("fp8")
+def gen_fp8(ns, shim):
+    # ---- fp8 weight storage, the reference's default GPU_memory_mode (predict_t2v.py:37,104,266; utils/fp8_optimization.py:
+    # 17-35): every parameter stored as float8_e4m3fn and up-cast to the compute dtype per call.  The reference's own
+    # wrappers run here on the CPU: bf16 compute through convert_weight_dtype_wrapper, and (the exact oracle) fp32 compute
+    # on the same fp8-rounded values.
+    from easyanimate.utils.fp8_optimization import convert_model_weight_to_float8, convert_weight_dtype_wrapper
+    cfg = dict(TINY)
+    m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+    shapes = _load_sd(m, 3, "stress")
+    g = _g(37)
+    B, Fr, H, W, T = 2, 3, 8, 12, 9
+    lat = torch.randn(B, 16, Fr, H, W, generator=g)
+    enc = torch.randn(B, T, cfg["text_embed_dim"], generator=g) * 3
+    t = torch.tensor([555.0, 555.0]).to(torch.bfloat16).float()
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+    cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+    m8 = copy.deepcopy(m).to(torch.bfloat16)            # predict_t2v.py loads with torch_dtype=float8_e4m3fn from a bf16 checkpoint
+    convert_model_weight_to_float8(m8)
+    assert all(p.dtype == torch.float8_e4m3fn for p in m8.parameters())
+    mq = copy.deepcopy(m)                               # fp32 compute on the fp8-representable values
+    mq.load_state_dict({k: v.float() for k, v in m8.state_dict().items()})
+    convert_weight_dtype_wrapper(m8, torch.bfloat16)
+    out8 = m8(lat.bfloat16(), t.bfloat16(), encoder_hidden_states=enc.bfloat16(), image_rotary_emb=(cos, sin), return_dict=False)[0]
+    outq = mq(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), return_dict=False)[0]
+    out0 = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), return_dict=False)[0]
+    print(f"  fp8 storage: reference bf16-through-wrappers vs fp32-on-fp8-values {_mse(out8.float(), outq):.3e}; the fp8 rounding itself "
+          f"moves the fp32 output by {_mse(outq, out0):.3e}")
+    torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style="stress", latents=lat, enc=enc, t=t, cos=cos, sin=sin, out=outq,
+                    out_bf16=out8.float(), out_unquantised=out0), os.path.join(OUT, "transformer_fp8_storage.pt"))
+
+
 @torch.no_grad()
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)

@@ -113,6 +113,26 @@ def test_transformer_after_norm_ref_clip_vs_golden(name):
     assert out.shape == g["out"].shape and mse < BAR
 
 
+def test_fp8_weight_storage_vs_reference_wrappers():
+    """SURVEY 8f rank 2, as a PARITY test: the reference's default memory mode stores every parameter as
+    float8_e4m3fn and up-casts per call (predict_t2v.py:37,104,266; utils/fp8_optimization.py:17-35).  The golden holds the
+    reference's own wrappers run on the CPU (bf16 compute) and fp32 compute on the same fp8-representable values; the product
+    model is put into the same storage mode (bf16 checkpoint values -> .to(float8_e4m3fn), as from_pretrained_2d does)."""
+    g = _load("transformer_fp8_storage.pt")
+    m = _model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    for p_ in m.parameters():
+        p_.data = p_.data.to(torch.float8_e4m3fn)              # convert_model_weight_to_float8
+    assert m.proj_out.weight.dtype == torch.float8_e4m3fn
+    with torch.no_grad():
+        out = m(g["latents"].to(DEV).bfloat16(), g["t"].to(DEV).bfloat16(), encoder_hidden_states=g["enc"].to(DEV).bfloat16(),
+                image_rotary_emb=(g["cos"], g["sin"]), return_dict=False)[0]
+    mse, floor = _mse(out.float(), g["out"]), _mse(g["out_bf16"], g["out"])
+    print(f"[parity] fp8 weight storage: new (fp8-stored, bf16 compute) vs reference fp32-on-fp8-values MSE={mse:.3e} | reference bf16 "
+          f"through its fp8 wrappers (floor) {floor:.3e} | new vs that {_mse(out.float(), g['out_bf16']):.3e} | the fp8 rounding itself "
+          f"moves the output by {_mse(g['out'], g['out_unquantised']):.3e}")
+    assert mse < BAR and mse < 0.1 * _mse(g["out"], g["out_unquantised"])
+
+
 @pytest.mark.parametrize("name", ["transformer_swa", "transformer_swa_mixed"])
 def test_transformer_swa_vs_golden(name):
     """sliding-window attention blocks (swa_layers; processor.py:320-459) -- strided cross keys (interval 2
