@@ -693,6 +693,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
 // The row-slab kernel on v_mfma_f32_16x16x32_bf16 (see gemm256_mi16_kernel in ea_gemm.hip: the shape sustains 14 % more under
 // the power limit).  Wave tile (256 / WM) voxels x 64 channels = MT x 4 tiles of 16 x 16; a (slab, dw) K-tile is four
 // phases (k32 step, M half); LDS rows swizzled with row & 7; 8-byte stores (4 channels per lane and tile).
+#ifndef EA_CONV_WIDE_PHASE
+#define EA_CONV_WIDE_PHASE 1   // build-time A/B switch (EA_HIPCC_EXTRA=-DEA_CONV_WIDE_PHASE=0)
+#endif
 template <int BN, bool UPS>
 __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     // UPS: nearest x2 up-sampling folded into the addressing -- output voxel u reads input voxel u >> 1, so the slab holds
@@ -700,6 +703,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     constexpr int NPIECE = UPS ? 17 : 33, PPW = UPS ? 3 : 5, NROW = UPS ? 130 : 258, ISTEP = UPS ? 1024 : 2048;
     constexpr int WN = BN / 64, WM = 8 / WN;
     constexpr int MT = 256 / WM / 16, MH = MT / 2;   // 16-voxel MFMA tiles per wave, per phase
+    constexpr bool WIDE_PHASE = (BN == 128) && (EA_CONV_WIDE_PHASE != 0);
     constexpr int WP = BN / 64;
     constexpr int A_STAGE = 34 * 1024, W_BYTES = BN * 128, W_BASE = 2 * A_STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -840,12 +844,48 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         __builtin_amdgcn_s_barrier();                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
     }
+    // BN = 128 (wave tile 64 voxels x 64 channels): a phase of 8 MFMAs (128 cycles) is too short next to the fixed cost of a
+    // phase (two barriers, the fragment-read latency): the whole k32 step -- both M halves, 16 MFMAs -- is one phase, two
+    // phases per tile.  The last phase retires its fragment reads before its first barrier (that frees the stage for the
+    // DMA the other wave group issues right after that barrier) and waits for the next tile's DMA.
+#define EA_C3_WPHASE(DW, KS, HAS_NEXT)   /* KS = k32 step */                                                \
+    {                                                                                                       \
+        bf16x8 af[MT];                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+            wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k[KS] + j * 2048));                          \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
+            af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[DW][KS] + i * ISTEP));                     \
+        if ((KS) == 0 && (DW) == 2 && (HAS_NEXT)) {                                                         \
+            next_slab();                                                                                    \
+            stage_a(a_dst, n_cb);                                                                           \
+        }                                                                                                   \
+        if ((KS) == 0 && (HAS_NEXT)) stage_w(w_dst, n_dtdh, n_cb, ((DW) + 1) % 3);                          \
+        if ((KS) == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);      \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
     // one tile = one (slab, dw): four k-steps; afterwards the W stage toggles (in place, on the fragment offsets)
 #define EA_C3_TILE(DW, HAS_NEXT)                                          \
-    EA_C3_PHASE(DW, 0, HAS_NEXT)                                          \
-    EA_C3_PHASE(DW, 1, HAS_NEXT)                                          \
-    EA_C3_PHASE(DW, 2, HAS_NEXT)                                          \
-    EA_C3_PHASE(DW, 3, HAS_NEXT)                                          \
+    if (WIDE_PHASE) {                                                     \
+        EA_C3_WPHASE(DW, 0, HAS_NEXT)                                     \
+        EA_C3_WPHASE(DW, 1, HAS_NEXT)                                     \
+    } else {                                                              \
+        EA_C3_PHASE(DW, 0, HAS_NEXT)                                      \
+        EA_C3_PHASE(DW, 1, HAS_NEXT)                                      \
+        EA_C3_PHASE(DW, 2, HAS_NEXT)                                      \
+        EA_C3_PHASE(DW, 3, HAS_NEXT)                                      \
+    }                                                                     \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) w_k[ks] += w_step;   \
     w_step = -w_step;                                                     \
     w_dst ^= 1;
@@ -880,6 +920,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef EA_C3_TILE
 #undef EA_C3_PHASE
+#undef EA_C3_WPHASE
 
     // ---- epilogue: lane owns voxel m (one per M tile), channels n0 .. n0+3 of every N tile
     const int64_t frame = (int64_t)p.H_out * p.W_out;
@@ -928,7 +969,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     if (p.gn_partial) {
         // lanes lr = 0..15 hold the 16 voxels of every M tile: fixed-order butterfly over them, then one (sum, sumsq) pair
         // per 4-channel bundle and wave -- the layout ea_groupnorm_finalize_bf16 reads (deterministic, no atomics)
-        const int64_t blk = ((int64_t)t_out * (p.gn_nblk / WM) + ((int64_t)h_out * tiles_w + (tm % tiles_w))) * WM + wr;
+        // with tdup the frame t_out >= 1 is stored twice (frames 2t-1 and 2t of y): both get the same partial sums
+        const bool dup = p.tdup && t_out >= 1;
+        const int64_t f0 = dup ? 2 * (int64_t)t_out - 1 : t_out;
+        const int64_t in_frame = ((int64_t)h_out * tiles_w + (tm % tiles_w)) * WM + wr;
+        const int64_t blk = f0 * p.gn_nblk + in_frame;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s_ = gs[j], q_ = gq[j];
@@ -942,6 +987,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
                 float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
                 dst[0] = s_;
                 dst[1] = q_;
+                if (dup) {
+                    dst += (int64_t)p.gn_nblk * (p.C_out >> 2) * 2;
+                    dst[0] = s_;
+                    dst[1] = q_;
+                }
             }
         }
     }
@@ -1043,11 +1093,12 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
             attr3_done = true;
         }
         const dim3 g3((unsigned)grid3), b3(512);
-        if (g_conv_mfma == 16 && gn_partial && !tdup) {
+        if (g_conv_mfma == 16 && gn_partial) {
             // fused GroupNorm statistics: one (sum, sumsq) pair per (frame, row tile, wave row, 4-channel bundle)
             const int wm = 8 / (bn / 64);
             const int64_t nblk = (int64_t)p.H_out * (p.W_out / 256) * wm;
-            const int64_t need = (int64_t)p.T_out * nblk * (C_out / 4) * 2;
+            const int64_t frames_y = (tdup && p.T_out > 1) ? 2 * (int64_t)p.T_out - 1 : p.T_out;
+            const int64_t need = frames_y * nblk * (C_out / 4) * 2;
             if (need <= gn_capacity && nblk < (1 << 30) && ((uintptr_t)gn_partial & 7) == 0) {
                 p.gn_partial = gn_partial;
                 p.gn_nblk = (int)nblk;

@@ -256,7 +256,7 @@ int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, con
  * activation (3.5 % of a 49 x 1024^2 decode).  Deterministic two-level form: the epilogue writes one (sum, sumsq) pair per
  * (frame, 256-voxel row tile, wave row, 4-channel bundle) into gn_partial (capacity in floats); ea_groupnorm_finalize_bf16
  * reduces them in a fixed order.  Only the row-slab kernel does this (3x3x3 / stride 1 / pad 1 layers whose output rows
- * are a multiple of 256 voxels wide, not with tdup): *gn_nblk_out (HOST int) is the number of partial blocks per frame
+ * are a multiple of 256 voxels wide; with tdup both copies of a frame get the sums): *gn_nblk_out (HOST int) is the number of partial blocks per frame
  * that were written, or 0 -- then the caller runs ea_groupnorm_stats_bf16 as before. */
 int ea_conv3d_cl_stats_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
                             const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,

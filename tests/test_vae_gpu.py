@@ -92,8 +92,9 @@ def test_conv3d_narrow_n(T, H, W, Ci, Co):
     assert rel < 4e-3
 
 
-@pytest.mark.parametrize("Ci,Co,ups,res", [(128, 128, False, True), (64, 256, False, False), (128, 128, True, False)])
-def test_groupnorm_stats_fused_in_conv_epilogue(Ci, Co, ups, res):
+@pytest.mark.parametrize("Ci,Co,ups,res,tdup", [(128, 128, False, True, False), (64, 256, False, False, False), (128, 128, True, False, False),
+                                                 (64, 256, True, False, True)])
+def test_groupnorm_stats_fused_in_conv_epilogue(Ci, Co, ups, res, tdup):
     """The row-slab convolution leaves the per-frame (sum, sumsq) partials of its output behind (ea_conv3d_cl_stats_bf16);
     GroupNorm + SiLU from those partials (finalize only) must equal GroupNorm + SiLU with its own statistics pass."""
     from easyanimate_amd import _lib, ops
@@ -106,10 +107,11 @@ def test_groupnorm_stats_fused_in_conv_epilogue(Ci, Co, ups, res):
     r = _bf(torch.randn(T, 256, 256, Co, generator=g)).to(DEV) if res else None
     gamma, beta = (1 + 0.3 * torch.randn(Co, generator=g)).to(DEV), (0.3 * torch.randn(Co, generator=g)).to(DEV)
     _lib.reset_counters()
-    y = ops.conv3d_cl(x, w, b, 3, ups=ups, res=r)
+    y = ops.conv3d_cl(x, w, b, 3, ups=ups, res=r, tdup=tdup)
     assert sum(v for k, v in _lib.counters().items() if k.startswith("conv_row16")) == 1
     assert hasattr(y, "gn_partial"), "the row-slab kernel served the call but left no partial sums"
-    y_plain = ops.conv3d_cl(x, w, b, 3, ups=ups, res=r, want_stats=False)
+    assert y.shape[0] == (2 * T - 1 if tdup else T)
+    y_plain = ops.conv3d_cl(x, w, b, 3, ups=ups, res=r, tdup=tdup, want_stats=False)
     assert torch.equal(y, y_plain) and not hasattr(y_plain, "gn_partial")
     a = ops.groupnorm_silu(y, gamma, beta, 32, 1e-6)
     ops.FUSED_GN_STATS = False
@@ -120,7 +122,7 @@ def test_groupnorm_stats_fused_in_conv_epilogue(Ci, Co, ups, res):
     ref = F.silu(F.group_norm(y.double().permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), 1e-6)).permute(0, 2, 3, 1)
     d = (a.float() - c.float()).abs()
     frac = (d > 0).float().mean().item()
-    print(f"[parity] GroupNorm from conv-epilogue partials vs own statistics pass ({Ci}->{Co}, ups {ups}, res {res}): "
+    print(f"[parity] GroupNorm from conv-epilogue partials vs own statistics pass ({Ci}->{Co}, ups {ups}, res {res}, tdup {tdup}): "
           f"{frac * 100:.4f} % of the outputs differ, max |d| {d.max().item():.3e}")
     assert frac < 1e-3 and d.max().item() <= 2.0 ** -6 * max(1.0, c.float().abs().max().item())
     err, rel = _rep("GroupNorm(fused stats)+SiLU vs fp64", a, ref)
