@@ -36,7 +36,8 @@ CONFIGS = {
     "c2": dict(desc="7B-class DiT (28 MMDiT layers, d=3072), 49f x 512x512, T=256, CFG batch 2, bf16",
                layers=28, frames=49, height=512, width=512),
     "c5": dict(desc="12B InP DiT (48 MMDiT layers, d=3072, in_channels 33), 49f x 768x768, T=256, CFG batch 2, bf16, "
-                    "random inpaint latents (I2V, BASELINE config 5: the denoise loop without its one VAE encode)",
+                    "random inpaint latents in the loop; the one VAE encode of the conditioning video is timed separately "
+                    "(i2v_conditioning) -- BASELINE config 5 on ONE of its four GPUs",
                layers=48, frames=49, height=768, width=768, in_channels=33),
     "tiny": dict(desc="2-layer d=3072 DiT, 5f x 128x128 (debug)", layers=2, frames=5, height=128, width=128),
 }
@@ -319,6 +320,33 @@ def main():
         del model, pipe, latents, embeds, kt
         torch.cuda.empty_cache()
         out["vae"] = vae_section(cpu=not args.no_cpu_baseline)
+    if rank == 0 and world == 1 and not args.no_vae and args.config == "c5" and not emu:
+        # BASELINE config 5 = the denoise loop PLUS its one VAE encode of the masked conditioning video (predict_i2v.py:
+        # pipeline_easyanimate_inpaint.py:1346-1383): timed here through the product pipeline method, reported beside the loop
+        del model, pipe, latents, embeds, kt
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_vae
+        from easyanimate_amd.pipeline import EasyAnimateInpaintPipeline, get_image_to_video_latent
+        vae = bench_vae.build_vae()
+
+        class _T:   # the two transformer attributes inpaint_conditioning reads
+            resize_inpaint_mask_directly = True
+            config = {"add_noise_in_inpaint_model": False}
+        ip = EasyAnimateInpaintPipeline(vae=vae, transformer=None, scheduler=None)
+        ip.transformer = _T()
+        video, mask = get_image_to_video_latent(torch.rand(3, cfg["height"], cfg["width"]), cfg["frames"])
+        with torch.no_grad():
+            ip.inpaint_conditioning(video, mask, torch.bfloat16, device, True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cond = ip.inpaint_conditioning(video, mask, torch.bfloat16, device, True)
+            torch.cuda.synchronize()
+        out["i2v_conditioning"] = {"seconds": time.perf_counter() - t0, "inpaint_latents_shape": list(cond.shape),
+                                   "what": "host mask / masked-video construction + upload + one VAE encode of 49 frames + mask resize "
+                                           "(once per pipeline call, not per step)"}
+        del vae, ip
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t_block, sample = cpu_baseline(S)
         est_step_s = t_block * B * L

@@ -451,6 +451,48 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
                             stream);
 }
 
+extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
+                                              int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin,
+                                              int q_end, int seg_rows, int n_seg, int skip_seg, int64_t seg_stride,
+                                              int kv_valid, float scale, float* state, int flags, void* stream) {
+    EA_REQUIRE(q && k_seg0 && vt_seg0 && (out || (flags & 2)), "ea_attention_fwd_segments_bf16: null tensor");
+    EA_REQUIRE(batch > 0 && heads > 0 && q_pad % ATT_QB == 0 && q_begin >= 0 && q_begin <= q_end && q_end <= q_pad,
+               "ea_attention_fwd_segments_bf16: bad query range");
+    EA_REQUIRE(seg_rows > 0 && seg_rows % ATT_KV == 0 && n_seg >= 1 && seg_stride >= 0,
+               "ea_attention_fwd_segments_bf16: segment rows must be a positive multiple of 64");
+    const int used = n_seg - ((skip_seg >= 0 && skip_seg < n_seg) ? 1 : 0);
+    EA_REQUIRE(used >= 1 && kv_valid > 0 && (int64_t)kv_valid <= (int64_t)used * seg_rows && kv_valid > (int64_t)(used - 1) * seg_rows,
+               "ea_attention_fwd_segments_bf16: kv_valid must end inside the last used segment");
+    EA_REQUIRE((flags & ~3) == 0 && (flags == 0 || state), "ea_attention_fwd_segments_bf16: bad flags / missing state buffer");
+    EA_REQUIRE(fabsf(scale * 1.4426950408889634f - 1.0f) < 1e-6f,
+               "ea_attention_fwd_segments_bf16: the softmax scale must be folded into Q (scale = ln 2)");
+    EA_REQUIRE((((uintptr_t)q | (uintptr_t)k_seg0 | (uintptr_t)vt_seg0) & 15) == 0 && seg_stride % 8 == 0,
+               "ea_attention_fwd_segments_bf16: pointers / segment stride must be 16-byte aligned");
+    if (q_end == q_begin) return EA_OK;
+    const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
+    const int bh = batch * heads;
+    const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
+    EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd_segments_bf16: grid too large");
+    AttSegments sg;
+    sg.rows = seg_rows; sg.tiles = seg_rows / ATT_KV; sg.skip = (skip_seg >= 0 && skip_seg < n_seg) ? skip_seg : n_seg;
+    sg.total_tiles = used * sg.tiles; sg.stride = seg_stride;
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* o16 = (unsigned short*)out;
+    f32x4* st4 = reinterpret_cast<f32x4*>(state);
+    ea_count("attention_v3_segments");
+#define EA_ATT_SEG(MODE) hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE, true>), grid, blk, ATT_LDS, st, q, k_seg0, vt_seg0, o16, \
+                                            out_batch_stride, heads, bh, 0, kv_valid, q_pad, q_begin, q_end, nqb, 1.0f, st4, sg)
+    switch (flags) {
+        case 0: EA_ATT_SEG(0); break;
+        case 1: EA_ATT_SEG(1); break;
+        case 2: EA_ATT_SEG(2); break;
+        default: EA_ATT_SEG(3); break;
+    }
+#undef EA_ATT_SEG
+    return ea_check_launch("ea_attention_fwd_segments_bf16");
+}
+
 extern "C" int ea_attention_window_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
                                             int64_t out_batch_stride, int batch, int heads, int seq, int s_pad, int window,
                                             float scale, void* stream) {

@@ -816,6 +816,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = i * 16 + lr;
+        // the token's cos / sin rows first: their latency is covered by the LayerNorm arithmetic below
+        f32x4_t c4[4], s4[4];
+        if (q.cosT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t tr = (int64_t)(tok0 + r) * 64 + j * 16 + lq * 4;
+                c4[j] = *reinterpret_cast<const f32x4_t*>(q.cosT + tr);
+                s4[j] = *reinterpret_cast<const f32x4_t*>(q.sinT + tr);
+            }
+        }
         float v[4][4];
         float s = 0.f;
 #pragma unroll
@@ -846,14 +856,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
                 v[j][e] = bf16_bits_to_f32(f32_to_bf16_bits((v[j][e] - mean) * rstd * gw4[j][e] + gb4[j][e]));
             u16x4 o;
             if (q.cosT) {
-                const int64_t tr = (int64_t)(tok0 + r) * 64 + j * 16 + lq * 4;
-                const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(q.cosT + tr);
-                const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(q.sinT + tr);
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     const float x0 = v[j][e], x1 = v[j][e + 1];
-                    o[e] = f32_to_bf16_bits((x0 * c4[e] - x1 * s4[e]) * osc);
-                    o[e + 1] = f32_to_bf16_bits((x1 * c4[e + 1] + x0 * s4[e + 1]) * osc);
+                    o[e] = f32_to_bf16_bits((x0 * c4[j][e] - x1 * s4[j][e]) * osc);
+                    o[e + 1] = f32_to_bf16_bits((x1 * c4[j][e + 1] + x0 * s4[j][e + 1]) * osc);
                 }
             } else {
 #pragma unroll

@@ -249,6 +249,29 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scal
     return out
 
 
+def attention_segments(q: torch.Tensor, gathered: torch.Tensor, n_seg: int, skip_seg: int, seg_rows: int, kv_valid: int,
+                       q_begin: int, q_end: int, state: Optional[torch.Tensor] = None, load_state: bool = False,
+                       store_state: bool = False, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Attention of query rows [q_begin, q_end) over the key segments of an all-gathered buffer `gathered`
+    [n_seg, 2, B, H, seg_rows*64] (per rank: K rows [B,H,seg_rows,64], then V^T [B,H,64,seg_rows]), skipping segment
+    skip_seg; softmax scale folded into Q."""
+    _dev(q, gathered, out, state)
+    B, H, q_pad, dh = q.shape
+    assert dh == 64 and q.is_contiguous() and gathered.is_contiguous() and gathered.dtype == _BF16
+    assert gathered.numel() == n_seg * 2 * B * H * seg_rows * 64
+    flags = (1 if load_state else 0) | (2 if store_state else 0)
+    if flags:
+        assert state is not None and state.dtype == _F32 and state.numel() * 4 >= _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)
+    if not store_state:
+        assert out is not None and out.stride(2) == 1 and out.stride(1) == H * 64 and out.shape[1] >= q_end
+    half = B * H * seg_rows * 64
+    base = gathered.data_ptr()
+    _timed("attention", lambda: _lib.call("ea_attention_fwd_segments_bf16", _p(q), ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * half),
+                                          _p(out), out.stride(0) if out is not None else 0, B, H, q_pad, q_begin, q_end, seg_rows,
+                                          n_seg, skip_seg, 2 * half, kv_valid, FOLDED_ATTN_SCALE, _p(state), flags, _stream()))
+    return out
+
+
 def attention_window(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, window: int, scale: float,
                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Band attention |i - j| <= window over rows [0, seq): q,k bf16 [B,H,S_pad,64], vt [B,H,64,S_pad] -> [B,seq,H*64]."""

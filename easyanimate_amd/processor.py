@@ -83,9 +83,15 @@ class EasyAnimateAttnProcessor2_0:
             for i, (lo, hi) in enumerate(lay.local_ranges):
                 ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
                                     store_state=True)
-            sp.exchange_finish(pending, ws, v_off)
-            ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lay.remote_begin, lay.remote_end,
-                                state=state, load_state=True, out=o)
+            gathered = sp.exchange_finish(pending, ws, v_off)
+            if gathered is None:
+                # bring-up mode (a world of one rank with force_exchange): the "remote" keys are the second half of its own rows
+                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lay.remote_begin, lay.remote_end,
+                                    state=state, load_state=True, out=o)
+            else:
+                # the other ranks' shards are read where the all-gather left them (rank order, own segment skipped)
+                ops.attention_segments(ws["q"], gathered, sp.size, sp.rank, sp.n_loc, lay.remote_end - lay.remote_begin, 0, S,
+                                       state=state, load_state=True, out=o)
         elif v_off != T:
             # single sequence rank with unaligned text: rows [T, v_off) are padding between the two key ranges
             state = _attention_state(B, H, S, dev)

@@ -13,8 +13,9 @@ Two orthogonal axes, chosen per forward call:
   QKV / out / FFN GEMMs, RoPE, residuals) is local.  The one exchange per block is an all-gather of the K rows /
   V^T columns of the shards.  It is *asynchronous*: while it is in flight the rank already attends its queries over
   its LOCAL keys (text + own shard) with `ea_attention_fwd_range_bf16(..., flags=store state)`; when the remote
-  shards have landed a second launch resumes from that state over the REMOTE keys.  Softmax does not care about the
-  key order, so each rank keeps a private row layout
+  shards have landed a second launch resumes from that state over the REMOTE keys, which it reads straight out of the
+  all-gather's output buffer (segment addressing, ea_attention_fwd_segments_bf16: no unpack copies between the two
+  passes).  Softmax does not care about the key order, so each rank keeps a private row layout
 
         [ text 0..T | (gap to a multiple of 64) | own shard | remote shards in rank order | pad ]
 
@@ -187,23 +188,33 @@ class SequenceParallel:
         work = dist.all_gather_into_tensor(recv, send.view(-1), group=self.axis.group, async_op=True)
         return (work, recv, send)
 
-    def exchange_finish(self, handle, ws: dict, v_off: int) -> None:
-        """Wait for the all-gather (a stream-level wait with RCCL) and scatter the remote shards into their slots."""
+    def exchange_finish(self, handle, ws: dict, v_off: int, unpack: Optional[bool] = None):
+        """Wait for the all-gather (a stream-level wait with RCCL).  Returns the gathered buffer viewed as
+        [P, 2, B, H, n_loc*64] (per rank: its K rows, then its V^T columns): on the GPU the attention kernel reads the
+        remote shards straight out of it (ea_attention_fwd_segments_bf16 -- no unpack copies on the critical path between the
+        local-key and the remote-key pass).  unpack=True (the default on CPU tensors: the gloo tests and the oracle
+        arithmetic they run) additionally scatters the remote shards into their slots of the rank-private layout."""
         if handle is None:
-            return
+            return None
         work, recv, send = handle
         if work is not None:
             work.wait()
+        if self.size == 1:      # bring-up mode: the collective ran, its result (== what was sent) is not needed
+            return None
         k, vt = ws["k"], ws["vt"]
         B, H = k.shape[0], k.shape[1]
         nl = self.n_loc
         recv = recv.view((self.size,) + tuple(send.shape))
-        for r in range(self.size):
-            if r == self.rank:
-                continue
-            o = v_off + self.slot(r) * nl
-            k[:, :, o:o + nl] = recv[r, 0].reshape(B, H, nl, 64)
-            vt[:, :, :, o:o + nl] = recv[r, 1].reshape(B, H, 64, nl)
+        if unpack is None:
+            unpack = not k.is_cuda
+        if unpack:
+            for r in range(self.size):
+                if r == self.rank:
+                    continue
+                o = v_off + self.slot(r) * nl
+                k[:, :, o:o + nl] = recv[r, 0].reshape(B, H, nl, 64)
+                vt[:, :, :, o:o + nl] = recv[r, 1].reshape(B, H, 64, nl)
+        return recv
 
     def all_reduce_sums(self, sums: torch.Tensor, n: int):
         """TeaCache: add the rel-L1 partial sums / element counts of every rank (batch slices and token shards)."""
@@ -255,22 +266,19 @@ class EmulatedRank(SequenceParallel):
         self.axis = self._flat
         self.n_total = 0
         self.n_loc = 0
-        self._filled = set()
+        self._filled = {}
 
     def exchange_start(self, ws: dict, v_off: int):
         if self.size == 1:
             return None
-        key = (ws["k"].data_ptr(), self.size, self.n_loc)
-        if key not in self._filled:   # remote slots: N(0,1) keys / values, written once (zeros would run at a higher clock)
-            lo = v_off + self.n_loc
-            hi = v_off + self.size * self.n_loc
-            ws["k"][:, :, lo:hi].normal_()
-            ws["vt"][:, :, :, lo:hi].normal_()
-            self._filled.add(key)
-        return None
+        k = ws["k"]
+        key = (tuple(k.shape), self.size, self.n_loc, str(k.device))
+        if key not in self._filled:   # the gathered buffer: N(0,1) keys / values, written once (zeros would run at a higher clock)
+            self._filled = {key: torch.randn((self.size, 2, k.shape[0], k.shape[1], self.n_loc * 64), device=k.device).to(k.dtype)}
+        return self._filled[key]
 
-    def exchange_finish(self, handle, ws: dict, v_off: int) -> None:
-        return None
+    def exchange_finish(self, handle, ws: dict, v_off: int, unpack: Optional[bool] = None):
+        return handle
 
     def all_reduce_sums(self, sums: torch.Tensor, n: int):
         return sums.to(torch.float64) * self.world, n * self.world

@@ -158,6 +158,19 @@ int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt,
                           int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
                           int q_begin, int q_end, float scale, void* stream);
 
+/* The resumable attention over keys that live in SEGMENTS: the other ranks' K / V^T shards exactly where
+ * all_gather_into_tensor left them (sequence parallelism; no unpack copies into a contiguous key layout).  Segment g
+ * (g = 0 .. n_seg-1, rank order) holds K as [batch*heads, seg_rows, 64] at k_seg0 + g*seg_stride and V^T as
+ * [batch*heads, 64, seg_rows] at vt_seg0 + g*seg_stride (elements); segment skip_seg (the caller's own shard, already
+ * attended from its local buffers; pass -1 to use every segment) is left out.  kv_valid = number of valid keys over the
+ * used segments in order (all full except possibly the last).  q / out / state / flags / q_begin / q_end as
+ * ea_attention_fwd_range_bf16 (q: [batch, heads, q_pad, 64]); the softmax scale must be folded into Q (scale = ln 2).
+ * seg_rows % 64 == 0. */
+int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
+                                   int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin, int q_end,
+                                   int seg_rows, int n_seg, int skip_seg, int64_t seg_stride, int kv_valid, float scale,
+                                   float* state, int flags, void* stream);
+
 /* Sliding-window (band) attention of EasyAnimateSWAttnProcessor2_0 (processor.py:420: flash_attn_func(q, k, v,
  * window_size=(w, w)) on the six re-ordered head groups): query row i attends key rows j with |i - j| <= window, rows
  * [0, seq) of q / k / vt (same layouts as ea_attention_fwd_bf16), softmax(QK^T * scale) V.  Only key tiles intersecting

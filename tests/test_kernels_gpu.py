@@ -554,6 +554,57 @@ def test_attention_resumable_key_ranges(splits, folded, attn_kernel):
     assert (out[:, qb:qe].float() - one[:, qb:qe].float()).abs().max().item() < 0.02
 
 
+@pytest.mark.parametrize("P,rank,nl,n_last", [(2, 0, 128, 128), (2, 1, 128, 70), (4, 1, 192, 192), (4, 3, 192, 100), (4, 0, 64, 5), (3, 2, 320, 17)])
+def test_attention_segments_equals_contiguous_keys(P, rank, nl, n_last):
+    """ea_attention_fwd_segments_bf16 (sequence parallelism: the remote K / V^T shards are read where all_gather_into_tensor
+    left them, own segment skipped) against ea_attention_fwd_range_bf16 over the same keys copied into one contiguous
+    layout -- same key order, same tiles, so every bit must agree; with and without a carried-in state."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(31 + P + rank)
+    B, H, T, n_own = 2, 3, 64, (n_last if rank == P - 1 else nl)
+    S_q = T + n_own
+    q_pad = ops.round_up(S_q, 256)
+    q = torch.zeros(B, H, q_pad, 64, dtype=torch.bfloat16, device=DEV)
+    q[:, :, :S_q] = _bf(torch.randn(B, H, S_q, 64, generator=g) * 0.3).to(DEV)
+    gathered = torch.zeros(P, 2, B, H, nl * 64, dtype=torch.bfloat16, device=DEV)
+    shard_rows = [nl] * (P - 1) + [n_last]
+    for r in range(P):
+        gathered[r, 0].view(B, H, nl, 64)[:, :, :shard_rows[r]] = _bf(torch.randn(B, H, shard_rows[r], 64, generator=g)).to(DEV)
+        gathered[r, 1].view(B, H, 64, nl)[:, :, :, :shard_rows[r]] = _bf(torch.randn(B, H, 64, shard_rows[r], generator=g)).to(DEV)
+    others = [r for r in range(P) if r != rank]
+    kv_valid = sum(nl for r in others[:-1]) + shard_rows[others[-1]]
+    # contiguous copy of the same keys, in the same order
+    s_pad = ops.round_up(len(others) * nl, 256)
+    k = torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=DEV)
+    for i, r in enumerate(others):
+        k[:, :, i * nl:(i + 1) * nl] = gathered[r, 0].view(B, H, nl, 64)
+        vt[:, :, :, i * nl:(i + 1) * nl] = gathered[r, 1].view(B, H, 64, nl)
+    kk = torch.zeros(B, H, max(s_pad, q_pad), 64, dtype=torch.bfloat16, device=DEV)
+    vv = torch.zeros(B, H, 64, max(s_pad, q_pad), dtype=torch.bfloat16, device=DEV)
+    qq = torch.zeros_like(kk)
+    kk[:, :, :s_pad], vv[:, :, :, :s_pad], qq[:, :, :q_pad] = k, vt, q
+    o_ref = torch.empty(B, S_q, H * 64, dtype=torch.bfloat16, device=DEV)
+    ops.attention_range(qq, kk, vv, ops.FOLDED_ATTN_SCALE, 0, S_q, 0, kv_valid, out=o_ref)
+    o_seg = torch.empty_like(o_ref)
+    ops.attention_segments(q, gathered, P, rank, nl, kv_valid, 0, S_q, out=o_seg)
+    assert torch.equal(o_seg, o_ref)
+    # resumed from a stored state (the local-key pass of the sequence-parallel block)
+    st_a = ops.attention_state(B, H, 0, S_q, DEV)
+    st_b = ops.attention_state(B, H, 0, S_q, DEV)
+    kl = _bf(torch.randn(B, H, 256, 64, generator=g)).to(DEV)
+    kloc = torch.zeros_like(qq); vloc = torch.zeros_like(vv)
+    kloc[:, :, :256] = kl
+    vloc[:, :, :, :256] = _bf(torch.randn(B, H, 64, 256, generator=g)).to(DEV)
+    ops.attention_range(qq, kloc, vloc, ops.FOLDED_ATTN_SCALE, 0, S_q, 0, 200, state=st_a, store_state=True)
+    st_b.copy_(st_a)
+    kq = torch.zeros(B, H, q_pad, 64, dtype=torch.bfloat16, device=DEV)
+    o1, o2 = torch.empty_like(o_ref), torch.empty_like(o_ref)
+    ops.attention_range(qq, kk, vv, ops.FOLDED_ATTN_SCALE, 0, S_q, 0, kv_valid, state=st_a, load_state=True, out=o1)
+    ops.attention_segments(q, gathered, P, rank, nl, kv_valid, 0, S_q, state=st_b, load_state=True, out=o2)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o_ref)
+
+
 def test_attention_full_size_config3():
     """BASELINE.json config 3 sequence (S = 53 504 = 836 key tiles, 209 query blocks), 2 heads: the product kernel against
     a chunked fp32 torch evaluation of the same attention on the GPU (checker only), plus the size-independent

@@ -210,6 +210,6 @@ def test_emulated_rank_runs_the_rank_local_work():
             assert out.shape == ref.shape and torch.isfinite(out.float()).all()
             sp = m.sequence_parallel
             assert sp.axis.cfg_degree == 2 and sp.size == P // 2
-            expect = g["cfg"]["num_layers"] * (1 if sp.size == 1 else 2)
-            assert cnt.get("attention_v3", 0) == expect, (P, r, cnt)
+            L = g["cfg"]["num_layers"]   # per block: one local-key pass (+ one pass over the gathered segments)
+            assert cnt.get("attention_v3", 0) == L and cnt.get("attention_v3_segments", 0) == (0 if sp.size == 1 else L), (P, r, cnt)
     m.sequence_parallel = None
