@@ -239,3 +239,32 @@ def test_restatement_swa_vs_golden(name):
     with torch.no_grad():
         out = R.transformer_forward(sd, g["cfg"], lat, g["t"], enc, rope)
     _close(out, g["out"].float(), 1.5e-3, "swa transformer (fixture stored fp16)")
+
+
+def test_where_the_50_step_loop_error_comes_from():
+    """Why the product keeps fp32 master latents: on the oracle, a bf16 model stepping fp32 latents
+    ends 50 CFG-6 steps well inside the 1e-4 bar, while an fp32 model whose latents are stored in bf16 after every Euler
+    update -- the reference's bf16 bookkeeping, pipeline_easyanimate.py:1111 -- ends several times outside it, at the
+    distance of the reference's own bf16 run."""
+    g = _load("denoise_loop_50_bf16in.pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    sdb = {k: v.bfloat16() for k, v in sd.items()}
+    rope, ref = (g["cos"], g["sin"]), g["trace"][50]
+
+    def loop(model_dt, lat_dt):
+        ts, sig = R.flow_sigmas(50)
+        x = g["latents"].to(lat_dt)
+        w = sdb if model_dt == torch.bfloat16 else sd
+        for i, t in enumerate(ts):
+            li = torch.cat([x] * 2).to(model_dt)
+            v = R.transformer_forward(w, g["cfg"], li, torch.tensor([t] * 2).to(model_dt), g["enc"].to(model_dt), rope).float()
+            vu, vt = v.chunk(2)
+            x = (x.float() + (sig[i + 1] - sig[i]) * (vu + 6.0 * (vt - vu))).to(lat_dt)
+        return ((x.double() - ref.double()) ** 2).mean().item()
+    with torch.no_grad():
+        bf16_model_fp32_latents = loop(torch.bfloat16, torch.float32)
+        fp32_model_bf16_latents = loop(torch.float32, torch.bfloat16)
+    floor = ((g["trace_bf16"][50].double() - ref.double()) ** 2).mean().item()
+    print(f"[parity] 50-step loop: bf16 model + fp32 latents {bf16_model_fp32_latents:.3e}; fp32 model + bf16 latents "
+          f"{fp32_model_bf16_latents:.3e}; reference bf16 run {floor:.3e}")
+    assert bf16_model_fp32_latents < 1e-4 < fp32_model_bf16_latents and fp32_model_bf16_latents > 0.5 * floor
