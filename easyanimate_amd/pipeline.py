@@ -158,11 +158,102 @@ class EasyAnimatePipeline:
         video = self.vae.decode(latents, postprocess=True)[0]
         return video.cpu().float().numpy()
 
-    def _embeds(self, prompt_embeds, negative_prompt_embeds, device, dtype):
+    def encode_prompt(self, prompt, device, dtype, num_images_per_prompt: int = 1, do_classifier_free_guidance: bool = True,
+                      negative_prompt=None, prompt_embeds=None, negative_prompt_embeds=None, prompt_attention_mask=None,
+                      negative_prompt_attention_mask=None, max_sequence_length: Optional[int] = None,
+                      text_encoder_index: int = 0, actual_max_sequence_length: int = 256):
+        """reference: pipeline_easyanimate.py:306-580.  The glue around the text encoder -- tokenisation (BERT / T5 tokenizers
+        directly, anything else through its chat template), the encoder call (last hidden state for BERT / T5, the
+        PENULTIMATE hidden state of the LLM, :438-447), repetition per image, the same for the negative prompt.  The encoder
+        itself is whatever `transformers` model sits in the pipeline's text_encoder slot (Qwen2-VL-7B for V5.1): it runs
+        once per call and is not part of this build's kernels.
+        -> (prompt_embeds, negative_prompt_embeds, prompt_attention_mask, negative_prompt_attention_mask)"""
+        tokenizer = [self.tokenizer, self.tokenizer_2][text_encoder_index]
+        text_encoder = [self.text_encoder, self.text_encoder_2][text_encoder_index]
+        if max_sequence_length is None:
+            max_length = min(tokenizer.model_max_length, actual_max_sequence_length)
+        else:
+            max_length = max_sequence_length
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        use_mask = bool(self.transformer.config.get("enable_text_attention_mask", True))
+
+        def classic(tok_cls_names=("BertTokenizer", "T5Tokenizer")):
+            return type(tokenizer).__name__ in tok_cls_names
+
+        def run_classic(texts, length, with_retry_mask):
+            ti = tokenizer(texts, padding="max_length", max_length=length, truncation=True, return_attention_mask=True,
+                           return_tensors="pt")
+            ids = ti.input_ids
+            if ids.shape[-1] > actual_max_sequence_length:
+                re = tokenizer.batch_decode(ids[:, :actual_max_sequence_length], skip_special_tokens=True)
+                ti = tokenizer(re, padding="max_length", max_length=length, truncation=True, return_attention_mask=True,
+                               return_tensors="pt")
+                ids = ti.input_ids
+            mask = ti.attention_mask.to(device)
+            out = text_encoder(ids.to(device), attention_mask=mask) if use_mask else text_encoder(ids.to(device))
+            return out[0], mask
+
+        def run_llm(p):
+            if p is not None and isinstance(p, str):
+                messages = [{"role": "user", "content": [{"type": "text", "text": p}]}]
+            else:
+                messages = [{"role": "user", "content": [{"type": "text", "text": _p}]} for _p in p]
+            text = tokenizer.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+            ti = tokenizer(text=[text], padding="max_length", max_length=max_length, truncation=True, return_attention_mask=True,
+                           padding_side="right", return_tensors="pt")
+            ti = ti.to(text_encoder.device)
+            if not use_mask:
+                raise ValueError("LLM needs attention_mask")
+            hs = text_encoder(input_ids=ti.input_ids, attention_mask=ti.attention_mask, output_hidden_states=True).hidden_states[-2]
+            return hs, ti.attention_mask
+
+        if prompt_embeds is None:
+            prompt_embeds, prompt_attention_mask = run_classic(prompt, max_length, True) if classic() else run_llm(prompt)
+            prompt_attention_mask = prompt_attention_mask.repeat(num_images_per_prompt, 1)
+        prompt_embeds = prompt_embeds.to(dtype=dtype, device=device)
+        bs_embed, seq_len, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(bs_embed * num_images_per_prompt, seq_len, -1)
+        prompt_attention_mask = prompt_attention_mask.to(device=device)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            if classic():
+                if negative_prompt is None:
+                    uncond = [""] * batch_size
+                elif prompt is not None and type(prompt) is not type(negative_prompt):
+                    raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} != {type(prompt)}.")
+                elif isinstance(negative_prompt, str):
+                    uncond = [negative_prompt]
+                elif batch_size != len(negative_prompt):
+                    raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size {batch_size}.")
+                else:
+                    uncond = negative_prompt
+                negative_prompt_embeds, negative_prompt_attention_mask = run_classic(uncond, prompt_embeds.shape[1], False)
+            else:
+                negative_prompt_embeds, negative_prompt_attention_mask = run_llm(negative_prompt)
+            negative_prompt_attention_mask = negative_prompt_attention_mask.repeat(num_images_per_prompt, 1)
+        if do_classifier_free_guidance:
+            seq_len = negative_prompt_embeds.shape[1]
+            negative_prompt_embeds = negative_prompt_embeds.to(dtype=dtype, device=device)
+            negative_prompt_embeds = negative_prompt_embeds.repeat(1, num_images_per_prompt, 1).view(batch_size * num_images_per_prompt, seq_len, -1)
+            negative_prompt_attention_mask = negative_prompt_attention_mask.to(device=device)
+        return prompt_embeds, negative_prompt_embeds, prompt_attention_mask, negative_prompt_attention_mask
+
+    def _embeds(self, prompt_embeds, negative_prompt_embeds, device, dtype, prompt=None, negative_prompt=None, index: int = 0):
+        """[negative | positive] embeddings of encoder `index` (:920-1056): from the given embeddings, or -- when the
+        pipeline holds that tokenizer / text encoder -- from the prompts through encode_prompt."""
+        tok = [self.tokenizer, self.tokenizer_2][index]
+        enc = [self.text_encoder, self.text_encoder_2][index]
+        if prompt_embeds is None and prompt is not None and tok is not None and enc is not None:
+            prompt_embeds, negative_prompt_embeds, _, _ = self.encode_prompt(
+                prompt, device, dtype, 1, self.do_classifier_free_guidance, negative_prompt, text_encoder_index=index)
         if prompt_embeds is None:
             raise NotImplementedError(
-                "text encoding (Qwen2-VL / T5 / BERT) is out of scope of this build: pass prompt_embeds and "
-                "negative_prompt_embeds (SURVEY.md section 2 row 8)")
+                "no prompt embeddings and no text encoder in the pipeline: pass prompt_embeds / negative_prompt_embeds, or put a "
+                "transformers text encoder + tokenizer into the text_encoder / tokenizer slots (SURVEY.md section 2 row 8)")
         pe = prompt_embeds.to(device=device, dtype=dtype)
         if self.do_classifier_free_guidance:
             if negative_prompt_embeds is None:
@@ -218,7 +309,7 @@ class EasyAnimatePipeline:
         self._interrupt = False
         device = self.transformer.device
         dtype = self.transformer.dtype
-        pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype)
+        pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype, prompt, negative_prompt, 0)
         timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, mu=1)
         self._num_timesteps = len(timesteps)
         nc = self.transformer.config.in_channels
@@ -226,8 +317,8 @@ class EasyAnimatePipeline:
                                        generator, latents)
         rope = self.rotary_embedding(height, width, latents.size(2))
         pe2 = None
-        if prompt_embeds_2 is not None:   # V5 two-encoder checkpoints (text_proj_t5)
-            pe2 = self._embeds(prompt_embeds_2, negative_prompt_embeds_2, device, dtype)
+        if prompt_embeds_2 is not None or (prompt is not None and self.tokenizer_2 is not None):   # V5 two-encoder checkpoints
+            pe2 = self._embeds(prompt_embeds_2, negative_prompt_embeds_2, device, dtype, prompt, negative_prompt, 1)
         latents = self.denoise(latents, pe, rope, timesteps, guidance_scale, prompt_embeds_2=pe2,
                                callback_on_step_end=callback_on_step_end, guidance_rescale=guidance_rescale)
         return self._output(latents, output_type, return_dict)
@@ -351,8 +442,10 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
         self._interrupt = False
         device = self.transformer.device
         dtype = self.transformer.dtype
-        pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype)
-        pe2 = self._embeds(prompt_embeds_2, negative_prompt_embeds_2, device, dtype) if prompt_embeds_2 is not None else None
+        pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype, prompt, negative_prompt, 0)
+        pe2 = None
+        if prompt_embeds_2 is not None or (prompt is not None and self.tokenizer_2 is not None):
+            pe2 = self._embeds(prompt_embeds_2, negative_prompt_embeds_2, device, dtype, prompt, negative_prompt, 1)
         timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, mu=1)
         timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
         self._num_timesteps = len(timesteps)

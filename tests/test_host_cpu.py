@@ -180,3 +180,96 @@ def test_loaders_round_trip_synthetic_checkpoint(tmp_path):
     assert s.config.shift == 1.0 and s.config.use_dynamic_shifting is False
     with pytest.raises(RuntimeError, match="does not exist"):
         T.from_pretrained_2d(str(tmp_path / "nope"), subfolder="transformer")
+
+
+class _StubLLMTokenizer:
+    """Stands in for Qwen2Tokenizer (vocabulary files are not available offline): a chat template and a byte-level
+    tokenisation with right padding -- only the CALL PROTOCOL of pipeline_easyanimate.py:421-447 matters here."""
+    model_max_length = 32768
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+        assert tokenize is False and add_generation_prompt
+        return "".join(f"<|im_start|>{m['role']}\n{m['content'][0]['text']}<|im_end|>\n" for m in messages) + "<|im_start|>assistant\n"
+
+    def __call__(self, text=None, padding=None, max_length=None, truncation=None, return_attention_mask=None, padding_side=None,
+                 return_tensors=None):
+        assert padding == "max_length" and truncation and return_attention_mask and padding_side == "right" and return_tensors == "pt"
+        rows, masks = [], []
+        for t in text:
+            ids = [3 + b % 97 for b in t.encode()][:max_length]
+            masks.append([1] * len(ids) + [0] * (max_length - len(ids)))
+            rows.append(ids + [0] * (max_length - len(ids)))
+
+        class _Enc(dict):
+            input_ids = torch.tensor(rows)
+            attention_mask = torch.tensor(masks)
+
+            def to(self, device):
+                return self
+        return _Enc()
+
+
+class _TinyLLM(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.emb = torch.nn.Parameter(torch.randn(100, 24, generator=g))
+        self.layers = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(24, 24, generator=g) / 5) for _ in range(3)])
+
+    @property
+    def device(self):
+        return self.emb.device
+
+    def forward(self, input_ids=None, attention_mask=None, output_hidden_states=False):
+        h = self.emb[input_ids] * attention_mask[..., None]
+        hs = [h]
+        for w in self.layers:
+            h = torch.tanh(h @ w)
+            hs.append(h)
+        return type("O", (), {"hidden_states": tuple(hs), "__getitem__": lambda s, i: hs[-1]})()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/easyanimate"), reason="/root/reference not present (GPU box)")
+def test_encode_prompt_matches_the_reference_glue(tmp_path):
+    """EasyAnimatePipeline.encode_prompt (pipeline_easyanimate.py:306-580) against the reference's own method, called
+    unbound on a stand-in `self`: the LLM path (chat template, penultimate hidden state) with a stub tokenizer + tiny
+    encoder, and the BERT path with a real BertTokenizer over a tiny vocabulary."""
+    import types
+    from oracle import ref_loader
+    from easyanimate_amd.pipeline import EasyAnimatePipeline
+    ns = ref_loader.load()
+    ref_cls = ns.pipeline_easyanimate.EasyAnimatePipeline
+    cfg = types.SimpleNamespace(enable_text_attention_mask=True, get=lambda k, d=None: {"enable_text_attention_mask": True}.get(k, d))
+    tr = types.SimpleNamespace(config=cfg)
+    enc = _TinyLLM()
+    mine = EasyAnimatePipeline(vae=None, text_encoder=enc, tokenizer=_StubLLMTokenizer(), transformer=tr, scheduler=None)
+    fake = types.SimpleNamespace(tokenizer=mine.tokenizer, tokenizer_2=None, text_encoder=enc, text_encoder_2=None, transformer=tr)
+    for prompt, neg in (("a dog shakes its head", "blurry, static"), (["first turn", "second turn"], ["bad", "worse"])):
+        with torch.no_grad():
+            a = mine.encode_prompt(prompt, "cpu", torch.float32, 2, True, neg)
+            b = ref_cls.encode_prompt(fake, prompt, "cpu", torch.float32, 2, True, neg)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y)
+        assert a[0].shape[1] == 256 and a[0].shape[0] == 2   # (a list of prompts becomes ONE multi-turn chat text, :421-435)
+    # BERT path
+    from transformers import BertTokenizer
+    vocab = tmp_path / "vocab.txt"
+    vocab.write_text("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "a", "dog", "shakes", "its", "head", "blurry", ","]))
+    tok = BertTokenizer(str(vocab), model_max_length=77)
+
+    class _Bert(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Parameter(torch.randn(12, 16, generator=torch.Generator().manual_seed(1)))
+
+        def forward(self, ids, attention_mask=None):
+            return (self.emb[ids] * (1 if attention_mask is None else attention_mask[..., None]),)
+    bert = _Bert()
+    mine = EasyAnimatePipeline(vae=None, text_encoder=bert, tokenizer=tok, transformer=tr, scheduler=None)
+    fake = types.SimpleNamespace(tokenizer=tok, tokenizer_2=None, text_encoder=bert, text_encoder_2=None, transformer=tr)
+    with torch.no_grad():
+        a = mine.encode_prompt("a dog shakes its head", "cpu", torch.float32, 1, True, None)
+        b = ref_cls.encode_prompt(fake, "a dog shakes its head", "cpu", torch.float32, 1, True, None)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert a[0].shape == (1, 77, 16)
