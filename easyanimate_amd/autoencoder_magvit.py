@@ -201,6 +201,7 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         self.scaling_factor = scaling_factor
         self.latent_channels = latent_channels
         self.out_channels = out_channels
+        self.temporal_parallel = None   # set by enable_temporal_parallel()
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -213,6 +214,16 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
 
     def _clear_conv_cache(self):
         pass  # whole-clip evaluation keeps no chunk caches
+
+    def enable_temporal_parallel(self, group=None):
+        """Exact multi-GPU encode / decode: every rank of `group` holds the same weights and passes the same input; each
+        evaluates a contiguous range of frames and all ranks return the whole result (easyanimate_amd/vae_parallel.py)."""
+        from .vae_parallel import TemporalParallel
+        self.temporal_parallel = TemporalParallel(group)
+        return self.temporal_parallel
+
+    def disable_temporal_parallel(self):
+        self.temporal_parallel = None
 
     def enable_cache_in_vae(self):
         self.cache_compression_vae, self.cache_mag_vae = self.cache_compression_vae_copy, self.cache_mag_vae_copy
@@ -232,20 +243,38 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
             raise ValueError(f"encode: {x.shape[2]} frames -- the reference's chunked encoder only matches whole-clip evaluation for "
                              f"1 + k * mini_batch_encoder ({self.mini_batch_encoder}) frames (predict_t2v.py:288-291 trims the video to that)")
         in_dtype = x.dtype
+        odt = in_dtype if in_dtype in (torch.float32, torch.bfloat16) else torch.float32
+        tp = self.temporal_parallel
+        n_temporal = sum(1 for blk in self.encoder.down_blocks if getattr(blk, "temporal_downsample_factor", 1) == 2)
         moments = []
         for b in range(x.shape[0]):
-            xb = x[b].contiguous()
+            xb = x[b]
             if xb.dtype not in (torch.float32, torch.bfloat16):
                 xb = xb.float()
-            h = self.encoder(ops.ncdhw_to_ndhwc(xb))
-            m = conv_cl(self.quant_conv, h)  # 1x1x1
-            moments.append(ops.ndhwc_to_ncdhw(m, self.quant_conv.out_channels, in_dtype if in_dtype in (torch.float32, torch.bfloat16) else torch.float32))
+            if tp is None:
+                h = self.encoder(ops.ncdhw_to_ndhwc(xb.contiguous()))
+                m = conv_cl(self.quant_conv, h)  # 1x1x1
+                moments.append(ops.ndhwc_to_ncdhw(m, self.quant_conv.out_channels, odt))
+                continue
+            from . import vae_parallel
+            t_lat = (xb.shape[1] - 1) // (2 ** n_temporal) + 1
+            ranges = tp.plan(t_lat)
+            fr = ranges[tp.rank]
+            for _ in range(n_temporal):
+                fr = tp.finer(fr)
+            m_loc = None
+            if tp.is_active:
+                with vae_parallel.activate(tp):
+                    h = self.encoder(ops.ncdhw_to_ndhwc(xb[:, fr[0]:fr[1]].contiguous()))
+                    m_loc = ops.ndhwc_to_ncdhw(conv_cl(self.quant_conv, h), self.quant_conv.out_channels, odt)
+            like = torch.empty((self.quant_conv.out_channels, 1, xb.shape[2] // 8, xb.shape[3] // 8), dtype=odt, device=xb.device)
+            moments.append(tp.gather_frames(m_loc, ranges, 1, like))
         posterior = DiagonalGaussianDistribution(torch.stack(moments).to(in_dtype))
         if not return_dict:
             return (posterior,)
         return AutoencoderKLOutput(latent_dist=posterior)
 
-    def _decode_one(self, z: torch.Tensor, out_dtype, post: int = 0) -> torch.Tensor:
+    def _decode_local(self, z: torch.Tensor, out_dtype, post: int = 0) -> torch.Tensor:
         zc = z.contiguous()
         if zc.dtype not in (torch.float32, torch.bfloat16):
             zc = zc.float()
@@ -253,6 +282,26 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         h = h[..., :self.post_quant_conv.out_channels].contiguous() if h.shape[-1] != self.post_quant_conv.out_channels else h
         y = self.decoder(h)
         return ops.ndhwc_to_ncdhw(y, self.out_channels, out_dtype, post)
+
+    def _decode_one(self, z: torch.Tensor, out_dtype, post: int = 0) -> torch.Tensor:
+        tp = self.temporal_parallel
+        if tp is None:
+            return self._decode_local(z, out_dtype, post)
+        from . import vae_parallel
+        ranges = tp.plan(z.shape[1])
+        from .vae_modules import SpatialTemporalUpsampler3D
+        n_temporal = sum(1 for blk in self.decoder.up_blocks if isinstance(getattr(blk, "upsampler", None), SpatialTemporalUpsampler3D))
+        out_ranges = ranges
+        for _ in range(n_temporal):
+            out_ranges = [tp.finer(r) for r in out_ranges]
+        y = None
+        if tp.is_active:
+            a, b = ranges[tp.rank]
+            with vae_parallel.activate(tp):
+                y = self._decode_local(z[:, a:b], out_dtype, post)
+        s_ = 2 ** (len(self.decoder.up_blocks) - 1)
+        like = torch.empty((self.out_channels, 1, z.shape[2] * s_, z.shape[3] * s_), dtype=out_dtype, device=z.device)
+        return tp.gather_frames(y, out_ranges, 1, like)
 
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None, postprocess: bool = False
                ) -> Union[DecoderOutput, Tuple[torch.Tensor]]:

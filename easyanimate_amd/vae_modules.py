@@ -40,7 +40,32 @@ def _pad_bias(b: Optional[torch.Tensor], n_pad: int) -> Optional[torch.Tensor]:
 
 def conv_cl(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None, ups: bool = False,
             tdup: bool = False) -> torch.Tensor:
-    """Apply a (Causal)Conv3d module's parameters to a channels-last clip x [T,H,W,Cin] -> [T',H',W',Cout_pad8]."""
+    """Apply a (Causal)Conv3d module's parameters to a channels-last clip x [T,H,W,Cin] -> [T',H',W',Cout_pad8].
+    Under a temporal split (vae_parallel) a rank that is not the first prepends its left neighbour's last frames and drops
+    the outputs that belong to them: every retained output sees exactly the inputs of the whole-clip evaluation."""
+    from . import vae_parallel
+    tp = vae_parallel.current()
+    if tp is None or conv.weight.shape[2] == 1:
+        return _conv_cl_local(conv, x, res, ups, tdup)
+    st = conv.stride[0]
+    n = tp.halo_frames(st)
+    halo = tp.exchange(x, n)
+    if halo is None:
+        return _conv_cl_local(conv, x, res, ups, tdup)
+    if res is not None:
+        res = torch.cat([res.new_zeros((n,) + tuple(res.shape[1:])), res])
+    y = _conv_cl_local(conv, torch.cat([halo, x]), res, ups, tdup)
+    drop = tp.dropped_outputs(st, n, tdup)
+    out = y[drop:]
+    fused = getattr(y, "gn_partial", None)
+    if fused is not None:   # the per-frame partial sums of the retained frames
+        partial, nblk = fused
+        out.gn_partial = (partial.view(-1)[drop * nblk * (y.shape[-1] // 4) * 2:], nblk)
+    return out
+
+
+def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None, ups: bool = False,
+                   tdup: bool = False) -> torch.Tensor:
     co, ci, kt, kh, kw = conv.weight.shape
     assert kt == kh == kw and kt in (1, 3)
     st, sh, sw = conv.stride
