@@ -71,7 +71,8 @@ int ea_gemm_tile_set(int v);      // ea_gemm.hip:      0 (auto) | 128 | 256
 int ea_gemm_mfma_set(int v);      // ea_gemm.hip: 16 | 32
 int ea_conv_mfma_set(int v);      // ea_conv.hip: 16 | 32
 int ea_attn_variant_set(int v);   // ea_attention.hip: 1 | 2
-int ea_conv_tile_set(int v);      // ea_conv.hip:      0 (auto) | 128 | 256 | 512
+int ea_conv_tile_set(int v);
+int ea_conv_m512_set(int v);      // ea_conv.hip: 0 | 1      // ea_conv.hip:      0 (auto) | 128 | 256 | 512
 
 extern "C" int ea_set_option(const char* name, int value) {
     if (!name) {
@@ -84,6 +85,7 @@ extern "C" int ea_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_variant")) rc = ea_attn_variant_set(value);
     else if (!strcmp(name, "conv_tile")) rc = ea_conv_tile_set(value);
     else if (!strcmp(name, "conv_mfma")) rc = ea_conv_mfma_set(value);
+    else if (!strcmp(name, "conv_m512")) rc = ea_conv_m512_set(value);
     else {
         ea_set_error("ea_set_option: unknown option '%s'", name);
         return EA_ERR_ARG;

@@ -43,6 +43,14 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// Buffer-addressed LDS-DMA: 16 bytes per lane from base + voff (per lane) + soff (scalar) to lds_wave_base + 16 * lane.  The
+// descriptor (base, extent: wave-uniform, SGPRs) range-checks every lane: an offset at or beyond `extent` writes zeros.
+// (A plain function, not inlined text in the kernel templates: the host pass drops template kernels whose bodies name the
+// device-only descriptor type.)
+__device__ __forceinline__ void bdma16(const void* base, int extent, int voff, int soff, void* lds_wave_base) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, extent, 0x00020000);   // raw buffer, 32-bit format
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
 __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
@@ -731,25 +739,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     const int h_out = orow % p.H_out, t_out = orow / p.H_out;
     const int col0 = tn * BN;
 
-    // ---- this lane's slab rows: piece q = wave*5 + i (q < 33), LDS row r = 8q + lane/8  <->  input voxel w0 - 1 + r
-    int a_woff[PPW];      // element offset of (voxel, source chunk) inside an input row, or -1: zero padding / unused row
+    // ---- this lane's slab rows: piece q = wave*5 + i (q < 33), LDS row r = 8q + lane/8  <->  input voxel w0 - 1 + r.
+    // The DMA is buffer-addressed (see the 512-voxel kernel below): descriptor = the slab's input row, a_voff = byte offset
+    // of (voxel, source chunk) inside it; padding / unused rows point far beyond the row and read zeros
+    int a_voff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int q = wave * PPW + i;
         const int r = q * 8 + (lane >> 3), c = lane & 7;
         const int w = (UPS ? (w0 >> 1) : w0) - 1 + r;
-        a_woff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? w * p.C_in + (c ^ (r & 7)) * 8 : -1;
+        a_voff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ (r & 7)) * 8) * 2 : 0x40000000;
     }
-    const int zoff = (lane & 7) * 8;   // any 16 bytes of the zero page will do
-    const int64_t wk = (int64_t)27 * p.C_in;
-    const unsigned short* wbase[WP];
+    const int wk = 27 * p.C_in;
+    int w_voff[WP];       // byte offset of (weight row, source chunk) in this N tile's rows of the packed weights
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
         const int r = (wave * WP + i) * 8 + (lane >> 3), c = lane & 7;
-        int rw = col0 + r;
-        rw = rw < p.C_out ? rw : p.C_out - 1;
-        wbase[i] = p.w + (int64_t)rw * wk + ((c ^ (r & 7)) * 8);
+        w_voff[i] = (r * wk + (c ^ (r & 7)) * 8) * 2;
     }
+    const unsigned short* const w_tile = p.w + (int64_t)col0 * wk;
+    const int w_bytes = BN * wk * 2, row_bytes = p.W_in * p.C_in * 2;
     char* const dma_a = smem + wave * PPW * 1024;
     char* const dma_w = smem + W_BASE + wave * (WP * 1024);
 
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     const int cblocks = p.C_in / BK;
     // the NEXT tile to stage: (dtdh, cb, dw)
     int n_dtdh = 0, n_cb = 0;
-    const unsigned short* slab_row = p.zeros;   // input row (ti, hh) of the staged (dt, dh), or the zero page
+    const unsigned short* slab_row = p.x;       // input row (ti, hh) of the staged (dt, dh)
     bool slab_ok = false;
     auto set_slab = [&](int dtdh) {
         const int dt = dtdh / 3, dh = dtdh - dt * 3;
@@ -792,19 +801,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     };
     int a_dst = 0, w_dst = 0;                   // stage (0 / 1) the NEXT A slab / W tile is written to
     auto stage_a = [&](int sa, int cb) {
+        const int extent = slab_ok ? row_bytes : 0;            // a row of padding: every lane reads zeros
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if (wave * PPW + i < NPIECE) {                     // wave-uniform
-                const bool ok = slab_ok && a_woff[i] >= 0;
-                const unsigned short* src = ok ? slab_row + a_woff[i] + cb * BK : p.zeros + zoff;
-                glds16(src, dma_a + sa * A_STAGE + i * 1024);
-            }
-        }
+        for (int i = 0; i < PPW; ++i)
+            if (wave * PPW + i < NPIECE)                       // wave-uniform
+                bdma16(slab_row, extent, a_voff[i], cb * (BK * 2), dma_a + sa * A_STAGE + i * 1024);
     };
     auto stage_w = [&](int sw, int dtdh, int cb, int dw) {
         const int koff = (dtdh * 3 + dw) * p.C_in + cb * BK;
 #pragma unroll
-        for (int i = 0; i < WP; ++i) glds16(wbase[i] + koff, dma_w + sw * W_BYTES + i * 1024);
+        for (int i = 0; i < WP; ++i) bdma16(w_tile, w_bytes, w_voff[i], koff * 2, dma_w + sw * W_BYTES + i * 1024);
     };
     auto next_slab = [&]() {
         if (++n_cb == cblocks) {
@@ -922,41 +928,51 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
 #undef EA_C3_PHASE
 #undef EA_C3_WPHASE
 
-    // ---- epilogue: lane owns voxel m (one per M tile), channels n0 .. n0+3 of every N tile
+    // ---- epilogue: lane owns voxel m (one per M tile), channels n0 .. n0+3 of every N tile.  The residual of M tile i + 1 is
+    // requested before tile i is rounded and stored (uniform branches around each load would serialise the round trips)
     const int64_t frame = (int64_t)p.H_out * p.W_out;
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool has_res = p.res != nullptr, has_gn = p.gn_partial != nullptr;
+    const bool dup_t = p.tdup && t_out >= 1;
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (p.bias) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + col0 + wc * 64 + j * 16 + lq * 4);
+        else b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t m_base = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + lr;
+    const int ch0 = col0 + wc * 64 + lq * 4;
+    const int64_t e_res = m_base * p.C_out + ch0;              // + i * e_step + j * 16
+    const int64_t e_step = (int64_t)16 * p.C_out;
+    // with tdup the frame t_out >= 1 is stored twice: frames 2t - 1 and 2t of y
+    const int64_t e_dst0 = dup_t ? e_res + ((int64_t)t_out - 1) * frame * p.C_out : e_res;
+    const int64_t e_dup = frame * p.C_out;
+    bf16x4 rr[2][4];
+    if (has_res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[0][j] = *reinterpret_cast<const bf16x4*>(p.res + e_res + j * 16);
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int64_t m = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + i * 16 + lr;
-        int64_t m_dst0 = m, m_dst1 = -1;
-        if (p.tdup && t_out >= 1) {
-            const int64_t rem = m - (int64_t)t_out * frame;
-            m_dst0 = (2 * (int64_t)t_out - 1) * frame + rem;
-            m_dst1 = (2 * (int64_t)t_out) * frame + rem;
+        if (has_res && i + 1 < MT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[(i + 1) & 1][j] = *reinterpret_cast<const bf16x4*>(p.res + e_res + (i + 1) * e_step + j * 16);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n0 = col0 + wc * 64 + j * 16 + lq * 4;
-            if (n0 >= p.C_out) continue;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-            if (p.bias) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+            if (has_res) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += b0[e];
-            }
-            if (p.res) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res + m * p.C_out + n0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                for (int e = 0; e < 4; ++e) v[e] += (float)rr[i & 1][j][e];
             }
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(p.y + m_dst0 * p.C_out + n0) = o;
-            if (m_dst1 >= 0) *reinterpret_cast<bf16x4*>(p.y + m_dst1 * p.C_out + n0) = o;
-            if (p.gn_partial) {   // GroupNorm statistics of the NEXT layer, over the values it will read (the rounded ones)
+            *reinterpret_cast<bf16x4*>(p.y + e_dst0 + i * e_step + j * 16) = o;
+            if (dup_t) *reinterpret_cast<bf16x4*>(p.y + e_dst0 + e_dup + i * e_step + j * 16) = o;
+            if (has_gn) {   // GroupNorm statistics of the NEXT layer, over the values it will read (the rounded ones)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float r = (float)o[e];
@@ -983,7 +999,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
                 q_ += __shfl_xor(q_, o_, 64);
             }
             const int n0 = col0 + wc * 64 + j * 16 + lq * 4;
-            if (lr == 0 && n0 < p.C_out) {
+            if (lr == 0) {
                 float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
                 dst[0] = s_;
                 dst[1] = q_;
@@ -997,6 +1013,257 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     }
 }
 
+// =================================================================================================================
+// The row-slab kernel for the C_out = 128 layers at full resolution (42 % of a 49 x 1024^2 decode): 512 voxels x 128
+// channels per workgroup.  The 256-voxel version above gives each wave a 64 x 64 tile: 8 fragment reads (8 KiB) per 16
+// MFMAs, and with eight waves that is 64 KiB of LDS reads per phase = 512 LDS cycles against 512 MFMA cycles per SIMD -- the
+// LDS read port is exactly saturated and the MFMA pipe ends at 55 % (profiles/r02k_conv_row16_sq_counters.txt: it is not
+// power-limited, 1.96 GHz).  A 128 x 64 wave tile needs 12 reads per 32 MFMAs (what the 256-channel tiles get), but its
+// 514-row slab does not fit beside the weights at 64 channels per stage (164 KiB).  So this kernel stages HALF the
+// channels: LDS rows are 64 bytes = 32 channels = exactly one k32 step,
+//     A slab 514 rows x 64 B (33 KiB) x 2 stages + W tile 128 rows x 64 B (8 KiB) x 3 stages = 92 KiB,
+// waves 4 (M) x 2 (N).  64-byte rows: the 16-byte chunk is XOR-swizzled with (row >> 1) & 3, so each ds_read_b128 lane group
+// (MI355X_MICROARCH.md, LDS) covers the 16 slots of a bank row once, for all three dw row offsets.
+//
+// Schedule: a (slab, dw) tile is ONE phase -- 12 fragment reads, 32 MFMAs (512 cycles) per wave, two barriers -- for the
+// two wave groups in turn.  A phase cannot wait for DMA it issued itself, so the weights run three stages deep (tile t + 2
+// is issued while tile t is read; the W stage of a tile is its dw) and the next slab is issued at dw = 1; every phase opens
+// with vmcnt(0) (the pieces issued one phase ago have had a whole MFMA phase to land) and retires its fragment reads before
+// its first barrier (which frees the stage for the DMA the other wave group issues right after it).
+//
+// DMA addressing: buffer loads (`buffer_load_dwordx4 ... offen lds`), descriptor = the slab's input row (wave-uniform, SGPRs),
+// per-lane byte offset fixed for the whole kernel, channel block in the scalar offset: no per-piece vector arithmetic at all.
+// Zero padding is the descriptor's range check: lanes on padding voxels carry an offset beyond the row, a row of padding
+// has extent 0 -- out-of-range buffer loads write zeros to the LDS.
+//
+// Measured (13 x 1024^2, in-session A/B, profiles/r02l_conv_m512_ab.txt): 128 -> 128 with residual + GroupNorm partials
+// 11.81 -> 9.61 ms (1021 -> 1255 TFLOP/s), 256 -> 128 19.8 -> 17.5 ms (1217 -> 1376); of which 512-voxel tiles +4 %, one
+// phase per tile +9 %, buffer addressing +1.5 %, the residual prefetch in the epilogue +5 % on residual layers.
+__global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p) {
+    constexpr int BN = 128, TM = 512, RB = 64, KC = 32;            // tile, LDS row bytes, channels per stage
+    constexpr int NPIECE = 33, PPW = 5, NROW = TM + 2, ISTEP = 16 * RB;   // 1 KiB DMA pieces = 16 rows
+    constexpr int WN = 2, WM = 4, MT = TM / WM / 16;                // wave tile 128 voxels x 64 channels
+    constexpr int A_STAGE = 34 * 1024, W_BYTES = BN * RB, W_BASE = 2 * A_STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int grp = wave >> 2;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm;
+    {
+        const int rpx = (p.tiles_m + 7) / 8;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int m_lo = xcd * rpx;
+        int rows = p.tiles_m - m_lo;
+        rows = rows < rpx ? rows : rpx;
+        if (rows <= 0 || idx >= rows) return;
+        tm = m_lo + idx;
+    }
+    const int tiles_w = p.W_out / TM;
+    const int w0 = (tm % tiles_w) * TM;
+    const int orow = tm / tiles_w;                 // t_out * H_out + h_out
+    const int h_out = orow % p.H_out, t_out = orow / p.H_out;
+
+    // ---- this lane's slab rows: piece q = wave*5 + i (q < 33), LDS row r = 16q + lane/4  <->  input voxel w0 - 1 + r.
+    // Byte offset of (voxel, source chunk) inside the input row; padding / unused rows point far beyond the row
+    int a_voff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int r = q * 16 + (lane >> 2), c = lane & 3;
+        const int w = w0 - 1 + r;
+        a_voff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ ((r >> 1) & 3)) * 8) * 2 : 0x40000000;
+    }
+    const int wk = 27 * p.C_in;
+    int w_voff;                      // one 1 KiB piece (16 weight rows) per wave
+    {
+        const int r = wave * 16 + (lane >> 2), c = lane & 3;
+        w_voff = (r * wk + (c ^ ((r >> 1) & 3)) * 8) * 2;
+    }
+    const int w_bytes = BN * wk * 2, row_bytes = p.W_in * p.C_in * 2;
+    char* const dma_a = smem + wave * PPW * 1024;
+    char* const dma_w = smem + W_BASE + wave * 1024;
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: row * 64 + ((lq ^ ((row >> 1) & 3)) << 4); A row = wr*128 + i*16 + lr + dw, W row = wc*64 + j*16 + lr
+    unsigned a_k[3];
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+        const int row = wr * (MT * 16) + lr + dw;
+        a_k[dw] = row * RB + ((lq ^ ((row >> 1) & 3)) << 4);
+    }
+    const unsigned w_k = W_BASE + (wc * 64 + lr) * RB + ((lq ^ ((lr >> 1) & 3)) << 4);
+    bf16x8 wf[4];
+
+    const int cblocks = p.C_in / KC;
+    int n_dtdh = 0, n_cb = 0;                      // the slab being staged: (dt, dh), channel block
+    const unsigned short* slab_row = p.x;
+    bool slab_ok = false;
+    auto set_slab = [&](int dtdh) {
+        const int dt = dtdh / 3, dh = dtdh - dt * 3;
+        int ti = t_out + dt - 2;
+        ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
+        const int hu = h_out + dh - 1;
+        slab_ok = hu >= 0 && hu < p.H_out;
+        slab_row = p.x + ((int64_t)ti * p.H_in + (slab_ok ? hu : 0)) * p.W_in * p.C_in;
+    };
+    int a_dst = 0;
+    auto stage_a = [&](int sa, int cb) {
+        // one descriptor per slab row (wave-uniform): base = the row, extent = the row (0 for a row of padding)
+        const int extent = slab_ok ? row_bytes : 0;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            if (wave * PPW + i < NPIECE)                       // wave-uniform
+                bdma16(slab_row, extent, a_voff[i], cb * (KC * 2), dma_a + sa * A_STAGE + i * 1024);
+    };
+    auto stage_w = [&](int sw, int dtdh, int cb, int dw) {
+        const int koff = (dtdh * 3 + dw) * p.C_in + cb * KC;
+        bdma16(p.w, w_bytes, w_voff, koff * 2, dma_w + sw * W_BYTES);
+    };
+    auto next_slab = [&]() {
+        if (++n_cb == cblocks) {
+            n_cb = 0;
+            ++n_dtdh;
+            set_slab(n_dtdh);
+        }
+    };
+
+    // tile (slab, DW) reads W stage DW and issues tile t + 2: dw = (DW + 2) % 3 of this slab (DW = 0) or of the next one
+#define EA_C5_TILE(DW, HAS_NEXT2)                                                                           \
+    {                                                                                                       \
+        bf16x8 af[MT];                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+            wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k + (DW) * W_BYTES + j * ISTEP));            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
+            af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[DW] + i * ISTEP));                         \
+        if ((DW) == 1 && (HAS_NEXT2)) {                                                                     \
+            next_slab();                                                                                    \
+            stage_a(a_dst, n_cb);                                                                           \
+        }                                                                                                   \
+        if (HAS_NEXT2) stage_w(((DW) + 2) % 3, n_dtdh, n_cb, ((DW) + 2) % 3);                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);      \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+
+    // ---- prologue: slab 0 -> A stage 0, its dw = 0 / 1 weights -> W stages 0 / 1; wave group 1 starts one phase late
+    set_slab(0);
+    stage_a(0, 0);
+    stage_w(0, 0, 0, 0);
+    stage_w(1, 0, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // one trip = one slab = three tiles (dw = 0, 1, 2); the A stage toggles per slab
+    const int nslabs = 9 * cblocks;
+    int a_step = A_STAGE;
+    a_dst = 1;
+    for (int sl = 0; sl < nslabs; ++sl) {
+        EA_C5_TILE(0, true)
+        EA_C5_TILE(1, sl + 1 < nslabs)
+        EA_C5_TILE(2, sl + 1 < nslabs)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) a_k[dw] += a_step;
+        a_step = -a_step;
+        a_dst ^= 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef EA_C5_TILE
+
+    // ---- epilogue: lane owns voxel m (one per M tile), channels n0 .. n0+3 of every N tile.  The residual of M tile i + 1 is
+    // requested before tile i is rounded and stored (uniform branches around each load would serialise 32 round trips)
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool has_res = p.res != nullptr, has_gn = p.gn_partial != nullptr;
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n0 = wc * 64 + j * 16 + lq * 4;
+        if (p.bias) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
+        else b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t m_base = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + lr;
+    const int64_t e_base = m_base * p.C_out + wc * 64 + lq * 4;       // + i * 16 * C_out + j * 16
+    const int64_t e_step = (int64_t)16 * p.C_out;
+    bf16x4 rr[2][4];
+    if (has_res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[0][j] = *reinterpret_cast<const bf16x4*>(p.res + e_base + j * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (has_res && i + 1 < MT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[(i + 1) & 1][j] = *reinterpret_cast<const bf16x4*>(p.res + e_base + (i + 1) * e_step + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rr[i & 1][j][e];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16) = o;
+            if (has_gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = (float)o[e];
+                    gs[j] += r;
+                    gq[j] += r * r;
+                }
+            }
+        }
+    }
+    if (p.gn_partial) {
+        const int64_t in_frame = ((int64_t)h_out * tiles_w + (tm % tiles_w)) * WM + wr;
+        const int64_t blk = (int64_t)t_out * p.gn_nblk + in_frame;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s_ = gs[j], q_ = gq[j];
+#pragma unroll
+            for (int o_ = 1; o_ < 16; o_ <<= 1) {
+                s_ += __shfl_xor(s_, o_, 64);
+                q_ += __shfl_xor(q_, o_, 64);
+            }
+            const int n0 = wc * 64 + j * 16 + lq * 4;
+            if (lr == 0) {
+                float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
+                dst[0] = s_;
+                dst[1] = q_;
+            }
+        }
+    }
+}
+
+int g_conv_m512 = 1;   // ea_set_option("conv_m512", 0 | 1): the 512-voxel row-slab kernel for C_out = 128 layers
 int g_conv_mfma = 16;  // ea_set_option("conv_mfma", 16 | 32): MFMA shape of the row-slab kernel
 int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles;
                        // 1024: force the row-slab kernel wherever it applies
@@ -1030,6 +1297,11 @@ __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned s
 int ea_conv_mfma_set(int v) {
     if (v != 16 && v != 32) return -1;
     g_conv_mfma = v;
+    return 0;
+}
+int ea_conv_m512_set(int v) {
+    if (v != 0 && v != 1) return -1;
+    g_conv_m512 = v;
     return 0;
 }
 int ea_conv_tile_set(int v) {
@@ -1093,6 +1365,32 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
             attr3_done = true;
         }
         const dim3 g3((unsigned)grid3), b3(512);
+        // C_out == 128 (one N tile), rows a multiple of 512 voxels, no folded up-sampling / temporal duplication: the
+        // 512-voxel kernel (128 x 64 wave tiles over 32-channel stages)
+        if (g_conv_mfma == 16 && g_conv_m512 && C_out == 128 && !ups && !tdup && p.W_out % 512 == 0 && C_in % 32 == 0) {
+            const int tiles5 = (int)(p.M / 512);
+            const int64_t grid5 = (int64_t)8 * ((tiles5 + 7) / 8);
+            if (gn_partial) {
+                const int64_t nblk = (int64_t)p.H_out * (p.W_out / 512) * 4;
+                const int64_t need = (int64_t)p.T_out * nblk * (C_out / 4) * 2;
+                if (need <= gn_capacity && ((uintptr_t)gn_partial & 7) == 0) {
+                    p.gn_partial = gn_partial;
+                    p.gn_nblk = (int)nblk;
+                    if (gn_nblk_out) *gn_nblk_out = (int)nblk;
+                }
+            }
+            p.tiles_m = tiles5;
+            p.tiles_n = 1;
+            const int lds5 = 2 * 34 * 1024 + 3 * 128 * 64;
+            static bool attr5_done = false;
+            if (!attr5_done) {
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_m512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+                attr5_done = true;
+            }
+            ea_count("conv_row16_m512");
+            hipLaunchKernelGGL(conv3d_cl_row16_m512_kernel, dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
+            return ea_check_launch("ea_conv3d_cl_bf16");
+        }
         if (g_conv_mfma == 16 && gn_partial) {
             // fused GroupNorm statistics: one (sum, sumsq) pair per (frame, row tile, wave row, 4-channel bundle)
             const int wm = 8 / (bn / 64);

@@ -237,6 +237,65 @@ def test_conv3d_cl_row_slab_is_deterministic_and_matches_tilewise():
             _lib.set_option("conv_mfma", 16)
 
 
+M512_CASES = [
+    # the 512-voxel row-slab kernel (C_out = 128, rows a multiple of 512): one / two tiles per row, first / last row,
+    # frame 0 (causal replicate), residual, two to six 32-channel stages
+    (2, 3, 512, 128, 128, True),
+    (3, 2, 1024, 64, 128, False),
+    (1, 5, 512, 64, 128, False),
+    (2, 1, 1536, 192, 128, True),
+]
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,res", M512_CASES)
+def test_conv3d_cl_row_slab_m512(T, H, W, Ci, Co, res):
+    from easyanimate_amd import _lib
+    _lib.set_option("conv_tile", 1024)
+    _lib.reset_counters()
+    try:
+        test_conv3d_cl(T, H, W, Ci, Co, 3, 1, 1, 1, False, False, res)
+    finally:
+        _lib.set_option("conv_tile", 0)
+    assert _lib.counters().get("conv_row16_m512", 0) == 1
+
+
+def test_conv3d_cl_row_slab_m512_deterministic_stats_and_switch():
+    """Race screen (repeated launches bit-identical), the GroupNorm partial sums of the 512-voxel kernel against a statistics
+    pass over its output, and the "conv_m512" switch: 0 serves the same call with the 256-voxel kernel (another K order:
+    last-bit bf16 flips only)."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight
+    g = torch.Generator().manual_seed(10)
+    x = _bf(torch.randn(3, 24, 1024, 128, generator=g)).to(DEV)
+    w = _pack_conv_weight(_bf(torch.randn(128, 128, 3, 3, 3, generator=g) / (128 * 27) ** 0.5)).to(DEV)
+    b = torch.randn(128, generator=g).to(DEV)
+    gamma, beta = (1 + 0.3 * torch.randn(128, generator=g)).to(DEV), (0.3 * torch.randn(128, generator=g)).to(DEV)
+    _lib.set_option("conv_tile", 1024)
+    try:
+        _lib.reset_counters()
+        y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+        assert _lib.counters().get("conv_row16_m512", 0) == 1 and hasattr(y1, "gn_partial")
+        for _ in range(4):
+            assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
+        a = ops.groupnorm_silu(y1, gamma, beta, 32, 1e-6)
+        ops.FUSED_GN_STATS = False
+        try:
+            c = ops.groupnorm_silu(y1, gamma, beta, 32, 1e-6)
+        finally:
+            ops.FUSED_GN_STATS = True
+        d = (a.float() - c.float()).abs()
+        assert (d > 0).float().mean().item() < 1e-3 and d.max().item() <= 2.0 ** -6 * max(1.0, c.float().abs().max().item())
+        _lib.set_option("conv_m512", 0)
+        _lib.reset_counters()
+        y0 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
+        assert _lib.counters().get("conv_row16_m512", 0) == 0 and _lib.counters().get("conv_row16_128", 0) == 1
+        d = (y0.float() - y1.float()).abs()
+        assert bool((d <= 2 ** -7 * y0.float().abs().clamp_min(1.0)).all()) and (d > 0).float().mean().item() < 0.01
+    finally:
+        _lib.set_option("conv_m512", 1)
+        _lib.set_option("conv_tile", 0)
+
+
 def test_small_cin_conv_via_im2col():
     from easyanimate_amd.vae_modules import CausalConv3d
     g = torch.Generator().manual_seed(4)

@@ -36,5 +36,26 @@ def pmc(db, sub=None):
         print(f"{short(n)},{cn},{c},{s:.1f},{a:.1f},{mn:.1f},{mx:.1f}")
 
 
+def pmc_each(db, sub=None):
+    """per-dispatch counter values (dispatch order), for runs whose launches of one kernel differ in shape"""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select dispatch_id, kernel_name, counter_name, sum(value) from counters_collection group by dispatch_id, kernel_name, counter_name order by dispatch_id").fetchall()
+    print("dispatch,kernel,counter,value")
+    for d, n, cn, v in rows:
+        if sub and sub not in n:
+            continue
+        print(f"{d},{short(n)},{cn},{v:.1f}")
+
+
+def each(db, sub=None):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, duration from kernels order by start").fetchall()
+    print("kernel,duration_us")
+    for n, dur in rows:
+        if sub and sub not in n:
+            continue
+        print(f"{short(n)},{dur / 1e3:.2f}")
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "pmc_each": pmc_each, "each": each}[sys.argv[1]](*sys.argv[2:])
