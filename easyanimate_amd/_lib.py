@@ -79,6 +79,8 @@ def load() -> ctypes.CDLL:
     lib.ea_attention_state_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.ea_set_option.restype = c_int
     lib.ea_set_option.argtypes = [ctypes.c_char_p, c_int]
+    lib.ea_get_option.restype = c_int
+    lib.ea_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(c_int)]
     lib.ea_get_counter.restype = ctypes.c_longlong
     lib.ea_get_counter.argtypes = [ctypes.c_char_p]
     lib.ea_counter_name.restype = c_int
@@ -101,6 +103,13 @@ def call(name: str, *args) -> None:
 def set_option(name: str, value: int) -> None:
     """ea_set_option: tuning / benchmarking switches (e.g. "gemm_tile" 0|128|256)."""
     call("ea_set_option", name.encode(), int(value))
+
+
+def get_option(name: str) -> int:
+    """ea_get_option: the current value of a tuning switch."""
+    v = ctypes.c_int(0)
+    call("ea_get_option", name.encode(), ctypes.byref(v))
+    return v.value
 
 
 def reset_counters() -> None:

@@ -67,29 +67,44 @@ extern "C" void ea_reset_counters(void) {
 extern "C" int ea_version(void) { return 100; }
 
 // Tuning / benchmarking switches.  Each kernel file owns its switch; results never depend on them.
-int ea_gemm_tile_set(int v);      // ea_gemm.hip:      0 (auto) | 128 | 256
-int ea_gemm_mfma_set(int v);      // ea_gemm.hip: 16 | 32
-int ea_conv_mfma_set(int v);      // ea_conv.hip: 16 | 32
-int ea_attn_variant_set(int v);   // ea_attention.hip: 1 | 2
-int ea_conv_tile_set(int v);
-int ea_conv_m512_set(int v);      // ea_conv.hip: 0 | 1      // ea_conv.hip:      0 (auto) | 128 | 256 | 512
+#define EA_OPTION(n) int ea_##n##_set(int v); int ea_##n##_get();
+EA_OPTION(gemm_tile)      // ea_gemm.hip:      0 (auto) | 128 | 256
+EA_OPTION(gemm_mfma)      // ea_gemm.hip:      16 | 32
+EA_OPTION(conv_mfma)      // ea_conv.hip:      16 | 32
+EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
+EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1
+EA_OPTION(attn_variant)   // ea_attention.hip: 1 | 2
+#undef EA_OPTION
+namespace {
+struct Option { const char* name; int (*set)(int); int (*get)(); };
+#define EA_OPTION(n) {#n, ea_##n##_set, ea_##n##_get}
+const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(conv_mfma),
+                            EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(attn_variant)};
+#undef EA_OPTION
+const Option* find_option(const char* name) {
+    for (const Option& o : g_options)
+        if (name && !strcmp(name, o.name)) return &o;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int ea_get_option(const char* name, int* value) {
+    const Option* o = find_option(name);
+    if (!o || !value) {
+        ea_set_error("ea_get_option: unknown option '%s' or null value", name ? name : "(null)");
+        return EA_ERR_ARG;
+    }
+    *value = o->get();
+    return EA_OK;
+}
 
 extern "C" int ea_set_option(const char* name, int value) {
-    if (!name) {
-        ea_set_error("ea_set_option: null name");
+    const Option* o = find_option(name);
+    if (!o) {
+        ea_set_error("ea_set_option: unknown option '%s'", name ? name : "(null)");
         return EA_ERR_ARG;
     }
-    int rc;
-    if (!strcmp(name, "gemm_tile")) rc = ea_gemm_tile_set(value);
-    else if (!strcmp(name, "gemm_mfma")) rc = ea_gemm_mfma_set(value);
-    else if (!strcmp(name, "attn_variant")) rc = ea_attn_variant_set(value);
-    else if (!strcmp(name, "conv_tile")) rc = ea_conv_tile_set(value);
-    else if (!strcmp(name, "conv_mfma")) rc = ea_conv_mfma_set(value);
-    else if (!strcmp(name, "conv_m512")) rc = ea_conv_m512_set(value);
-    else {
-        ea_set_error("ea_set_option: unknown option '%s'", name);
-        return EA_ERR_ARG;
-    }
+    const int rc = o->set(value);
     if (rc != 0) {
         ea_set_error("ea_set_option: value %d is not valid for '%s'", value, name);
         return EA_ERR_ARG;

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
 
 }  // namespace
 
+int ea_attn_variant_get() { return g_attn_variant; }
 int ea_attn_variant_set(int v) {
     if (v != 1 && v != 2 && v != 3) return -1;
     g_attn_variant = v;

@@ -1294,16 +1294,19 @@ __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned s
 
 }  // namespace
 
+int ea_conv_mfma_get() { return g_conv_mfma; }
 int ea_conv_mfma_set(int v) {
     if (v != 16 && v != 32) return -1;
     g_conv_mfma = v;
     return 0;
 }
+int ea_conv_m512_get() { return g_conv_m512; }
 int ea_conv_m512_set(int v) {
     if (v != 0 && v != 1) return -1;
     g_conv_m512 = v;
     return 0;
 }
+int ea_conv_tile_get() { return g_conv_tile; }
 int ea_conv_tile_set(int v) {
     if (v != 0 && v != 128 && v != 256 && v != 512 && v != 1024) return -1;
     g_conv_tile = v;

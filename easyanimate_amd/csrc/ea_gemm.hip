@@ -1005,11 +1005,13 @@ extern "C" int ea_debug_gemm_timestamps(void* buf) {
 }
 #endif
 
+int ea_gemm_tile_get() { return g_gemm_tile; }
 int ea_gemm_tile_set(int v) {
     if (v != 0 && v != 128 && v != 256) return -1;
     g_gemm_tile = v;
     return 0;
 }
+int ea_gemm_mfma_get() { return g_gemm_mfma; }
 int ea_gemm_mfma_set(int v) {
     if (v != 16 && v != 32) return -1;
     g_gemm_mfma = v;

@@ -54,6 +54,8 @@ int ea_version(void);
  *   "attn_variant": 3 = the pipelined kernel on 16x16x32 MFMAs (default; serves calls with the scale folded into Q,
  *                   others fall through to 2), 2 = the pipelined kernel on 32x32x16, 1 = the first, un-pipelined kernel. */
 int ea_set_option(const char* name, int value);
+/* Current value of a switch (tests restore what they found). */
+int ea_get_option(const char* name, int* value);
 /* Dispatch counters (host-side bookkeeping): how many launches each kernel variant has served since the last reset,
  * e.g. "conv_row16_128", "conv_row16_256_ups", "conv_pp_256x256", "conv_128x128", "gemm_256_mi16", "gemm_128",
  * "attention_v3".  Tests use them to assert that the kernels a parity case is meant to cover actually ran.

@@ -23,10 +23,19 @@ def test_c_abi_exports_every_declared_symbol(lib_built):
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     from easyanimate_amd import _lib
-    assert set(_lib.PROTOTYPES) | {"ea_last_error_string", "ea_version", "ea_set_option", "ea_attention_state_bytes",
+    assert set(_lib.PROTOTYPES) | {"ea_last_error_string", "ea_version", "ea_set_option", "ea_get_option", "ea_attention_state_bytes",
                                     "ea_get_counter", "ea_counter_name", "ea_reset_counters", "ea_last_dispatch"} == declared
     assert _lib.counters() == {} and _lib.load().ea_get_counter(b"conv_row16_128") == 0   # host-side bookkeeping, no GPU
     assert _lib.load().ea_version() >= 100
+    # tuning switches: host-side state, readable and restorable without a GPU
+    for name in ("gemm_mfma", "conv_m512", "gemm_tile"):
+        v0 = _lib.get_option(name)
+        _lib.set_option(name, v0)
+        assert _lib.get_option(name) == v0
+    with pytest.raises(RuntimeError, match="unknown option"):
+        _lib.get_option("no_such_switch")
+    with pytest.raises(RuntimeError, match="not valid"):
+        _lib.set_option("gemm_mfma", 48)
 
 
 def test_argument_errors_do_not_abort(lib_built):
