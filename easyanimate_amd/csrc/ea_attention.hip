@@ -20,6 +20,15 @@
 
 namespace {
 
+#ifndef EA_ATT3_BUFDMA
+#define EA_ATT3_BUFDMA 1   // build-time A/B switch: K / V^T tiles by buffer-addressed LDS-DMA (0: per-lane 64-bit addresses)
+#endif
+// Buffer-addressed LDS-DMA: 16 bytes per lane from base + voff (per lane, fixed for the kernel) + soff (scalar: the key tile)
+// to lds_wave_base + 16 * lane -- no per-piece vector address arithmetic beside the softmax's VALU work.
+__device__ __forceinline__ void bdma16(const void* base, int extent, int voff, int soff, void* lds_wave_base) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, extent, 0x00020000);   // raw buffer, 32-bit format
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

@@ -1,0 +1,19 @@
+"""Attention timing at the config-3 shape (1 x 48 heads x 53 504 tokens, scale folded into Q); EA_LIB_PATH selects the library
+build for an A/B (one library per process; alternate the processes)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from easyanimate_amd import ops
+from microbench_vae_common import timeit
+
+lib = os.path.basename(os.environ.get("EA_LIB_PATH", "default"))
+B, H, S = 1, 48, 53504
+q = torch.randn(B, H, S, 64, device="cuda").to(torch.bfloat16)
+k = torch.randn(B, H, S, 64, device="cuda").to(torch.bfloat16)
+vt = torch.randn(B, H, 64, S, device="cuda").to(torch.bfloat16)
+qq = (q.float() * ops.FOLDED_Q_SCALE).to(torch.bfloat16)
+out = torch.empty(B, S, H * 64, dtype=torch.bfloat16, device="cuda")
+for rep in range(3):
+    ms = timeit(lambda: ops.attention(qq, k, vt, S, ops.FOLDED_ATTN_SCALE, out=out), warm=1, iters=5)
+    print(json.dumps({"lib": lib, "kernel": "attention v3", "ms": round(ms, 3), "TFLOPs": round(4.0 * B * H * S * S * 64 / ms / 1e9, 1)}), flush=True)
