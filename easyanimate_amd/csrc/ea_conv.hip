@@ -1039,11 +1039,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
 // Measured (13 x 1024^2, in-session A/B, profiles/r02l_conv_m512_ab.txt): 128 -> 128 with residual + GroupNorm partials
 // 11.81 -> 9.61 ms (1021 -> 1255 TFLOP/s), 256 -> 128 19.8 -> 17.5 ms (1217 -> 1376); of which 512-voxel tiles +4 %, one
 // phase per tile +9 %, buffer addressing +1.5 %, the residual prefetch in the epilogue +5 % on residual layers.
-__global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p) {
-    constexpr int BN = 128, TM = 512, RB = 64, KC = 32;            // tile, LDS row bytes, channels per stage
-    constexpr int NPIECE = 33, PPW = 5, NROW = TM + 2, ISTEP = 16 * RB;   // 1 KiB DMA pieces = 16 rows
-    constexpr int WN = 2, WM = 4, MT = TM / WM / 16;                // wave tile 128 voxels x 64 channels
-    constexpr int A_STAGE = 34 * 1024, W_BYTES = BN * RB, W_BASE = 2 * A_STAGE;
+template <int BN, int TM>   // 128 x 512 or 256 x 256: (channels, voxels) per workgroup
+__global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p) {
+    static_assert(BN * TM == 65536, "wave tile 128 voxels x 64 channels");
+    constexpr int RB = 64, KC = 32;                                 // LDS row bytes, channels per stage
+    constexpr int NROW = TM + 2, NPIECE = (NROW + 15) / 16, PPW = (NPIECE + 7) / 8, ISTEP = 16 * RB;   // 1 KiB DMA pieces = 16 rows
+    constexpr int WN = BN / 64, WM = 8 / WN, MT = TM / WM / 16;     // wave tile 128 voxels x 64 channels, MT = 8
+    constexpr int WP = BN / 128;                                    // W pieces (16 weight rows each) per wave
+    constexpr int A_STAGE = (NPIECE + 1) * 1024, W_BYTES = BN * RB, W_BASE = 2 * A_STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1052,22 +1055,24 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p
     const int grp = wave >> 2;
     const int lr = lane & 15, lq = lane >> 4;
 
-    int tm;
+    int tm, tn;
     {
         const int rpx = (p.tiles_m + 7) / 8;
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         const int m_lo = xcd * rpx;
         int rows = p.tiles_m - m_lo;
         rows = rows < rpx ? rows : rpx;
-        if (rows <= 0 || idx >= rows) return;
-        tm = m_lo + idx;
+        if (rows <= 0 || idx >= rows * p.tiles_n) return;
+        tm = m_lo + idx / p.tiles_n;
+        tn = idx % p.tiles_n;
     }
+    const int col0 = tn * BN;
     const int tiles_w = p.W_out / TM;
     const int w0 = (tm % tiles_w) * TM;
     const int orow = tm / tiles_w;                 // t_out * H_out + h_out
     const int h_out = orow % p.H_out, t_out = orow / p.H_out;
 
-    // ---- this lane's slab rows: piece q = wave*5 + i (q < 33), LDS row r = 16q + lane/4  <->  input voxel w0 - 1 + r.
+    // ---- this lane's slab rows: piece q = wave*PPW + i (q < NPIECE), LDS row r = 16q + lane/4  <->  input voxel w0 - 1 + r.
     // Byte offset of (voxel, source chunk) inside the input row; padding / unused rows point far beyond the row
     int a_voff[PPW];
 #pragma unroll
@@ -1078,14 +1083,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p
         a_voff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ ((r >> 1) & 3)) * 8) * 2 : 0x40000000;
     }
     const int wk = 27 * p.C_in;
-    int w_voff;                      // one 1 KiB piece (16 weight rows) per wave
-    {
-        const int r = wave * 16 + (lane >> 2), c = lane & 3;
-        w_voff = (r * wk + (c ^ ((r >> 1) & 3)) * 8) * 2;
+    int w_voff[WP];                  // 1 KiB pieces of 16 weight rows, WP per wave
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = (wave * WP + i) * 16 + (lane >> 2), c = lane & 3;
+        w_voff[i] = (r * wk + (c ^ ((r >> 1) & 3)) * 8) * 2;
     }
+    const unsigned short* const w_tile = p.w + (int64_t)col0 * wk;
     const int w_bytes = BN * wk * 2, row_bytes = p.W_in * p.C_in * 2;
     char* const dma_a = smem + wave * PPW * 1024;
-    char* const dma_w = smem + W_BASE + wave * 1024;
+    char* const dma_w = smem + W_BASE + wave * (WP * 1024);
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -1128,7 +1135,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p
     };
     auto stage_w = [&](int sw, int dtdh, int cb, int dw) {
         const int koff = (dtdh * 3 + dw) * p.C_in + cb * KC;
-        bdma16(p.w, w_bytes, w_voff, koff * 2, dma_w + sw * W_BYTES);
+#pragma unroll
+        for (int i = 0; i < WP; ++i) bdma16(w_tile, w_bytes, w_voff[i], koff * 2, dma_w + sw * W_BYTES + i * 1024);
     };
     auto next_slab = [&]() {
         if (++n_cb == cblocks) {
@@ -1201,12 +1209,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p
     f32x4 b4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n0 = wc * 64 + j * 16 + lq * 4;
+        const int n0 = col0 + wc * 64 + j * 16 + lq * 4;
         if (p.bias) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
         else b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int64_t m_base = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + lr;
-    const int64_t e_base = m_base * p.C_out + wc * 64 + lq * 4;       // + i * 16 * C_out + j * 16
+    const int64_t e_base = m_base * p.C_out + col0 + wc * 64 + lq * 4;   // + i * 16 * C_out + j * 16
     const int64_t e_step = (int64_t)16 * p.C_out;
     bf16x4 rr[2][4];
     if (has_res) {
@@ -1253,7 +1261,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p
                 s_ += __shfl_xor(s_, o_, 64);
                 q_ += __shfl_xor(q_, o_, 64);
             }
-            const int n0 = wc * 64 + j * 16 + lq * 4;
+            const int n0 = col0 + wc * 64 + j * 16 + lq * 4;
             if (lr == 0) {
                 float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
                 dst[0] = s_;
@@ -1263,7 +1271,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_m512_kernel(ConvArgs p
     }
 }
 
-int g_conv_m512 = 1;   // ea_set_option("conv_m512", 0 | 1): the 512-voxel row-slab kernel for C_out = 128 layers
+// ea_set_option("conv_m512", bit 0: the 512-voxel x 128-channel kernel, bit 1: the 256 x 256 kernel over 32-channel stages).
+// Bit 1 is off by default: for the 256-channel tiles the four-phase kernel over 64-channel stages is 1.5-3 % faster
+// (profiles/r02p_conv_k32_256_ab.txt) -- their W tile is 16 pieces of half cache lines per 32-MFMA phase.
+int g_conv_m512 = 1;
 int g_conv_mfma = 16;  // ea_set_option("conv_mfma", 16 | 32): MFMA shape of the row-slab kernel
 int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles;
                        // 1024: force the row-slab kernel wherever it applies
@@ -1302,7 +1313,7 @@ int ea_conv_mfma_set(int v) {
 }
 int ea_conv_m512_get() { return g_conv_m512; }
 int ea_conv_m512_set(int v) {
-    if (v != 0 && v != 1) return -1;
+    if (v < 0 || v > 3) return -1;
     g_conv_m512 = v;
     return 0;
 }
@@ -1368,30 +1379,41 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
             attr3_done = true;
         }
         const dim3 g3((unsigned)grid3), b3(512);
-        // C_out == 128 (one N tile), rows a multiple of 512 voxels, no folded up-sampling / temporal duplication: the
-        // 512-voxel kernel (128 x 64 wave tiles over 32-channel stages)
-        if (g_conv_mfma == 16 && g_conv_m512 && C_out == 128 && !ups && !tdup && p.W_out % 512 == 0 && C_in % 32 == 0) {
-            const int tiles5 = (int)(p.M / 512);
-            const int64_t grid5 = (int64_t)8 * ((tiles5 + 7) / 8);
+        // no folded up-sampling / temporal duplication: the one-phase-per-tile kernels over 32-channel stages -- 512 voxels x
+        // 128 channels for C_out == 128 with rows a multiple of 512 voxels, 256 x 256 for the 256-channel tiles
+        const bool k32_128 = C_out == 128 && p.W_out % 512 == 0 && (g_conv_m512 & 1);
+        const bool k32_256 = bn == 256 && (g_conv_m512 & 2);
+        if (g_conv_mfma == 16 && !ups && !tdup && (k32_128 || k32_256)) {
+            const int tmv = k32_128 ? 512 : 256, wm = k32_128 ? 4 : 2;
+            const int tiles5 = (int)(p.M / tmv);
+            p.tiles_m = tiles5;
+            p.tiles_n = k32_128 ? 1 : C_out / 256;
+            const int64_t grid5 = (int64_t)8 * ((tiles5 + 7) / 8) * p.tiles_n;
+            EA_REQUIRE(grid5 < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
             if (gn_partial) {
-                const int64_t nblk = (int64_t)p.H_out * (p.W_out / 512) * 4;
+                const int64_t nblk = (int64_t)p.H_out * (p.W_out / tmv) * wm;
                 const int64_t need = (int64_t)p.T_out * nblk * (C_out / 4) * 2;
-                if (need <= gn_capacity && ((uintptr_t)gn_partial & 7) == 0) {
+                if (need <= gn_capacity && nblk < (1 << 30) && ((uintptr_t)gn_partial & 7) == 0) {
                     p.gn_partial = gn_partial;
                     p.gn_nblk = (int)nblk;
                     if (gn_nblk_out) *gn_nblk_out = (int)nblk;
                 }
             }
-            p.tiles_m = tiles5;
-            p.tiles_n = 1;
-            const int lds5 = 2 * 34 * 1024 + 3 * 128 * 64;
+            // LDS: two A stages of (pieces + 1) KiB, three W stages of BN x 64 B
+            const int lds5 = k32_128 ? 2 * 34 * 1024 + 3 * 128 * 64 : 2 * 18 * 1024 + 3 * 256 * 64;
             static bool attr5_done = false;
             if (!attr5_done) {
-                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_m512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 3 * 128 * 64);
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 18 * 1024 + 3 * 256 * 64);
                 attr5_done = true;
             }
-            ea_count("conv_row16_m512");
-            hipLaunchKernelGGL(conv3d_cl_row16_m512_kernel, dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
+            if (k32_128) {
+                ea_count("conv_row16_m512");
+                hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<128, 512>), dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
+            } else {
+                ea_count("conv_row16_256_k32");
+                hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<256, 256>), dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
+            }
             return ea_check_launch("ea_conv3d_cl_bf16");
         }
         if (g_conv_mfma == 16 && gn_partial) {

@@ -197,17 +197,30 @@ ROW_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mfma", [16, 32])
+@pytest.mark.parametrize("mfma,k32", [(16, 3), (16, 0), (32, 0)])
 @pytest.mark.parametrize("T,H,W,Ci,Co,ups,tdup,res", ROW_CASES)
-def test_conv3d_cl_row_slab(T, H, W, Ci, Co, ups, tdup, res, mfma):
+def test_conv3d_cl_row_slab(T, H, W, Ci, Co, ups, tdup, res, mfma, k32):
+    """k32 = the "conv_m512" switch: 3 sends the layers without folded up-sampling to the one-phase-per-tile kernels over
+    32-channel stages (512 voxels x 128 channels, 256 x 256), 0 keeps the four-phase kernels over 64-channel stages."""
     from easyanimate_amd import _lib
+    k0 = _lib.get_option("conv_m512")
     _lib.set_option("conv_tile", 1024)
     _lib.set_option("conv_mfma", mfma)
+    _lib.set_option("conv_m512", k32)
+    _lib.reset_counters()
     try:
         test_conv3d_cl(T, H, W, Ci, Co, 3, 1, 1, 1, ups, tdup, res)
     finally:
         _lib.set_option("conv_tile", 0)
         _lib.set_option("conv_mfma", 16)
+        _lib.set_option("conv_m512", k0)
+    c = _lib.counters()
+    if mfma == 16 and k32 == 3 and not ups and not tdup and Co % 256 == 0:
+        assert c == {"conv_row16_256_k32": 1}, c
+    elif mfma == 16 and k32 == 3 and not ups and not tdup and Co == 128 and W % 512 == 0:
+        assert c == {"conv_row16_m512": 1}, c
+    elif mfma == 16:
+        assert len(c) == 1 and next(iter(c)).startswith("conv_row16_") and "k32" not in next(iter(c)) and "m512" not in next(iter(c)), c
 
 
 def test_conv3d_cl_row_slab_is_deterministic_and_matches_tilewise():
@@ -259,22 +272,26 @@ def test_conv3d_cl_row_slab_m512(T, H, W, Ci, Co, res):
     assert _lib.counters().get("conv_row16_m512", 0) == 1
 
 
-def test_conv3d_cl_row_slab_m512_deterministic_stats_and_switch():
-    """Race screen (repeated launches bit-identical), the GroupNorm partial sums of the 512-voxel kernel against a statistics
-    pass over its output, and the "conv_m512" switch: 0 serves the same call with the 256-voxel kernel (another K order:
-    last-bit bf16 flips only)."""
+@pytest.mark.parametrize("Ci,Co,W", [(128, 128, 1024), (256, 256, 512), (128, 512, 256)])
+def test_conv3d_cl_row_slab_k32_deterministic_stats_and_switch(Ci, Co, W):
+    """Race screen (repeated launches bit-identical) for the one-phase-per-tile kernels, their GroupNorm partial sums against
+    a statistics pass over the output, and the "conv_m512" switch: 0 serves the same call with the four-phase kernel over
+    64-channel stages (another K order: last-bit bf16 flips only)."""
     from easyanimate_amd import _lib, ops
     from easyanimate_amd.vae_modules import _pack_conv_weight
     g = torch.Generator().manual_seed(10)
-    x = _bf(torch.randn(3, 24, 1024, 128, generator=g)).to(DEV)
-    w = _pack_conv_weight(_bf(torch.randn(128, 128, 3, 3, 3, generator=g) / (128 * 27) ** 0.5)).to(DEV)
-    b = torch.randn(128, generator=g).to(DEV)
-    gamma, beta = (1 + 0.3 * torch.randn(128, generator=g)).to(DEV), (0.3 * torch.randn(128, generator=g)).to(DEV)
+    x = _bf(torch.randn(3, 24, W, Ci, generator=g)).to(DEV)
+    w = _pack_conv_weight(_bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    gamma, beta = (1 + 0.3 * torch.randn(Co, generator=g)).to(DEV), (0.3 * torch.randn(Co, generator=g)).to(DEV)
+    name = "conv_row16_m512" if Co == 128 else "conv_row16_256_k32"
+    k0 = _lib.get_option("conv_m512")
     _lib.set_option("conv_tile", 1024)
+    _lib.set_option("conv_m512", 3)
     try:
         _lib.reset_counters()
         y1 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
-        assert _lib.counters().get("conv_row16_m512", 0) == 1 and hasattr(y1, "gn_partial")
+        assert _lib.counters() == {name: 1} and hasattr(y1, "gn_partial")
         for _ in range(4):
             assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 1, 1), y1)
         a = ops.groupnorm_silu(y1, gamma, beta, 32, 1e-6)
@@ -288,11 +305,11 @@ def test_conv3d_cl_row_slab_m512_deterministic_stats_and_switch():
         _lib.set_option("conv_m512", 0)
         _lib.reset_counters()
         y0 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1)
-        assert _lib.counters().get("conv_row16_m512", 0) == 0 and _lib.counters().get("conv_row16_128", 0) == 1
+        assert _lib.counters() == {("conv_row16_128" if Co == 128 else "conv_row16_256"): 1}
         d = (y0.float() - y1.float()).abs()
         assert bool((d <= 2 ** -7 * y0.float().abs().clamp_min(1.0)).all()) and (d > 0).float().mean().item() < 0.01
     finally:
-        _lib.set_option("conv_m512", 1)
+        _lib.set_option("conv_m512", k0)
         _lib.set_option("conv_tile", 0)
 
 

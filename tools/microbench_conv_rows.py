@@ -15,7 +15,7 @@ for (T, H, W, Ci, Co) in [(13, 1024, 1024, 128, 128), (13, 1024, 1024, 256, 128)
     b = torch.randn(Co, device="cuda")
     fl = 2.0 * 27 * Ci * Co * T * H * W
     res = torch.randn(T, H, W, Co, device="cuda").to(torch.bfloat16) if Ci == Co else None
-    for m512 in ((1, 0, 1, 0) if Co == 128 else (1, 1)):
+    for m512 in (3, 0, 3, 0):
         _lib.set_option("conv_m512", m512)
         for r in ((None, res) if res is not None else (None,)):
             ms = timeit(lambda: ops.conv3d_cl(x, w, b, 3, 1, 1, 1, res=r, want_stats=r is not None))
