@@ -303,6 +303,25 @@ def gen_vae_full(ns, shim):
     print("  moments std", out["moments_std"], "dec std", out["dec_std"], {k: v for k, v in out.items() if k.endswith("floor_mse")})
 
 
+@section("vae_dec_512")
+def gen_vae_dec_512(ns, shim):
+    # ---- full-width decoder at 5 x 512^2: rows of 512 voxels, the shape class where the C_out = 128 layers run on the
+    # 512-voxel row-slab kernel (the kernel that carries 39 % of a 49 x 1024^2 decode).  Output stored at every second
+    # pixel (fp16): the comparison is an MSE, and the fixture stays at 2 MB.
+    vkw = dict(FULL_VAE)
+    vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()
+    shapes = _load_sd(vae, 2, "default")
+    _, zlat = vae_full_inputs(seed=10, frames=5, size=512)
+    import time
+    t0 = time.time()
+    dec = vae.decode(zlat)[0]
+    print("  decode fp32 5x512^2", time.time() - t0, flush=True)
+    out = dict(cfg=vkw, shapes=shapes, seed=2, style="default", input_seed=10, frames=5, size=512, z_sum=zlat.double().sum().item(),
+               dec_sub_f16=dec[..., ::2, ::2].to(torch.float16).contiguous(), dec_std=dec.std().item(), dec_shape=tuple(dec.shape))
+    torch.save(out, os.path.join(OUT, "vae_dec_5x512.pt"))
+    print("  dec std", out["dec_std"], "shape", out["dec_shape"])
+
+
 def _ref_loop(ns, shim, m, latents, enc, rope, steps, guidance, dt, keep=None):
     """The reference's sampling loop (pipeline_easyanimate.py:1069-1111) over the shim-hosted reference transformer."""
     mm = copy.deepcopy(m).to(dt)

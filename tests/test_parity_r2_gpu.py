@@ -228,3 +228,28 @@ def test_vae_full_width_vs_golden():
     assert c_dec.get("conv_row16_256_ups", 0) >= 1      # the 256-channel up-sampler with folded x2 addressing
     assert c_dec.get("conv_pp_256x256", 0) >= 1         # 256 x 256 ping-pong implicit GEMM
     assert c_enc.get("conv_row16_128", 0) >= 4 and c_enc.get("conv_pp_256x256", 0) >= 1
+
+
+def test_vae_decoder_512_rows_vs_golden():
+    """Full-width decoder at 5 x 512^2 against the reference (fp32, chunked mode; every second pixel stored): output rows of
+    512 voxels send the C_out = 128 layers to the 512-voxel row-slab kernel -- the kernel that carries a 49 x 1024^2 decode
+    -- inside the real network, automatic dispatch."""
+    from easyanimate_amd import AutoencoderKLMagvit, _lib
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle.gen_golden import vae_full_inputs
+    g = _load("vae_dec_5x512.pt")
+    _, z = vae_full_inputs(g["input_seed"], g["frames"], g["size"])
+    assert abs(z.double().sum().item() - g["z_sum"]) < 1e-4
+    vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    _lib.reset_counters()
+    with torch.no_grad():
+        dec = vae.decode(z.to(DEV).bfloat16())[0]
+    torch.cuda.synchronize()
+    c = _lib.counters()
+    assert tuple(dec.shape) == tuple(g["dec_shape"]) == (1, 3, 5, 512, 512)
+    mse = _mse(dec[..., ::2, ::2].float(), g["dec_sub_f16"].float())
+    print(f"[parity] full-width decoder 5x512^2: MSE={mse:.3e} (ref std {g['dec_std']:.3f}); kernels {c}")
+    assert mse < BAR
+    assert c.get("conv_row16_m512", 0) >= 6 and c.get("conv_row16_256_ups", 0) >= 1 and c.get("conv_row16_256", 0) >= 1
