@@ -3,6 +3,7 @@ K-padded).  Derived copies are cached per parameter and invalidated when the par
 (`_version`), re-pointed (`data_ptr`) or moved, so load_state_dict / LoRA merges are observed."""
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Callable, Dict, Tuple
 
@@ -45,6 +46,20 @@ def f32(p):
     if p.dtype == torch.float32 and p.is_contiguous():
         return p.detach()
     return derived(p, "f32", lambda t: t.float().contiguous())
+
+
+# fp8 weight storage (the reference's `model_cpu_offload_and_qfloat8`): True = the block GEMMs read the fp8 parameter itself
+# (ea_gemm_bf16_w8 / ea_qkv_gemm_norm_rope_bf16_w8 widen it inside the kernel: one byte per weight in HBM, no bf16 copy);
+# False = up-cast once into the derived-parameter cache (two more bytes per weight, the bf16 kernels).  Same results.
+FP8_NATIVE_GEMM = os.environ.get("EA_FP8_NATIVE_GEMM", "1") != "0"
+
+
+def gemm_weight(p):
+    """The [N, K] weight operand of ops.gemm / ops.qkv_gemm_norm_rope for a Linear: the parameter itself when it is
+    contiguous bf16 or (fp8 storage mode, FP8_NATIVE_GEMM) contiguous float8_e4m3fn with K % 64 == 0, else a cached bf16 copy."""
+    if FP8_NATIVE_GEMM and p.dtype == torch.float8_e4m3fn and p.dim() == 2 and p.is_contiguous() and p.shape[1] % 64 == 0:
+        return p.detach()
+    return bf16_weight(p)
 
 
 def bf16_weight(p, k_pad: int | None = None):

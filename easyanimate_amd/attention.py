@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._params import bf16_weight, f32
+from ._params import f32, gemm_weight
 from .norm import EasyAnimateLayerNormZero, FP32LayerNorm
 from .processor import EasyAnimateAttnProcessor2_0, EasyAnimateSWAttnProcessor2_0
 
@@ -88,12 +88,12 @@ class FeedForward(nn.Module):
                 gate: Optional[torch.Tensor] = None, *args, **kwargs) -> torch.Tensor:
         x = hidden_states if hidden_states.dtype == torch.bfloat16 else hidden_states.to(torch.bfloat16)
         fc1, fc2 = self.net[0].proj, self.net[2]
-        h = ops.gemm(x, bf16_weight(fc1.weight), f32(fc1.bias), ops.EPI_BIAS_GELU_TANH)
+        h = ops.gemm(x, gemm_weight(fc1.weight), f32(fc1.bias), ops.EPI_BIAS_GELU_TANH)
         if residual is not None:
             B = x.shape[0]
-            return ops.gemm(h, bf16_weight(fc2.weight), f32(fc2.bias), ops.EPI_BIAS_GATE_RES,
+            return ops.gemm(h, gemm_weight(fc2.weight), f32(fc2.bias), ops.EPI_BIAS_GATE_RES,
                             res=residual, gate=gate.reshape(B, -1))
-        return ops.gemm(h, bf16_weight(fc2.weight), f32(fc2.bias), ops.EPI_BIAS)
+        return ops.gemm(h, gemm_weight(fc2.weight), f32(fc2.bias), ops.EPI_BIAS)
 
 
 class EasyAnimateDiTBlock(nn.Module):

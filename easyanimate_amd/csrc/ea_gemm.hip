@@ -39,6 +39,45 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- fp8 weight storage (the reference's `model_cpu_offload_and_qfloat8` mode, utils/fp8_optimization.py:17-35: every
+// Linear weight is kept as torch.float8_e4m3fn = OCP E4M3 and up-cast to bf16 for each call).  The W8 kernel variants read
+// the fp8 bytes themselves: a weight tile row comes in through registers (16 bytes = 16 elements per load), is widened to
+// bf16 -- exact: E4M3 has 3 mantissa bits, and the fp32 the converter returns is cut to its upper half -- and is written into
+// the same swizzled LDS image the LDS-DMA of bf16 weights produces.  Same MFMAs on the same values: bit-identical results,
+// half the weight bytes in HBM and on the L2 -> LDS path.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fp8x16_to_bf16x16(const u32x4 src, u32x4& lo, u32x4& hi) {
+    unsigned o[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)src[d], false);   // bytes 0, 1
+        const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8((int)src[d], true);    // bytes 2, 3
+        const float a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];   // (bit_cast of a vector element miscompiles: copy first)
+        o[2 * d] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);       // (hi16(a1) << 16) | hi16(a0)
+        o[2 * d + 1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
+    }
+    lo = u32x4{o[0], o[1], o[2], o[3]};
+    hi = u32x4{o[4], o[5], o[6], o[7]};
+}
+// one thread's share of a W tile: row r, 32 consecutive k (bytes) = LDS chunks c0 .. c0 + 3 of that row
+struct W8Lane {
+    const unsigned char* src;   // this lane's 32 bytes of K tile 0
+    unsigned lds[4];            // byte offsets of its four 16-byte chunks inside a W stage (swizzle applied)
+    u32x4 r[2];
+    __device__ __forceinline__ void load(int k_bytes) {
+        r[0] = *reinterpret_cast<const u32x4*>(src + k_bytes);
+        r[1] = *reinterpret_cast<const u32x4*>(src + k_bytes + 16);
+    }
+    __device__ __forceinline__ void store(char* w_stage) const {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 lo, hi;
+            fp8x16_to_bf16x16(r[u], lo, hi);
+            *reinterpret_cast<u32x4*>(w_stage + lds[2 * u]) = lo;
+            *reinterpret_cast<u32x4*>(w_stage + lds[2 * u + 1]) = hi;
+        }
+    }
+};
 __device__ __forceinline__ int swap23(int m) {  // swap bits 2 and 3
     return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
 }
@@ -114,7 +153,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int b, int m, int n
     }
 }
 
-template <int EPI>
+template <int EPI, bool W8>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -167,18 +206,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     const int nk = p.K / BK;
+    // W8: thread (row tid / 2, k half tid % 2) brings 32 fp8 weights per K tile through registers (see W8Lane)
+    W8Lane w8;
+    if (W8) {
+        const int r = tid >> 1, h = tid & 1;
+        int rw = col0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        w8.src = reinterpret_cast<const unsigned char*>(p.W) + (int64_t)rw * p.K + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w8.lds[c] = r * 128 + (((h * 4 + c) ^ ((r >> 1) & 7)) << 4);
+    }
     auto issue = [&](int t, int stage) {
         char* sa = smem + stage * STAGE_BYTES + wave * 4096;
         char* sw = sa + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             glds16(asrc[i] + t * BK, sa + i * 1024);
-            glds16(wsrc[i] + t * BK, sw + i * 1024);
+            if (!W8) glds16(wsrc[i] + t * BK, sw + i * 1024);
         }
+        if (W8) w8.load(t * BK);
     };
 
     issue(0, 0);
     for (int t = 0; t < nk; ++t) {
+        // W8: tile t's weights go to their stage now -- its last readers (tile t - 2) are behind the previous barrier
+        if (W8) {
+            w8.store(smem + (t & 1) * STAGE_BYTES + TILE_BYTES);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -497,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-#define EA_G3_PHASE(S, P, HAS_NEXT, SWAP)                                                                     \
+#define EA_G3_PHASE(S, P, HAS_NEXT, HAS_NEXT2, SWAP, W8)                                                      \
     {                                                                                                         \
         bf16x8 af[4];                                                                                         \
         if (((P) & 1) == 0) {                                                                                 \
@@ -512,13 +567,26 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
                 glds16(asrc[i], dma_a + ((S) ^ 1) * OPER2 + i * 1024);                                        \
             }                                                                                                 \
         }                                                                                                     \
-        if ((P) == 1 && (HAS_NEXT)) {                                                                         \
+        if ((P) == 1 && (HAS_NEXT) && !(W8)) {                                                                \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
                 wsrc[i] += BK;                                                                                \
                 glds16(wsrc[i], dma_w + ((S) ^ 1) * OPER2 + i * 1024);                                        \
             }                                                                                                 \
         }                                                                                                     \
-        if ((P) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+        if ((P) == 2 && (HAS_NEXT) && (W8)) {                                                                 \
+            /* fp8 weights: tile t + 1 (in registers since the previous tile) is widened and written to its   \
+               stage -- phase 3 waits for these stores; then tile t + 2 is requested into the same registers  \
+               and stays in flight across phase 3 (vmcnt(2): the A pieces were issued first) */              \
+            w8.store(smem + 2 * OPER2 + ((S) ^ 1) * OPER2);                                                   \
+            if (HAS_NEXT2) {                                                                                  \
+                w8k += BK;                                                                                    \
+                w8.load(w8k);                                                                                 \
+            }                                                                                                 \
+        }                                                                                                     \
+        if ((P) == 3) {                                                                                       \
+            if ((W8) && (HAS_NEXT2)) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");              \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                  \
+        }                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         __builtin_amdgcn_s_barrier();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -535,19 +603,30 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_s_barrier();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
-#define EA_G3_TILE(S, HAS_NEXT, SWAP) \
-    EA_G3_PHASE(S, 0, HAS_NEXT, SWAP) \
-    EA_G3_PHASE(S, 1, HAS_NEXT, SWAP) \
-    EA_G3_PHASE(S, 2, HAS_NEXT, SWAP) \
-    EA_G3_PHASE(S, 3, HAS_NEXT, SWAP)
+#define EA_G3_TILE(S, HAS_NEXT, HAS_NEXT2, SWAP, W8) \
+    EA_G3_PHASE(S, 0, HAS_NEXT, HAS_NEXT2, SWAP, W8) \
+    EA_G3_PHASE(S, 1, HAS_NEXT, HAS_NEXT2, SWAP, W8) \
+    EA_G3_PHASE(S, 2, HAS_NEXT, HAS_NEXT2, SWAP, W8) \
+    EA_G3_PHASE(S, 3, HAS_NEXT, HAS_NEXT2, SWAP, W8)
 // prologue DMA of tile 0, the staggered start of the two wave groups, the K loop, and the balancing barrier.
 // SWAP = 1 exchanges the MFMA operand roles (activation fragment as A, weight fragment as B): the accumulator tile is
 // then the transpose -- a lane holds 4 consecutive output ROWS of one column (the fused QKV kernel's V^T tiles).
-#define EA_G3_MAINLOOP(SWAP)                                                                    \
+// W8 = the fp8-weight variant (needs `W8Lane w8`, set up by the kernel): W tiles through registers instead of LDS-DMA.
+#define EA_G3_MAINLOOP(SWAP, W8)                                                                \
     {                                                                                           \
+        int w8k = 0;                                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
             glds16(asrc[i], dma_a + i * 1024);                                                  \
-            glds16(wsrc[i], dma_w + i * 1024);                                                  \
+            if (!(W8)) glds16(wsrc[i], dma_w + i * 1024);                                       \
+        }                                                                                       \
+        if (W8) {   /* tile 0 to its stage; tile 1 stays in the registers until phase 2 of tile 0 */     \
+            w8.load(0);                                                                         \
+            w8.store(smem + 2 * OPER2);                                                         \
+            if (nk > 1) {                                                                       \
+                w8k = BK;                                                                       \
+                w8.load(BK);                                                                    \
+            }                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
         }                                                                                       \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         __builtin_amdgcn_s_barrier();                                                           \
@@ -556,17 +635,18 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_sched_barrier(0);                                                      \
         for (int t = 0; t < nk; t += 2) {                                                       \
             const bool n0_ = t + 1 < nk;                                                        \
-            EA_G3_TILE(0, n0_, SWAP)                                                            \
+            const bool n1_ = t + 2 < nk;                                                        \
+            EA_G3_TILE(0, n0_, n1_, SWAP, W8)                                                   \
             if (n0_) {                                                                          \
-                const bool n1_ = t + 2 < nk;                                                    \
-                EA_G3_TILE(1, n1_, SWAP)                                                        \
+                const bool n2_ = t + 3 < nk;                                                    \
+                EA_G3_TILE(1, n1_, n2_, SWAP, W8)                                               \
             }                                                                                   \
         }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
         if (wr == 0) __builtin_amdgcn_s_barrier(); /* balance the stagger */                    \
     }
 
-template <int EPI>
+template <int EPI, bool W8>
 __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -614,8 +694,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
     }
     const int nk = p.K / BK;
     bf16x8 wf[4];
+    W8Lane w8;
+    if (W8) {   // thread (row tid / 2, k half tid % 2): 32 fp8 weights per K tile
+        const int r = tid >> 1, h = tid & 1;
+        int rw = col0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        w8.src = reinterpret_cast<const unsigned char*>(p.W) + (int64_t)rw * p.K + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w8.lds[c] = r * 128 + (((h * 4 + c) ^ (r & 7)) << 4);
+    }
 
-    EA_G3_MAINLOOP(0)
+    EA_G3_MAINLOOP(0, W8)
 
     // ---- epilogue through the wave-private 16 KiB image (rows = the wave's 128 output rows, 128 B = its 64 columns,
     // 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and the read-out already use)
@@ -714,6 +803,7 @@ struct QkvArgs {
     int tiles_m, tiles_n, rows_per_xcd;
 };
 
+template <bool W8>
 __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -765,6 +855,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     }
     const int nk = q.K / BK;
     bf16x8 wf[4];
+    W8Lane w8;
+    if (W8) {   // fp8-stored weights (q.W point at bytes): thread (row tid / 2, k half tid % 2), 32 weights per K tile
+        const int r = tid >> 1, h = tid & 1;
+        w8.src = reinterpret_cast<const unsigned char*>(Wb) + (int64_t)(col0 + r) * q.K + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w8.lds[c] = r * 128 + (((h * 4 + c) ^ (r & 7)) << 4);
+    }
 
     char* const img = smem + wave * 16384;
     const int tok0 = row0 + wr * 128;                 // first token (row of A) of this wave tile
@@ -772,7 +869,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     const int64_t bh = (int64_t)b * q.heads + head;
 
     if (which == 2) {
-        EA_G3_MAINLOOP(1)
+        EA_G3_MAINLOOP(1, W8)
         // ---- v: lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -799,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
         return;
     }
 
-    EA_G3_MAINLOOP(0)
+    EA_G3_MAINLOOP(0, W8)
     // ---- q / k: lane holds features j*16 + lq*4 + 0..3 of token i*16 + lr
     const float* gw = q.nw[which];
     const float* gb = q.nb[which];
@@ -882,7 +979,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
 
 int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of the 256^2 kernel (32: the first version, kept as cross-check)
 
-template <int EPI>
+template <int EPI, bool W8>
 int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
     GemmArgs p = p0;
     const int bm = tile, threads = tile == 256 ? 512 : 256;
@@ -898,50 +995,50 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done[1] = true;
         }
-        if (g_gemm_mfma == 16 && EPI != EA_EPI_F32_OUT) {
+        if ((g_gemm_mfma == 16 || W8) && EPI != EA_EPI_F32_OUT) {
             static bool attr16_done = false;
             if (!attr16_done) {
-                hipFuncSetAttribute((const void*)gemm256_mi16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)gemm256_mi16_kernel<EPI, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 attr16_done = true;
             }
-            ea_count("gemm_256_mi16");
-            hipLaunchKernelGGL(gemm256_mi16_kernel<EPI>, grid, dim3(threads), lds, st, p);
+            ea_count(W8 ? "gemm_256_mi16_w8" : "gemm_256_mi16");
+            hipLaunchKernelGGL((gemm256_mi16_kernel<EPI, W8>), grid, dim3(threads), lds, st, p);
         } else {
             ea_count("gemm_256_mi32");
             hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
         }
     } else {
         if (!attr_done[0]) {
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done[0] = true;
         }
-        ea_count("gemm_128");
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(threads), lds, st, p);
+        ea_count(W8 ? "gemm_128_w8" : "gemm_128");
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, W8>), grid, dim3(threads), lds, st, p);
     }
     return EA_OK;
 }
 
 int g_gemm_tile = 0;   // 0 = auto, 128 / 256 = forced (ea_set_option("gemm_tile", ...), benchmarking only)
 
-}  // namespace
-
-extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16* C,
-                            const ea_bf16* res, const float* gate, int batch, int M, int N, int K, int64_t lda,
-                            int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
-                            int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream) {
+// W8: W points at fp8 (OCP E4M3) bytes, [N, K] K-contiguous (ea_gemm_bf16_w8)
+template <bool W8>
+int gemm_entry(const ea_bf16* A, const void* W, const float* bias, ea_bf16* C, const ea_bf16* res, const float* gate, int batch,
+               int M, int N, int K, int64_t lda, int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
+               int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream) {
     EA_REQUIRE(A && W && C, "ea_gemm_bf16: null tensor");
     EA_REQUIRE(batch > 0 && batch <= 65535 && M >= 0 && N > 0 && K > 0, "ea_gemm_bf16: bad sizes");
     EA_REQUIRE(K % BK == 0, "ea_gemm_bf16: K=%d must be a multiple of %d", K, BK);
     EA_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldc % 8 == 0, "ea_gemm_bf16: N, lda, ldc must be multiples of 8");
     EA_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0, "ea_gemm_bf16: pointers must be 16-byte aligned");
     EA_REQUIRE(epilogue >= 0 && epilogue <= 3, "ea_gemm_bf16: unknown epilogue %d", epilogue);
+    EA_REQUIRE(!(W8 && epilogue == EA_EPI_F32_OUT), "ea_gemm_bf16_w8: no fp32-output epilogue");
     if (epilogue == EA_EPI_BIAS_GATE_RES)
         EA_REQUIRE(res && gate && ldres % 8 == 0 && ((uintptr_t)res % 16 == 0) && ((uintptr_t)gate % 16 == 0),
                    "ea_gemm_bf16: gated-residual epilogue needs aligned res and gate");
     if (bias) EA_REQUIRE((uintptr_t)bias % 16 == 0, "ea_gemm_bf16: bias must be 16-byte aligned");
     if (M == 0) return EA_OK;
     GemmArgs p;
-    p.A = A; p.W = W; p.bias = bias; p.C = C; p.res = res; p.gate = gate;
+    p.A = A; p.W = reinterpret_cast<const unsigned short*>(W); p.bias = bias; p.C = C; p.res = res; p.gate = gate;
     p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.abs_ = a_batch_stride; p.ldc = ldc; p.cbs = c_batch_stride;
     p.ldres = ldres; p.rbs = res_batch_stride; p.gbs = gate_batch_stride;
@@ -951,16 +1048,37 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
         tile = ((int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch >= 512 && N % 256 == 0) ? 256 : 128;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case EA_EPI_BIAS: launch_gemm<0>(p, batch, tile, st); break;
-        case EA_EPI_BIAS_GELU_TANH: launch_gemm<1>(p, batch, tile, st); break;
-        case EA_EPI_F32_OUT: launch_gemm<3>(p, batch, tile, st); break;
-        default: launch_gemm<2>(p, batch, tile, st); break;
+        case EA_EPI_BIAS: launch_gemm<0, W8>(p, batch, tile, st); break;
+        case EA_EPI_BIAS_GELU_TANH: launch_gemm<1, W8>(p, batch, tile, st); break;
+        case EA_EPI_F32_OUT: launch_gemm<3, false>(p, batch, tile, st); break;
+        default: launch_gemm<2, W8>(p, batch, tile, st); break;
     }
-    return ea_check_launch("ea_gemm_bf16");
+    return ea_check_launch(W8 ? "ea_gemm_bf16_w8" : "ea_gemm_bf16");
+}
+
+}  // namespace
+
+extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16* C,
+                            const ea_bf16* res, const float* gate, int batch, int M, int N, int K, int64_t lda,
+                            int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
+                            int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream) {
+    return gemm_entry<false>(A, W, bias, C, res, gate, batch, M, N, K, lda, a_batch_stride, ldc, c_batch_stride, ldres,
+                             res_batch_stride, gate_batch_stride, epilogue, stream);
+}
+
+extern "C" int ea_gemm_bf16_w8(const ea_bf16* A, const uint8_t* W_fp8, const float* bias, ea_bf16* C,
+                               const ea_bf16* res, const float* gate, int batch, int M, int N, int K, int64_t lda,
+                               int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
+                               int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream) {
+    return gemm_entry<true>(A, W_fp8, bias, C, res, gate, batch, M, N, K, lda, a_batch_stride, ldc, c_batch_stride, ldres,
+                            res_batch_stride, gate_batch_stride, epilogue, stream);
 }
 
 
-extern "C" int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
+namespace {
+// W8: Wq / Wk / Wv point at fp8 (OCP E4M3) bytes (ea_qkv_gemm_norm_rope_bf16_w8)
+template <bool W8>
+int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
                                           const float* bq, const float* bk, const float* bv, ea_bf16* q_out,
                                           ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
                                           const float* nk_w, const float* nk_b, const float* cos, const float* sin,
@@ -980,7 +1098,10 @@ extern "C" int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, c
                  (uintptr_t)nk_w | (uintptr_t)nk_b | (uintptr_t)cos | (uintptr_t)sin) & 15) == 0,
                "ea_qkv_gemm_norm_rope_bf16: pointers must be 16-byte aligned");
     QkvArgs q;
-    q.A = A; q.W[0] = Wq; q.W[1] = Wk; q.W[2] = Wv; q.bias[0] = bq; q.bias[1] = bk; q.bias[2] = bv;
+    q.A = A;
+    q.W[0] = reinterpret_cast<const unsigned short*>(Wq);
+    q.W[1] = reinterpret_cast<const unsigned short*>(Wk);
+    q.W[2] = reinterpret_cast<const unsigned short*>(Wv); q.bias[0] = bq; q.bias[1] = bk; q.bias[2] = bv;
     q.q_out = q_out; q.k_out = k_out; q.vt_out = vt_out;
     q.nw[0] = nq_w; q.nb[0] = nq_b; q.nw[1] = nk_w; q.nb[1] = nk_b; q.cosT = cos; q.sinT = sin;
     q.M = M; q.K = K; q.inner = heads * 64; q.heads = heads; q.seq_off = seq_off; q.s_pad = s_pad;
@@ -991,12 +1112,33 @@ extern "C" int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, c
     dim3 grid(q.rows_per_xcd ? 8 * q.rows_per_xcd * q.tiles_n : q.tiles_m * q.tiles_n, batch);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm256_qkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
+        hipFuncSetAttribute((const void*)gemm256_qkv_kernel<W8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
         attr_done = true;
     }
-    ea_count("gemm_qkv_fused");
-    hipLaunchKernelGGL(gemm256_qkv_kernel, grid, dim3(512), GEMM2_LDS, (hipStream_t)stream, q);
-    return ea_check_launch("ea_qkv_gemm_norm_rope_bf16");
+    ea_count(W8 ? "gemm_qkv_fused_w8" : "gemm_qkv_fused");
+    hipLaunchKernelGGL(gemm256_qkv_kernel<W8>, grid, dim3(512), GEMM2_LDS, (hipStream_t)stream, q);
+    return ea_check_launch(W8 ? "ea_qkv_gemm_norm_rope_bf16_w8" : "ea_qkv_gemm_norm_rope_bf16");
+}
+}  // namespace
+
+extern "C" int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
+                                          const float* bq, const float* bk, const float* bv, ea_bf16* q_out,
+                                          ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
+                                          const float* nk_w, const float* nk_b, const float* cos, const float* sin,
+                                          int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
+                                          int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
+    return qkv_entry<false>(A, Wq, Wk, Wv, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, batch, M, heads, K, lda,
+                            a_batch_stride, seq_off, s_pad, ln_eps, q_scale, stream);
+}
+
+extern "C" int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq_fp8, const uint8_t* Wk_fp8, const uint8_t* Wv_fp8,
+                                             const float* bq, const float* bk, const float* bv, ea_bf16* q_out,
+                                             ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
+                                             const float* nk_w, const float* nk_b, const float* cos, const float* sin,
+                                             int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
+                                             int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
+    return qkv_entry<true>(A, Wq_fp8, Wk_fp8, Wv_fp8, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, batch, M, heads, K,
+                           lda, a_batch_stride, seq_off, s_pad, ln_eps, q_scale, stream);
 }
 
 #ifdef EA_GEMM_TIMESTAMPS

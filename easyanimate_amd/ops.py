@@ -19,6 +19,7 @@ EPI_F32_OUT = 3
 
 _BF16 = torch.bfloat16
 _F32 = torch.float32
+_FP8 = torch.float8_e4m3fn   # fp8 weight storage (utils/fp8_optimization.py:17-22 of the reference)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -148,9 +149,14 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
          out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
          gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[b] = epi(A[b] @ W.T + bias).  A bf16 [B,M,K] or [M,K] (row stride free, inner stride 1),
-    W bf16 [N,K] contiguous, bias fp32 [N]; res bf16 like out (may alias out); gate fp32 [B,N]."""
+    W bf16 [N,K] contiguous -- or torch.float8_e4m3fn [N,K] (fp8 weight storage: ea_gemm_bf16_w8 widens the weight inside
+    the kernel, bit-identical to the GEMM on W.to(bf16)) --, bias fp32 [N]; res bf16 like out (may alias out); gate fp32 [B,N]."""
     _dev(A, W, bias, out, res, gate)
-    _chk(A, _BF16, "A"); _chk(W, _BF16, "W")
+    w8 = W.dtype == _FP8
+    _chk(A, _BF16, "A")
+    if not w8:
+        _chk(W, _BF16, "W")
+    assert not (w8 and epilogue == EPI_F32_OUT)
     squeeze = A.dim() == 2
     if squeeze:
         A = A.unsqueeze(0)
@@ -175,7 +181,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
         _chk(res, _BF16, "res"); _chk(gate, _F32, "gate")
         assert res.shape == (B, M, N) and res.stride(2) == 1 and gate.shape == (B, N) and gate.stride(1) == 1
         ldres, rbs, gbs = res.stride(1), res.stride(0), gate.stride(0)
-    _timed("gemm", lambda: _lib.call("ea_gemm_bf16", _p(A), _p(W), _p(bias), _p(out), _p(res), _p(gate), B, M, N, K,
+    _timed("gemm", lambda: _lib.call("ea_gemm_bf16_w8" if w8 else "ea_gemm_bf16", _p(A), _p(W), _p(bias), _p(out), _p(res), _p(gate), B, M, N, K,
                                      A.stride(1), A.stride(0), out.stride(1), out.stride(0), ldres, rbs, gbs, epilogue,
                                      _stream()))
     return out.squeeze(0) if squeeze else out
@@ -221,13 +227,14 @@ def qkv_gemm_norm_rope(x: torch.Tensor, wq, wk, wv, bq, bk, bv, q_out: torch.Ten
     B, n_tok, K = x.shape
     _, H, s_pad, dh = q_out.shape
     assert dh == 64 and x.stride(2) == 1 and q_out.is_contiguous() and k_out.is_contiguous() and vt_out.is_contiguous()
+    w8 = wq.dtype == _FP8          # fp8 weight storage: all three or none
     for w in (wq, wk, wv):
-        _chk(w, _BF16, "W")
+        _chk(w, _FP8 if w8 else _BF16, "W")
         assert w.shape == (H * 64, K) and w.is_contiguous()
     if cos is not None:
         _chk(cos, _F32, "cos"); _chk(sin, _F32, "sin")
         assert cos.shape == (n_tok, 64) and cos.is_contiguous() and sin.is_contiguous()
-    _timed("gemm", lambda: _lib.call("ea_qkv_gemm_norm_rope_bf16", _p(x), _p(wq), _p(wk), _p(wv), _p(bq), _p(bk), _p(bv),
+    _timed("gemm", lambda: _lib.call("ea_qkv_gemm_norm_rope_bf16_w8" if w8 else "ea_qkv_gemm_norm_rope_bf16", _p(x), _p(wq), _p(wk), _p(wv), _p(bq), _p(bk), _p(bv),
                                      _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b), _p(nk_w), _p(nk_b), _p(cos),
                                      _p(sin), B, n_tok, H, K, x.stride(1), x.stride(0), seq_off, s_pad, float(eps),
                                      float(q_scale), _stream()))

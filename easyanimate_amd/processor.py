@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import ops
-from ._params import bf16_weight, f32
+from ._params import f32, gemm_weight
 
 _ws: Dict[tuple, dict] = {}
 
@@ -151,7 +151,7 @@ class EasyAnimateAttnProcessor2_0:
             nq, nk = mod.norm_q, mod.norm_k
             if self.fuse_qkv and ops.qkv_fused_ok(n_tok, d, inp.shape[2], seq_off):
                 # one launch: the [B, n, 3d] QKV buffer never exists (ea_qkv_gemm_norm_rope_bf16)
-                ops.qkv_gemm_norm_rope(inp, bf16_weight(lq.weight), bf16_weight(lk.weight), bf16_weight(lv.weight),
+                ops.qkv_gemm_norm_rope(inp, gemm_weight(lq.weight), gemm_weight(lk.weight), gemm_weight(lv.weight),
                                        f32(lq.bias), f32(lk.bias), f32(lv.bias), ws["q"], ws["k"], ws["vt"],
                                        f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias), c, s_, seq_off, nq.eps,
                                        q_scale=ops.FOLDED_Q_SCALE)
@@ -159,7 +159,7 @@ class EasyAnimateAttnProcessor2_0:
             # three GEMMs into one [B, n, 3d] buffer, then one normalise / rotate / scatter pass
             qkv = torch.empty(B, n_tok, 3 * d, dtype=torch.bfloat16, device=dev)
             for i, lin in enumerate((lq, lk, lv)):
-                ops.gemm(inp, bf16_weight(lin.weight), f32(lin.bias), ops.EPI_BIAS, out=qkv[:, :, i * d:(i + 1) * d])
+                ops.gemm(inp, gemm_weight(lin.weight), f32(lin.bias), ops.EPI_BIAS, out=qkv[:, :, i * d:(i + 1) * d])
             ops.qknorm_rope(qkv, ws["q"], ws["k"], ws["vt"], f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias),
                             c, s_, seq_off, nq.eps, q_scale=ops.FOLDED_Q_SCALE)
 
@@ -174,13 +174,13 @@ class EasyAnimateAttnProcessor2_0:
         if residual is not None:
             g_v = gate.reshape(B, d)
             g_t = encoder_gate.reshape(B, d)
-            h_out = ops.gemm(o_v, bf16_weight(lo_v.weight), f32(lo_v.bias), ops.EPI_BIAS_GATE_RES,
+            h_out = ops.gemm(o_v, gemm_weight(lo_v.weight), f32(lo_v.bias), ops.EPI_BIAS_GATE_RES,
                              res=_bf16c(residual), gate=g_v)
-            e_out = ops.gemm(o_t, bf16_weight(lo_t.weight), f32(lo_t.bias), ops.EPI_BIAS_GATE_RES,
+            e_out = ops.gemm(o_t, gemm_weight(lo_t.weight), f32(lo_t.bias), ops.EPI_BIAS_GATE_RES,
                              res=_bf16c(encoder_residual), gate=g_t)
         else:
-            h_out = ops.gemm(o_v, bf16_weight(lo_v.weight), f32(lo_v.bias), ops.EPI_BIAS)
-            e_out = ops.gemm(o_t, bf16_weight(lo_t.weight), f32(lo_t.bias), ops.EPI_BIAS)
+            h_out = ops.gemm(o_v, gemm_weight(lo_v.weight), f32(lo_v.bias), ops.EPI_BIAS)
+            e_out = ops.gemm(o_t, gemm_weight(lo_t.weight), f32(lo_t.bias), ops.EPI_BIAS)
         return h_out, e_out
 
 

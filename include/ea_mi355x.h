@@ -115,6 +115,16 @@ int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16*
                  int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
                  int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream);
 
+/* The same GEMM with the weight stored as fp8: W_fp8 = torch.float8_e4m3fn (OCP E4M3) bytes, [N,K] row-major, the storage
+ * mode of the reference's `model_cpu_offload_and_qfloat8` (utils/fp8_optimization.py:17-35 keeps every Linear weight in fp8
+ * and up-casts it to bf16 for each call).  The kernel reads the fp8 bytes, widens them to bf16 on the way into the LDS
+ * (exact) and runs the same MFMAs: results are bit-identical to ea_gemm_bf16 on the up-cast weight; the weight costs one
+ * byte per element in HBM and no bf16 copy exists.  EA_EPI_F32_OUT is not offered. */
+int ea_gemm_bf16_w8(const ea_bf16* A, const uint8_t* W_fp8, const float* bias, ea_bf16* C,
+                    const ea_bf16* res, const float* gate, int batch, int M, int N, int K, int64_t lda,
+                    int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
+                    int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream);
+
 /* ---- attention ----------------------------------------------------------------------------- */
 
 /* qk-LayerNorm(head_dim=64) + interleaved RoPE + head-major scatter, one pass over a QKV buffer.
@@ -151,6 +161,13 @@ int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf1
                                const float* nk_b, const float* cos, const float* sin, int batch, int M, int heads,
                                int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, float ln_eps,
                                float q_scale, void* stream);
+/* ... with the three weights stored as fp8 (see ea_gemm_bf16_w8): bit-identical to ea_qkv_gemm_norm_rope_bf16 on the up-cast weights. */
+int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq_fp8, const uint8_t* Wk_fp8, const uint8_t* Wv_fp8,
+                                  const float* bq, const float* bk, const float* bv, ea_bf16* q_out, ea_bf16* k_out,
+                                  ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
+                                  const float* nk_b, const float* cos, const float* sin, int batch, int M, int heads,
+                                  int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, float ln_eps,
+                                  float q_scale, void* stream);
 
 /* Non-causal, unmasked softmax(Q K^T * scale) V, head_dim 64, bf16 in/out, fp32 softmax state.
  * Replaces F.scaled_dot_product_attention at processor.py:287-289 plus the transpose/reshape at :291.

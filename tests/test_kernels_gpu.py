@@ -329,6 +329,94 @@ def test_qkv_fused_matches_unfused(B, H, M, K, seq_off, use_rope):
     assert torch.equal(q3, q1) and torch.equal(k3, k1) and torch.equal(vt3, vt1)
 
 
+W8_SHAPES = [
+    # B, M, N, K, tile: both kernels, M / N tails, odd / even K-tile counts, strided batch
+    (1, 128, 128, 64, 128), (2, 300, 320, 192, 128), (1, 512, 3072, 3072, 128),
+    (1, 256, 256, 64, 256), (2, 700, 768, 1024, 256), (1, 16500, 320, 320, 256), (1, 2048, 12288, 256, 256),
+]
+
+
+@pytest.mark.parametrize("B,M,N,K,tile", W8_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_fp8_weight_bit_identical(B, M, N, K, tile, epi):
+    """ea_gemm_bf16_w8 (weight stored as float8_e4m3fn, widened inside the kernel; the storage mode of
+    utils/fp8_optimization.py:17-35) against ea_gemm_bf16 on W.to(bfloat16) -- what the reference's per-call up-cast
+    computes with: every bit agrees, for both tile sizes and every epilogue."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(29)
+    A = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+    W8 = (torch.randn(N, K, generator=g) / math.sqrt(K) * 4).to(torch.float8_e4m3fn).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = _bf(torch.randn(B, M, N, generator=g)).to(DEV) if epi == 2 else None
+    gate = torch.randn(B, N, generator=g).to(DEV) if epi == 2 else None
+    _lib.set_option("gemm_tile", tile)
+    try:
+        _lib.reset_counters()
+        y8 = ops.gemm(A, W8, bias, epi, res=res, gate=gate)
+        assert _lib.counters() == {("gemm_256_mi16_w8" if tile == 256 else "gemm_128_w8"): 1}
+        yb = ops.gemm(A, W8.to(torch.bfloat16), bias, epi, res=res, gate=gate)
+        assert torch.equal(y8, yb)
+        for _ in range(3):                                   # race screen of the register-staged weight path
+            assert torch.equal(ops.gemm(A, W8, bias, epi, res=res, gate=gate), y8)
+    finally:
+        _lib.set_option("gemm_tile", 0)
+    ref = A.double() @ W8.to(torch.float32).double().t() + bias.double()
+    if epi == 0:
+        err, rel = _report(f"gemm fp8-weight B{B} {M}x{N}x{K} tile{tile}", y8, ref)
+        assert rel < 4e-3
+
+
+def test_fp8_widening_is_exact_for_every_code():
+    """All 254 finite E4M3 codes through the in-kernel fp8 -> bf16 widening: one-hot activations pick single weights, so
+    C[m, n] must equal float(W[n, m]) exactly (checks the OCP E4M3 decoding of v_cvt_pk_f32_fp8 on gfx950 against torch)."""
+    ops = _ops()
+    codes = torch.arange(256, dtype=torch.uint8)
+    codes[codes == 0x7F] = 0
+    codes[codes == 0xFF] = 0x80                                  # the two NaN codes: not weights
+    W8 = codes.repeat(256 * 64 // 256).view(256, 64).contiguous()          # row n, column k: code (64 n + k) % 256
+    W8 = W8.view(torch.float8_e4m3fn).to(DEV)
+    A = torch.zeros(128, 64, dtype=torch.bfloat16)
+    A[torch.arange(128), torch.arange(128) % 64] = 1.0
+    for tile in (128, 256):
+        from easyanimate_amd import _lib
+        _lib.set_option("gemm_tile", tile)
+        try:
+            y = ops.gemm(A.to(DEV), W8, None, 0)                  # y[m, n] = W[n, m % 64]
+        finally:
+            _lib.set_option("gemm_tile", 0)
+        want = W8.to(torch.float32).t()[torch.arange(128) % 64]   # [m, n]
+        assert torch.equal(y.float(), want), tile
+
+
+@pytest.mark.parametrize("B,H,M,K,seq_off", [(2, 4, 512, 128, 8), (1, 48, 768, 3072, 256)])
+def test_qkv_fused_fp8_weight_bit_identical(B, H, M, K, seq_off):
+    """ea_qkv_gemm_norm_rope_bf16_w8 against ea_qkv_gemm_norm_rope_bf16 on the up-cast weights."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(31)
+    d = H * 64
+    x = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+    w8 = [(torch.randn(d, K, generator=g) / K ** 0.5 * 4).to(torch.float8_e4m3fn).to(DEV) for _ in range(3)]
+    bs = [(0.3 * torch.randn(d, generator=g)).to(DEV) for _ in range(3)]
+    nw = [(1 + 0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    nb = [(0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    ang = torch.rand(M, 32, generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV), ang.sin().repeat_interleave(2, 1).contiguous().to(DEV)
+    s_pad = ops.round_up(seq_off + M, 256)
+    outs = []
+    for ws in (w8, [w.to(torch.bfloat16) for w in w8]):
+        q, k = (torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        vt = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=DEV)
+        _lib.reset_counters()
+        ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q, k, vt, nw[0], nb[0], nw[1], nb[1], cos, sin, seq_off, 1e-6,
+                               q_scale=ops.FOLDED_Q_SCALE)
+        assert _lib.counters() == {("gemm_qkv_fused_w8" if ws is w8 else "gemm_qkv_fused"): 1}
+        outs.append((q, k, vt))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _attn_inputs(B, H, S, seed, scale_q=1.0):
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(seed)

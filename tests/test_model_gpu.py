@@ -162,8 +162,9 @@ def test_teacache_kernels():
 
 def test_fp8_weight_storage_and_lora_merge_are_observed():
     """SURVEY 8(f) rank 2.  (a) fp8 weight storage (utils/fp8_optimization.py:17-22 stores every parameter as
-    float8_e4m3fn and up-casts per call): the kernels read weights through the derived-parameter cache, which up-casts
-    once -- the output equals that of a model holding the fp8-rounded values in bf16, bit for bit.  (b) LoRA merge
+    float8_e4m3fn and up-casts per call): the block GEMMs read the fp8 parameters themselves (W8 kernels), everything
+    else goes through the derived-parameter cache, which up-casts once -- the output equals that of a model holding the
+    fp8-rounded values in bf16, bit for bit.  (b) LoRA merge
     (utils/lora_utils.py:369-433 does `weight.data += delta`): bf16 Linear weights are read in place, so the merged
     weights are used by the very next forward; derived copies (fp32 masters, the 4-D patch-embedding kernel) need
     easyanimate_amd.invalidate_weight_cache() because `.data` writes do not bump the version counter."""
@@ -183,8 +184,20 @@ def test_fp8_weight_storage_and_lora_merge_are_observed():
             q = p8.data.to(torch.float8_e4m3fn)
             p8.data = q                                   # what convert_model_weight_to_float8 does
             pq.data = q.to(torch.bfloat16)                # the values an up-cast per call would compute with
+        from easyanimate_amd import _lib, _params
+        _lib.reset_counters()
         y8, yq = fwd(m8), fwd(mq)
         assert torch.equal(y8, yq)
+        # the block GEMMs read the fp8 parameters themselves (ea_gemm_bf16_w8: widened inside the kernel, no bf16 copy) ...
+        c = _lib.counters()
+        assert c.get("gemm_128_w8", 0) >= 8 * g["cfg"]["num_layers"], c
+        # ... and the other route through the same storage (up-cast once into the derived-parameter cache) agrees bit for bit
+        _params.FP8_NATIVE_GEMM = False
+        try:
+            _lib.reset_counters()
+            assert torch.equal(fwd(m8), y8) and not any(k.endswith("_w8") for k in _lib.counters())
+        finally:
+            _params.FP8_NATIVE_GEMM = True
         assert not torch.equal(y8, y0) and (y8.float() - y0.float()).abs().max().item() < 0.5   # fp8 rounding is visible, not wild
         # ---- (b) LoRA merge into bf16 Linear weights, in place through .data
         ml = copy.deepcopy(base)

@@ -16,7 +16,11 @@ for (M, N, K, epi) in [(106496, 12288, 3072, 1), (106496, 3072, 12288, 2), (1064
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     gate = torch.randn(1, N, device="cuda")
     fn = (lambda: ops.gemm(A, W, bias, 2, out=out, res=out, gate=gate)) if epi == 2 else (lambda: ops.gemm(A, W, bias, epi, out=out))
+    W8 = W.to(torch.float8_e4m3fn)
+    fn8 = (lambda: ops.gemm(A, W8, bias, 2, out=out, res=out, gate=gate)) if epi == 2 else (lambda: ops.gemm(A, W8, bias, epi, out=out))
     for rep in range(2):
+        ms = timeit(fn8, warm=2, iters=7)
+        print(json.dumps({"lib": lib, "kernel": "gemm, fp8-stored weight", "M": M, "N": N, "K": K, "epi": epi, "ms": round(ms, 4), "TFLOPs": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
         ms = timeit(fn, warm=2, iters=7)
         print(json.dumps({"lib": lib, "kernel": "gemm", "M": M, "N": N, "K": K, "epi": epi, "ms": round(ms, 4), "TFLOPs": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
     del A, W, out
@@ -33,6 +37,10 @@ q = torch.zeros(B, H, s_pad, 64, device="cuda", dtype=torch.bfloat16); k = torch
 vt = torch.zeros(B, H, 64, s_pad, device="cuda", dtype=torch.bfloat16)
 fl = 2.0 * B * M * 3 * d * K
 fused = lambda: ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q, k, vt, nw[0], nb[0], nw[1], nb[1], cos, sin, 256, 1e-6, q_scale=ops.FOLDED_Q_SCALE)
+w8s = [w.to(torch.float8_e4m3fn) for w in ws]
+fused8 = lambda: ops.qkv_gemm_norm_rope(x, w8s[0], w8s[1], w8s[2], bs[0], bs[1], bs[2], q, k, vt, nw[0], nb[0], nw[1], nb[1], cos, sin, 256, 1e-6, q_scale=ops.FOLDED_Q_SCALE)
 for rep in range(2):
+    ms = timeit(fused8, warm=2, iters=7)
+    print(json.dumps({"lib": lib, "kernel": "qkv fused, fp8-stored weights", "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}), flush=True)
     ms = timeit(fused, warm=2, iters=7)
     print(json.dumps({"lib": lib, "kernel": "qkv fused", "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}), flush=True)
