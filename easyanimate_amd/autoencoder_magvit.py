@@ -237,6 +237,13 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         if x.dim() != 5:
             raise ValueError("expected [B, C, F, H, W]")
 
+    @property
+    def _enc_c_pad(self):
+        """Channel padding of the encoder's input layout: <= 8 input channels (RGB) travel as one 16-byte chunk per voxel, the
+        form the 8-channel implicit-GEMM kernel gathers (vae_modules._conv_cl_local)."""
+        ci = self.encoder.conv_in.in_channels
+        return 8 if ci <= 8 else None
+
     def encode(self, x: torch.Tensor, return_dict: bool = True) -> Union[AutoencoderKLOutput, Tuple[DiagonalGaussianDistribution]]:
         self._check(x)
         if x.shape[2] != 1 and (x.shape[2] - 1) % self.mini_batch_encoder != 0:
@@ -252,7 +259,7 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
             if xb.dtype not in (torch.float32, torch.bfloat16):
                 xb = xb.float()
             if tp is None:
-                h = self.encoder(ops.ncdhw_to_ndhwc(xb.contiguous()))
+                h = self.encoder(ops.ncdhw_to_ndhwc(xb.contiguous(), self._enc_c_pad))
                 m = conv_cl(self.quant_conv, h)  # 1x1x1
                 moments.append(ops.ndhwc_to_ncdhw(m, self.quant_conv.out_channels, odt))
                 continue
@@ -265,7 +272,7 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
             m_loc = None
             if tp.is_active:
                 with vae_parallel.activate(tp):
-                    h = self.encoder(ops.ncdhw_to_ndhwc(xb[:, fr[0]:fr[1]].contiguous()))
+                    h = self.encoder(ops.ncdhw_to_ndhwc(xb[:, fr[0]:fr[1]].contiguous(), self._enc_c_pad))
                     m_loc = ops.ndhwc_to_ncdhw(conv_cl(self.quant_conv, h), self.quant_conv.out_channels, odt)
             like = torch.empty((self.quant_conv.out_channels, 1, xb.shape[2] // 8, xb.shape[3] // 8), dtype=odt, device=xb.device)
             moments.append(tp.gather_frames(m_loc, ranges, 1, like))

@@ -53,6 +53,11 @@ __device__ __forceinline__ void bdma16(const void* base, int extent, int voff, i
 }
 __device__ __forceinline__ int swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
+// C8: the 8-channel input layers (encoder conv_in: RGB padded to 8 channels = one 16-byte chunk per voxel).  A K tile is then
+// eight TAPS, one chunk each: the lane that stages chunk c of a row gathers it from the voxel tap 8 t + c selects (taps
+// beyond kt*kh*kw read the page of zeros; the packed weight has zero columns there).  27 taps = 4 K tiles instead of an
+// im2col pass (a 13 GB round trip at 49 x 1024^2) followed by a GEMM.
+template <bool C8>
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -90,13 +95,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
         int64_t m = row0 + r;
         vvalid[i] = m < p.M;
         m = vvalid[i] ? m : p.M - 1;
-        vw[i] = (int)(m % p.W_out);
-        const int64_t q = m / p.W_out;
-        vh[i] = (int)(q % p.H_out);
-        vt[i] = (int)(q / p.H_out);
+        if (C8) {   // (the host checks M < 2^31 for this path: 32-bit divisions -- a workgroup only runs four K tiles)
+            const unsigned m32 = (unsigned)m, q32 = m32 / (unsigned)p.W_out;
+            vw[i] = (int)(m32 - q32 * (unsigned)p.W_out);
+            vt[i] = (int)(q32 / (unsigned)p.H_out);
+            vh[i] = (int)(q32 - (unsigned)vt[i] * (unsigned)p.H_out);
+        } else {
+            vw[i] = (int)(m % p.W_out);
+            const int64_t q = m / p.W_out;
+            vh[i] = (int)(q % p.H_out);
+            vt[i] = (int)(q / p.H_out);
+        }
         int rw = col0 + r;
         rw = rw < p.C_out ? rw : p.C_out - 1;
-        wsrc[i] = p.w + (int64_t)rw * ((int64_t)p.kt * p.kh * p.kw * p.C_in) + csw[i];
+        const int64_t wk = C8 ? (int64_t)((p.kt * p.kh * p.kw + 7) / 8) * BK : (int64_t)p.kt * p.kh * p.kw * p.C_in;
+        wsrc[i] = p.w + (int64_t)rw * wk + csw[i];
     }
 
     f32x16 acc[2][2];
@@ -118,31 +131,39 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
         w_sw[i] = (rw >> 1) & 7;
     }
 
-    const int cblocks = p.C_in / BK;
+    const int cblocks = C8 ? 1 : p.C_in / BK;
     const int ntaps = p.kt * p.kh * p.kw;
-    const int nk = ntaps * cblocks;
+    const int nk = C8 ? (ntaps + 7) / 8 : ntaps * cblocks;
     const int H_eff = p.ups ? p.H_in * 2 : p.H_in;
     const int W_eff = p.ups ? p.W_in * 2 : p.W_in;
 
     auto issue = [&](int t, int stage) {
-        const int tap = t / cblocks, cb = t - tap * cblocks;
-        const int dw = tap % p.kw;
-        const int dh = (tap / p.kw) % p.kh;
-        const int dt = tap / (p.kw * p.kh);
+        int tap = t / cblocks;
+        const int cb = t - tap * cblocks;
+        int dw = tap % p.kw;
+        int dh = (tap / p.kw) % p.kh;
+        int dt = tap / (p.kw * p.kh);
         char* sa = smem + stage * STAGE_BYTES + wave * 4096;
         char* sw = sa + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (C8) {   // per lane: the tap of this lane's chunk (3 x 3 x 3: constant divisors)
+                tap = t * 8 + (csw[i] >> 3);
+                dt = tap / 9;
+                const int r9 = tap - dt * 9;
+                dh = r9 / 3;
+                dw = r9 - dh * 3;
+            }
             int ti = vt[i] * p.st + dt - (p.kt - 1);
             ti = ti < 0 ? 0 : ti;  // causal replicate padding
             int hh = vh[i] * p.ss + dh - p.pad;
             int ww = vw[i] * p.ss + dw - p.pad;
-            const bool ok = (unsigned)hh < (unsigned)H_eff && (unsigned)ww < (unsigned)W_eff;
+            const bool ok = (unsigned)hh < (unsigned)H_eff && (unsigned)ww < (unsigned)W_eff && (!C8 || tap < ntaps);
             hh >>= (p.ups ? 1 : 0);
             ww >>= (p.ups ? 1 : 0);
             const unsigned vox = (unsigned)((ti * p.H_in + hh) * p.W_in + ww);   // < 2^31 voxels per clip
-            const unsigned short* src = p.x + (uint64_t)vox * (unsigned)p.C_in + cb * BK;
-            src = (ok ? src : p.zeros) + csw[i];
+            const unsigned short* src = C8 ? p.x + (uint64_t)vox * 8u : p.x + (uint64_t)vox * (unsigned)p.C_in + cb * BK + csw[i];
+            src = ok ? src : p.zeros + csw[i];
             glds16(src, sa + i * 1024);
             glds16(wsrc[i] + (int64_t)t * BK, sw + i * 1024);
         }
@@ -1332,7 +1353,9 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
                           int* gn_nblk_out, void* stream) {
     if (gn_nblk_out) *gn_nblk_out = 0;
     EA_REQUIRE(x && w && y && zeros, "ea_conv3d_cl_bf16: null tensor");
-    EA_REQUIRE(C_in > 0 && C_in % BK == 0, "ea_conv3d_cl_bf16: C_in=%d must be a multiple of 64 (use ea_im2col3d_bf16 + ea_gemm_bf16)", C_in);
+    EA_REQUIRE(C_in == 8 || (C_in > 0 && C_in % BK == 0),
+               "ea_conv3d_cl_bf16: C_in=%d must be 8 or a multiple of 64 (otherwise ea_im2col3d_bf16 + ea_gemm_bf16)", C_in);
+    EA_REQUIRE(!(C_in == 8 && (kt != 3 || ups || tdup)), "ea_conv3d_cl_bf16: the 8-channel layers are plain 3x3x3 convolutions");
     EA_REQUIRE(C_out > 0 && C_out % 8 == 0, "ea_conv3d_cl_bf16: C_out must be a multiple of 8");
     EA_REQUIRE((kt == 3 && kh == 3 && kw == 3) || (kt == 1 && kh == 1 && kw == 1), "ea_conv3d_cl_bf16: kernel must be 3x3x3 or 1x1x1");
     EA_REQUIRE((st == 1 || st == 2) && (ss == 1 || ss == 2) && (pad == 0 || pad == 1), "ea_conv3d_cl_bf16: bad stride/pad");
@@ -1354,6 +1377,21 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     p.W_out = conv_out_dim(We, kw, ss, pad, pad_hi);
     p.M = (int64_t)p.T_out * p.H_out * p.W_out;
     EA_REQUIRE(p.M > 0 && p.M < (1ll << 40), "ea_conv3d_cl_bf16: bad output size");
+    if (C_in == 8) {   // one 16-byte chunk per voxel: eight taps per K tile (conv3d_cl_kernel<true>)
+        EA_REQUIRE(p.M < (1ll << 31), "ea_conv3d_cl_bf16: too many output voxels for the 8-channel kernel");
+        p.tiles_m = (int)((p.M + BM - 1) / BM);
+        p.tiles_n = (C_out + BN - 1) / BN;
+        const int64_t grid8 = (int64_t)8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+        EA_REQUIRE(grid8 < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
+        static bool attr8_done = false;
+        if (!attr8_done) {
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+            attr8_done = true;
+        }
+        ea_count("conv_c8_128x128");
+        hipLaunchKernelGGL(conv3d_cl_kernel<true>, dim3((unsigned)grid8), dim3(256), CONV_LDS, (hipStream_t)stream, p);
+        return ea_check_launch("ea_conv3d_cl_bf16");
+    }
     // ping-pong kernels: C_out a multiple of 128 and enough tiles to fill the chip
     const int bn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 0);
     const int64_t tiles256 = (p.M + 255) / 256;
@@ -1491,11 +1529,11 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     EA_REQUIRE(grid < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+        (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
         attr_done = true;
     }
     ea_count("conv_128x128");
-    hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)grid), dim3(256), CONV_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv3d_cl_kernel<false>, dim3((unsigned)grid), dim3(256), CONV_LDS, (hipStream_t)stream, p);
     return ea_check_launch("ea_conv3d_cl_bf16");
 }
 

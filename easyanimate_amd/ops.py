@@ -443,6 +443,8 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
               pad: int = 1, ups: bool = False, tdup: bool = False, res: Optional[torch.Tensor] = None,
               want_stats: bool = True) -> torch.Tensor:
     """x bf16 [T,H,W,Cin] (Cin % 64 == 0), w_packed bf16 [Cout, k^3*Cin] -> bf16 [T',H',W',Cout].
+    Cin == 8 (RGB padded to one 16-byte chunk per voxel; k = 3): w_packed [Cout, 256] = 32 tap slots x 8 channels, zero beyond
+    tap 26 / the real channels (pack_conv_weight_c8).
     If the row-slab kernel serves the call it also leaves the per-frame GroupNorm partial sums of its output on the
     returned tensor (`y.gn_partial = (partial, nblk)`): groupnorm_silu() then skips its statistics pass."""
     _dev(x, w_packed, bias, res)
@@ -450,7 +452,7 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     assert x.is_contiguous() and w_packed.is_contiguous() and x.dim() == 4
     T, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
-    assert w_packed.shape[1] == k * k * k * Cin
+    assert w_packed.shape[1] == (256 if Cin == 8 else k * k * k * Cin)
     To, Ho, Wo = conv_out_shape(T, H, W, k, st, ss, pad, ups)
     Ty = 2 * To - 1 if (tdup and To > 1) else To
     y = torch.empty((Ty, Ho, Wo, Cout), dtype=_BF16, device=x.device)

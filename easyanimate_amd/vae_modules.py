@@ -64,6 +64,15 @@ def conv_cl(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None
     return out
 
 
+def _pack_conv_weight_c8(w: torch.Tensor, n_pad: int) -> torch.Tensor:
+    """[Cout, Cin <= 8, 3, 3, 3] -> bf16 [n_pad, 256]: 32 tap slots x 8 channels (tap-major), zeros in the five unused tap
+    slots, the padded channels and the padded rows -- the layout conv3d_cl_kernel<C8> reads (ea_conv3d_cl_bf16, C_in == 8)."""
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.zeros((n_pad, 32, 8), dtype=torch.bfloat16, device=w.device)
+    out[:co, :27, :ci] = w.permute(0, 2, 3, 4, 1).reshape(co, 27, ci).to(torch.bfloat16)
+    return out.view(n_pad, 256)
+
+
 def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None, ups: bool = False,
                    tdup: bool = False) -> torch.Tensor:
     co, ci, kt, kh, kw = conv.weight.shape
@@ -72,8 +81,15 @@ def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor]
     assert sh == sw
     pad = conv.padding[1] if kt == 3 else 0
     n_pad = ops.round_up(co, 8)
-    if x.shape[-1] != ci:
+    c8 = ci <= 8 and kt == 3 and x.shape[-1] == 8 and res is None and not ups and not tdup
+    if x.shape[-1] != ci and not c8:
         raise ValueError(f"conv expects {ci} input channels, got {x.shape[-1]}")
+    if c8:
+        # <= 8 input channels, handed over padded to 8 (one 16-byte chunk per voxel; the encoder's conv_in on RGB): the
+        # implicit-GEMM kernel gathers eight taps per K tile -- no im2col buffer
+        w = derived(conv.weight, f"c8_{n_pad}", lambda t: _pack_conv_weight_c8(t, n_pad))
+        b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None
+        return ops.conv3d_cl(x, w, b, kt, st, sh, pad)
     if (ci % 64 == 0 and co <= 4 and kt == 3 and (st, sh, pad) == (1, 1, 1) and res is None and not ups and not tdup
             and (x.shape[0] * x.shape[1] * x.shape[2]) % 8 == 0):
         # narrow-N convolution (decoder conv_out 128 -> 3): one GEMM over the input voxels + a 27-tap gather

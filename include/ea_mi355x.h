@@ -271,8 +271,11 @@ int ea_gated_residual_bf16(const ea_bf16* x, const ea_bf16* res, const float* ga
 /* Causal 3-D convolution as an im2col-free implicit GEMM (vaemodules/common.py:84-179 CausalConv3d; the
  * strided down-samplers downsamplers.py:24-94; the up-samplers upsamplers.py:21-37,123-153; the residual add of
  * ResidualBlock3D common.py:322).
- *   x : bf16 [T_in, H_in, W_in, C_in]      C_in % 64 == 0
+ *   x : bf16 [T_in, H_in, W_in, C_in]      C_in % 64 == 0, or C_in == 8 (below)
  *   w : bf16 [C_out, kt*kh*kw*C_in]        (the [C_out,C_in,kt,kh,kw] parameter permuted to tap-major)
+ * C_in == 8 (3x3x3 only; the encoder's conv_in on RGB padded to one 16-byte chunk per voxel, omnigen_enc_dec.py:100-107):
+ *   w : bf16 [C_out, 256] = 32 tap slots x 8 channels, zero in slots 27..31 and in the padded channels; a K tile is
+ *   eight taps gathered by address (no im2col buffer).
  *   y : bf16 [T_out, H_out, W_out, C_out]  C_out % 8 == 0
  * Temporal padding = kt-1 replicated leading frames (identical to the reference's chunk caches, SURVEY 8c
  * property 1); spatial padding `pad` zeros on the low side and, for the pad-0 strided convs, one zero

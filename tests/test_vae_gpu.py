@@ -332,6 +332,44 @@ def test_small_cin_conv_via_im2col():
             assert y[..., co:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("ci,co,T,H,W,st,ss,pad", [(3, 128, 5, 33, 40, 1, 1, 1), (3, 64, 4, 9, 10, 1, 1, 1), (8, 128, 3, 16, 24, 1, 1, 1),
+                                                  (1, 256, 2, 20, 20, 1, 1, 1), (3, 128, 5, 16, 18, 2, 2, 0)])
+def test_conv_8_channel_input(ci, co, T, H, W, st, ss, pad):
+    """conv3d_cl_kernel<C8> (the encoder's conv_in: RGB handed over as 8 channels, omnigen_enc_dec.py:100-107): eight taps
+    per K tile gathered by address, against fp64 F.conv3d with causal replicate padding -- through the module's dispatch
+    -- and bit-identical to the im2col + GEMM route it replaces for the same K order?  No: another K layout (tap slots of 8),
+    so fp32 summation-order noise only."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import CausalConv3d
+    g = torch.Generator().manual_seed(41)
+    conv = CausalConv3d(ci, co, kernel_size=3, stride=(st, ss, ss), padding=pad)
+    with torch.no_grad():
+        conv.weight.copy_(_bf(torch.randn(conv.weight.shape, generator=g) / (27 * ci) ** 0.5).float())
+        conv.bias.copy_(torch.randn(co, generator=g))
+    x = _bf(torch.randn(1, ci, T, H, W, generator=g))
+    xr = x.double()
+    if pad == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    xr = F.pad(xr, (0, 0, 0, 0, 2, 0), mode="replicate")
+    ref = F.conv3d(xr, conv.weight.double(), conv.bias.double(), stride=(st, ss, ss), padding=(0, pad, pad))
+    conv = conv.to(DEV)
+    x8 = ops.ncdhw_to_ndhwc(x[0].contiguous().to(DEV), 8)
+    assert x8.shape == (T, H, W, 8) and (ci == 8 or x8[..., ci:].abs().max().item() == 0)
+    _lib.reset_counters()
+    y = conv(x8)
+    assert _lib.counters() == {"conv_c8_128x128": 1}
+    got = y[..., :co].permute(3, 0, 1, 2)[None]
+    assert got.shape == ref.shape
+    err, rel = _rep(f"conv 8-channel input {ci}->{co} s{st}{ss}", got, ref)
+    assert rel < 4e-3
+    for _ in range(3):
+        assert torch.equal(conv(x8), y)
+    # the im2col + GEMM route on the unpadded layout agrees to summation-order noise
+    y2 = conv(x[0].permute(1, 2, 3, 0).contiguous().to(DEV))
+    d = (y2.float() - y.float()).abs()
+    assert bool((d <= 2 ** -6 * y2.float().abs().clamp_min(1.0)).all())
+
+
 @pytest.mark.parametrize("T,HW,C,G", [(3, 100, 64, 16), (2, 5000, 128, 32), (1, 4096, 512, 32), (4, 333, 256, 32)])
 def test_groupnorm_silu(T, HW, C, G):
     from easyanimate_amd import ops
