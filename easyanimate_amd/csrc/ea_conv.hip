@@ -196,6 +196,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
 
     // ---- epilogue: lane owns voxel m, channels n0..n0+7
     const int64_t frame = (int64_t)p.H_out * p.W_out;
+    // GroupNorm partial sums of the output (see conv3d_cl_row16_kernel): the host enables them only when a 128-voxel tile
+    // never straddles two frames and nothing is duplicated; [j][g][4-channel bundle]
+    const bool has_gn = p.gn_partial != nullptr;
+    float gs[2][2][2], gq[2][2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) gs[j][g][b] = gq[j][g][b] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int64_t m = row0 + wm * 64 + i * 32 + l31;
@@ -236,8 +246,41 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
                 *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
                 if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
+                if (has_gn) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float r = bf16_bits_to_f32(o[e]);   // the value the next layer's GroupNorm reads
+                        gs[j][g][e >> 2] += r;
+                        gq[j][g][e >> 2] += r * r;
+                    }
+                }
             }
         }
+    }
+    if (has_gn) {
+        // 32 lanes (l31) hold the 64 voxels of the wave tile, two each: fixed-order butterfly, then one (sum, sumsq) pair
+        // per (frame, 128-voxel tile, wave row, 4-channel bundle) -- the layout ea_groupnorm_finalize_bf16 reads
+        const int64_t t_out = row0 / frame;
+        const int64_t blk = t_out * p.gn_nblk + ((row0 - t_out * frame) >> 7) * 2 + wm;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float s_ = gs[j][g][b], q_ = gq[j][g][b];
+#pragma unroll
+                    for (int o_ = 1; o_ < 32; o_ <<= 1) {
+                        s_ += __shfl_xor(s_, o_, 64);
+                        q_ += __shfl_xor(q_, o_, 64);
+                    }
+                    const int n0 = col0 + wn * 64 + j * 32 + g * 16 + hi * 8 + b * 4;
+                    if (l31 == 0 && n0 < p.C_out) {
+                        float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
+                        dst[0] = s_;
+                        dst[1] = q_;
+                    }
+                }
     }
 }
 
@@ -1387,6 +1430,17 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
         if (!attr8_done) {
             (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
             attr8_done = true;
+        }
+        // GroupNorm partial sums from the epilogue: one block per (128-voxel tile, wave row), tiles inside one frame
+        const int64_t frame8 = (int64_t)p.H_out * p.W_out;
+        if (gn_partial && frame8 % BM == 0 && C_out % 4 == 0) {
+            const int64_t nblk = frame8 / BM * 2;
+            const int64_t need = (int64_t)p.T_out * nblk * (C_out / 4) * 2;
+            if (need <= gn_capacity && nblk < (1 << 30) && ((uintptr_t)gn_partial & 7) == 0) {
+                p.gn_partial = gn_partial;
+                p.gn_nblk = (int)nblk;
+                if (gn_nblk_out) *gn_nblk_out = (int)nblk;
+            }
         }
         ea_count("conv_c8_128x128");
         hipLaunchKernelGGL(conv3d_cl_kernel<true>, dim3((unsigned)grid8), dim3(256), CONV_LDS, (hipStream_t)stream, p);

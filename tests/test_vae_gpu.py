@@ -370,6 +370,35 @@ def test_conv_8_channel_input(ci, co, T, H, W, st, ss, pad):
     assert bool((d <= 2 ** -6 * y2.float().abs().clamp_min(1.0)).all())
 
 
+def test_conv_8_channel_input_leaves_groupnorm_partials():
+    """The encoder's conv_in at a frame size that is a multiple of 128 voxels: the 8-channel kernel's epilogue leaves the
+    GroupNorm partial sums of its output; GroupNorm + SiLU from them equals GroupNorm + SiLU with its own statistics pass."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import CausalConv3d
+    g = torch.Generator().manual_seed(43)
+    conv = CausalConv3d(3, 128, kernel_size=3)
+    with torch.no_grad():
+        conv.weight.copy_(_bf(torch.randn(conv.weight.shape, generator=g) / 9.0).float())
+        conv.bias.copy_(torch.randn(128, generator=g))
+    conv = conv.to(DEV)
+    x8 = ops.ncdhw_to_ndhwc((torch.rand(3, 5, 256, 256, generator=g) * 2 - 1).to(DEV), 8)
+    gamma, beta = (1 + 0.3 * torch.randn(128, generator=g)).to(DEV), (0.3 * torch.randn(128, generator=g)).to(DEV)
+    _lib.reset_counters()
+    y = conv(x8)
+    assert _lib.counters() == {"conv_c8_128x128": 1} and hasattr(y, "gn_partial")
+    a = ops.groupnorm_silu(y, gamma, beta, 32, 1e-6)
+    ops.FUSED_GN_STATS = False
+    try:
+        c = ops.groupnorm_silu(y, gamma, beta, 32, 1e-6)
+    finally:
+        ops.FUSED_GN_STATS = True
+    d = (a.float() - c.float()).abs()
+    assert (d > 0).float().mean().item() < 1e-3 and d.max().item() <= 2.0 ** -6 * max(1.0, c.float().abs().max().item())
+    ref = F.silu(F.group_norm(y.double().permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), 1e-6)).permute(0, 2, 3, 1)
+    err, rel = _rep("GroupNorm(partials of the 8-channel conv)+SiLU vs fp64", a, ref)
+    assert rel < 5e-3
+
+
 @pytest.mark.parametrize("T,HW,C,G", [(3, 100, 64, 16), (2, 5000, 128, 32), (1, 4096, 512, 32), (4, 333, 256, 32)])
 def test_groupnorm_silu(T, HW, C, G):
     from easyanimate_amd import ops
