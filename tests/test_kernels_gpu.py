@@ -332,7 +332,8 @@ def test_qkv_fused_matches_unfused(B, H, M, K, seq_off, use_rope):
 W8_SHAPES = [
     # B, M, N, K, tile: both kernels, M / N tails, odd / even K-tile counts, strided batch
     (1, 128, 128, 64, 128), (2, 300, 320, 192, 128), (1, 512, 3072, 3072, 128),
-    (1, 256, 256, 64, 256), (2, 700, 768, 1024, 256), (1, 16500, 320, 320, 256), (1, 2048, 12288, 256, 256),
+    (1, 256, 256, 64, 256), (1, 256, 512, 128, 256), (1, 512, 256, 192, 256), (2, 700, 768, 1024, 256), (1, 16500, 320, 320, 256),
+    (1, 2048, 12288, 256, 256),
 ]
 
 
