@@ -282,3 +282,41 @@ def test_encode_prompt_matches_the_reference_glue(tmp_path):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert a[0].shape == (1, 77, 16)
+
+
+def test_conv_weight_packing_for_8_channel_inputs():
+    """vae_modules._pack_conv_weight_c8: [Cout, Cin <= 8, 3, 3, 3] -> [n_pad, 32 tap slots x 8 channels]; column 8 * tap + c
+    holds w[:, c, dt, dh, dw] with tap = (dt * 3 + dh) * 3 + dw, everything else is zero (what conv3d_cl_kernel<C8> reads)."""
+    from easyanimate_amd.vae_modules import _pack_conv_weight_c8
+    g = torch.Generator().manual_seed(2)
+    for co, ci, n_pad in ((5, 3, 8), (128, 3, 128), (16, 8, 16), (4, 1, 8)):
+        w = torch.randn(co, ci, 3, 3, 3, generator=g)
+        pk = _pack_conv_weight_c8(w, n_pad)
+        assert pk.shape == (n_pad, 256) and pk.dtype == torch.bfloat16
+        ref = torch.zeros(n_pad, 256)
+        for dt in range(3):
+            for dh in range(3):
+                for dw in range(3):
+                    tap = (dt * 3 + dh) * 3 + dw
+                    ref[:co, 8 * tap:8 * tap + ci] = w[:, :, dt, dh, dw].bfloat16().float()
+        assert torch.equal(pk.float(), ref)
+
+
+def test_gemm_weight_keeps_fp8_parameters():
+    """_params.gemm_weight: a contiguous float8_e4m3fn Linear weight with K % 64 == 0 goes to the kernels as it is (fp8 weight
+    storage, utils/fp8_optimization.py:17-22); with FP8_NATIVE_GEMM off, or for shapes the fp8 kernels do not take, the cached
+    bf16 up-cast; bf16 weights are passed through untouched."""
+    from easyanimate_amd import _params
+    w = torch.randn(16, 128).to(torch.float8_e4m3fn)
+    p = torch.nn.Parameter(w, requires_grad=False)
+    assert _params.gemm_weight(p).dtype == torch.float8_e4m3fn and _params.gemm_weight(p).data_ptr() == p.data_ptr()
+    _params.FP8_NATIVE_GEMM = False
+    try:
+        up = _params.gemm_weight(p)
+        assert up.dtype == torch.bfloat16 and torch.equal(up, w.to(torch.bfloat16)) and _params.gemm_weight(p) is up   # cached
+    finally:
+        _params.FP8_NATIVE_GEMM = True
+    odd = torch.nn.Parameter(torch.randn(16, 96).to(torch.float8_e4m3fn), requires_grad=False)       # K % 64 != 0
+    assert _params.gemm_weight(odd).dtype == torch.bfloat16
+    b = torch.nn.Parameter(torch.randn(16, 128).bfloat16(), requires_grad=False)
+    assert _params.gemm_weight(b).data_ptr() == b.data_ptr()
