@@ -1103,11 +1103,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
 // Measured (13 x 1024^2, in-session A/B, profiles/r02l_conv_m512_ab.txt): 128 -> 128 with residual + GroupNorm partials
 // 11.81 -> 9.61 ms (1021 -> 1255 TFLOP/s), 256 -> 128 19.8 -> 17.5 ms (1217 -> 1376); of which 512-voxel tiles +4 %, one
 // phase per tile +9 %, buffer addressing +1.5 %, the residual prefetch in the epilogue +5 % on residual layers.
-template <int BN, int TM>   // 128 x 512 or 256 x 256: (channels, voxels) per workgroup
+//
+// S2: the spatially strided down-sampler (3x3x3, spatial stride 2, pad 0 with one zero row / column on the high side;
+// downsamplers.py:24-94): output voxel w reads input voxels 2w + dw.  The slab is staged de-interleaved -- LDS rows 0 .. TM
+// hold the even input voxels 2 (w0 + r), rows TM + 1 .. 2 TM the odd ones -- so the three dw taps are again three shifted
+// reads of one staged row: dw = 0 the even rows, dw = 1 the odd rows, dw = 2 the even rows + 1.  (The tile-per-tap kernel
+// ran this layer at 690 TFLOP/s.)
+template <int BN, int TM, bool S2>   // 128 x 512 or 256 x 256: (channels, voxels) per workgroup
 __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p) {
     static_assert(BN * TM == 65536, "wave tile 128 voxels x 64 channels");
     constexpr int RB = 64, KC = 32;                                 // LDS row bytes, channels per stage
-    constexpr int NROW = TM + 2, NPIECE = (NROW + 15) / 16, PPW = (NPIECE + 7) / 8, ISTEP = 16 * RB;   // 1 KiB DMA pieces = 16 rows
+    constexpr int NROW = S2 ? 2 * TM + 1 : TM + 2, NPIECE = (NROW + 15) / 16, PPW = (NPIECE + 7) / 8, ISTEP = 16 * RB;   // 1 KiB DMA pieces = 16 rows
     constexpr int WN = BN / 64, WM = 8 / WN, MT = TM / WM / 16;     // wave tile 128 voxels x 64 channels, MT = 8
     constexpr int WP = BN / 128;                                    // W pieces (16 weight rows each) per wave
     constexpr int A_STAGE = (NPIECE + 1) * 1024, W_BYTES = BN * RB, W_BASE = 2 * A_STAGE;
@@ -1143,7 +1149,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
     for (int i = 0; i < PPW; ++i) {
         const int q = wave * PPW + i;
         const int r = q * 16 + (lane >> 2), c = lane & 3;
-        const int w = w0 - 1 + r;
+        const int w = S2 ? (r <= TM ? 2 * (w0 + r) : 2 * (w0 + r - TM - 1) + 1) : w0 - 1 + r;
         a_voff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ ((r >> 1) & 3)) * 8) * 2 : 0x40000000;
     }
     const int wk = 27 * p.C_in;
@@ -1170,7 +1176,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
     unsigned a_k[3];
 #pragma unroll
     for (int dw = 0; dw < 3; ++dw) {
-        const int row = wr * (MT * 16) + lr + dw;
+        const int row = wr * (MT * 16) + lr + (S2 ? (dw == 1 ? TM + 1 : dw >> 1) : dw);
         a_k[dw] = row * RB + ((lq ^ ((row >> 1) & 3)) << 4);
     }
     const unsigned w_k = W_BASE + (wc * 64 + lr) * RB + ((lq ^ ((lr >> 1) & 3)) << 4);
@@ -1182,10 +1188,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
     bool slab_ok = false;
     auto set_slab = [&](int dtdh) {
         const int dt = dtdh / 3, dh = dtdh - dt * 3;
-        int ti = t_out + dt - 2;
+        int ti = (S2 ? t_out * p.st : t_out) + dt - 2;
         ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
-        const int hu = h_out + dh - 1;
-        slab_ok = hu >= 0 && hu < p.H_out;
+        const int hu = S2 ? 2 * h_out + dh : h_out + dh - 1;   // S2: pad 0, one zero row below the last one
+        slab_ok = hu >= 0 && hu < p.H_in;
         slab_row = p.x + ((int64_t)ti * p.H_in + (slab_ok ? hu : 0)) * p.W_in * p.C_in;
     };
     int a_dst = 0;
@@ -1452,6 +1458,33 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     bool pp = bn != 0 && tiles256 * (C_out / (bn ? bn : 1)) >= 256;
     if (g_conv_tile == 128) pp = false;
     if (g_conv_tile >= 256 && bn != 0) pp = true;
+    // strided down-sampler with C_out == 128 and output rows a multiple of 512 voxels (encoder level 1 at 1024^2): the
+    // de-interleaved row-slab kernel
+    if (g_conv_mfma == 16 && (g_conv_m512 & 1) && (g_conv_tile == 0 || g_conv_tile == 1024) && kt == 3 && ss == 2 && pad == 0 &&
+        !ups && !tdup && C_out == 128 && p.W_out % 512 == 0 && C_in % 32 == 0) {
+        p.tiles_m = (int)(p.M / 512);
+        p.tiles_n = 1;
+        const int64_t grid6 = (int64_t)8 * ((p.tiles_m + 7) / 8);
+        EA_REQUIRE(grid6 < (1ll << 31), "ea_conv3d_cl_bf16: grid too large");
+        if (gn_partial) {
+            const int64_t nblk = (int64_t)p.H_out * (p.W_out / 512) * 4;
+            const int64_t need = (int64_t)p.T_out * nblk * (C_out / 4) * 2;
+            if (need <= gn_capacity && nblk < (1 << 30) && ((uintptr_t)gn_partial & 7) == 0) {
+                p.gn_partial = gn_partial;
+                p.gn_nblk = (int)nblk;
+                if (gn_nblk_out) *gn_nblk_out = (int)nblk;
+            }
+        }
+        const int lds6 = 2 * 66 * 1024 + 3 * 128 * 64;      // two A stages of 65 pieces + 1 KiB, three W stages
+        static bool attr6_done = false;
+        if (!attr6_done) {
+            (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<128, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6);
+            attr6_done = true;
+        }
+        ea_count("conv_row16_m512_s2");
+        hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<128, 512, true>), dim3((unsigned)grid6), dim3(512), lds6, (hipStream_t)stream, p);
+        return ea_check_launch("ea_conv3d_cl_bf16");
+    }
     // row-slab kernel: 3x3x3, stride 1, pad 1 (with or without the folded x2 up-sampling), output rows a multiple of 256
     // voxels wide
     const bool row_ok = bn != 0 && kt == 3 && st == 1 && ss == 1 && pad == 1 && p.W_out % 256 == 0 && C_in % 64 == 0;
@@ -1495,16 +1528,16 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
             const int lds5 = k32_128 ? 2 * 34 * 1024 + 3 * 128 * 64 : 2 * 18 * 1024 + 3 * 256 * 64;
             static bool attr5_done = false;
             if (!attr5_done) {
-                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 3 * 128 * 64);
-                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 18 * 1024 + 3 * 256 * 64);
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<128, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 3 * 128 * 64);
+                (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<256, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 18 * 1024 + 3 * 256 * 64);
                 attr5_done = true;
             }
             if (k32_128) {
                 ea_count("conv_row16_m512");
-                hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<128, 512>), dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
+                hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<128, 512, false>), dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
             } else {
                 ea_count("conv_row16_256_k32");
-                hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<256, 256>), dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
+                hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<256, 256, false>), dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
             }
             return ea_check_launch("ea_conv3d_cl_bf16");
         }

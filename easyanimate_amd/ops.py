@@ -459,7 +459,7 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     if res is not None:
         assert res.is_contiguous() and res.shape == (To, Ho, Wo, Cout) and res.dtype == _BF16
     dup = int(tdup and To > 1)
-    if want_stats and k == 3 and st == 1 and ss == 1 and pad == 1 and Wo % 256 == 0 and Cout % 128 == 0:
+    if want_stats and k == 3 and ((st, ss, pad) == (1, 1, 1) or (ss == 2 and pad == 0 and not ups)) and Wo % 256 == 0 and Cout % 128 == 0:
         cap = Ty * Ho * (Wo // 256) * 4 * (Cout // 4) * 2       # the largest layout the kernel may choose
         partial = torch.empty(cap, dtype=_F32, device=x.device)
         nblk = ctypes.c_int(0)

@@ -50,7 +50,7 @@ int ea_version(void);
  *                   1024 = the row-slab kernel wherever it applies (3x3x3, stride 1, rows a multiple of 256 voxels wide);
  *   "conv_mfma":    MFMA shape of the row-slab convolution kernel: 16 = 16x16x32 (default), 32 = 32x32x16;
  *   "conv_m512":    row-slab layers without folded up-sampling, bit 0 (1): C_out == 128 with rows a multiple of 512 voxels use the
- *                   512-voxel x 128-channel kernel, bit 1 (2): the 256-channel tiles use the 256 x 256 kernel -- both one phase
+ *                   512-voxel x 128-channel kernel (stride 1, and the spatially strided down-sampler in its de-interleaved form), bit 1 (2): the 256-channel tiles use the 256 x 256 kernel -- both one phase
  *                   per tile over 32-channel stages; 1 = default (bit 1 measured 1.5-3 % slower), 0 = the four-phase kernels over 64-channel stages;
  *   "attn_variant": 3 = the pipelined kernel on 16x16x32 MFMAs (default; serves calls with the scale folded into Q,
  *                   others fall through to 2), 2 = the pipelined kernel on 32x32x16, 1 = the first, un-pipelined kernel. */

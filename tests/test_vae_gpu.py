@@ -370,6 +370,61 @@ def test_conv_8_channel_input(ci, co, T, H, W, st, ss, pad):
     assert bool((d <= 2 ** -6 * y2.float().abs().clamp_min(1.0)).all())
 
 
+S2_CASES = [
+    # the strided down-sampler on the de-interleaved row-slab kernel: spatial stride 2 (temporal 1 / 2), pad 0 with the zero row
+    # / column on the high side (H_in even: the last output row reads it), one and two 512-voxel tiles per output row
+    (3, 6, 1024, 64, 1), (4, 5, 1024, 128, 2), (2, 4, 2048, 64, 1), (5, 2, 1024, 192, 2),
+]
+
+
+@pytest.mark.parametrize("T,H,W,Ci,st", S2_CASES)
+def test_conv3d_cl_strided_row_slab(T, H, W, Ci, st):
+    from easyanimate_amd import _lib
+    _lib.reset_counters()
+    test_conv3d_cl(T, H, W, Ci, 128, 3, st, 2, 0, False, False, False)
+    assert _lib.counters() == {"conv_row16_m512_s2": 1}
+    # the switch that turns the one-phase kernels off sends the layer back to the tile-per-tap kernel
+    k0 = _lib.get_option("conv_m512")
+    _lib.set_option("conv_m512", 0)
+    try:
+        _lib.reset_counters()
+        test_conv3d_cl(T, H, W, Ci, 128, 3, st, 2, 0, False, False, False)
+        assert "conv_row16_m512_s2" not in _lib.counters()
+    finally:
+        _lib.set_option("conv_m512", k0)
+
+
+def test_conv3d_cl_strided_row_slab_deterministic_and_stats():
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight
+    g = torch.Generator().manual_seed(12)
+    x = _bf(torch.randn(3, 16, 1024, 128, generator=g)).to(DEV)
+    w = _pack_conv_weight(_bf(torch.randn(128, 128, 3, 3, 3, generator=g) / (128 * 27) ** 0.5)).to(DEV)
+    b = torch.randn(128, generator=g).to(DEV)
+    gamma, beta = (1 + 0.3 * torch.randn(128, generator=g)).to(DEV), (0.3 * torch.randn(128, generator=g)).to(DEV)
+    _lib.reset_counters()
+    y = ops.conv3d_cl(x, w, b, 3, 1, 2, 0)
+    assert _lib.counters() == {"conv_row16_m512_s2": 1} and y.shape == (3, 8, 512, 128) and hasattr(y, "gn_partial")
+    for _ in range(4):
+        assert torch.equal(ops.conv3d_cl(x, w, b, 3, 1, 2, 0), y)
+    a = ops.groupnorm_silu(y, gamma, beta, 32, 1e-6)
+    ops.FUSED_GN_STATS = False
+    try:
+        c = ops.groupnorm_silu(y, gamma, beta, 32, 1e-6)
+    finally:
+        ops.FUSED_GN_STATS = True
+    d = (a.float() - c.float()).abs()
+    assert (d > 0).float().mean().item() < 1e-3 and d.max().item() <= 2.0 ** -6 * max(1.0, c.float().abs().max().item())
+    k0 = _lib.get_option("conv_m512")
+    _lib.set_option("conv_m512", 0)
+    try:
+        y0 = ops.conv3d_cl(x, w, b, 3, 1, 2, 0)
+    finally:
+        _lib.set_option("conv_m512", k0)
+    d = (y0.float() - y.float()).abs()
+    assert bool((d <= 2 ** -7 * y0.float().abs().clamp_min(1.0)).all()) and (d > 0).float().mean().item() < 0.01
+
+
 def test_conv_8_channel_input_leaves_groupnorm_partials():
     """The encoder's conv_in at a frame size that is a multiple of 128 voxels: the 8-channel kernel's epilogue leaves the
     GroupNorm partial sums of its output; GroupNorm + SiLU from them equals GroupNorm + SiLU with its own statistics pass."""
