@@ -172,6 +172,28 @@ def vae_section(cpu: bool):
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run the same command line as N ranks of one node under
+    torch.distributed.run (--master-addr 127.0.0.1, a free port).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    shared = os.environ.get("EA_BENCH_SHARED_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not shared:
+        print(f"bench.py --gpus {n}: this node exposes {have} GPU(s); one rank per GPU is required "
+              f"(EA_BENCH_SHARED_DEVICE=1 runs the ranks on one device over gloo, for testing the code path only)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,9 +210,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL rendezvous on the
+        # loopback address) by re-executing this file under torch.distributed.run; rank 0's JSON line is the output.
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     # EA_BENCH_SHARED_DEVICE=1 (testing only, 1-GPU box): every rank uses cuda:0 and the rendezvous is gloo -- RCCL
     # refuses two ranks on one device; the timing of such a run means nothing, it exercises the multi-rank code path.
@@ -258,6 +282,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
     finite = bool(torch.isfinite(latents.float()).all().item())
+    gathered_devices = [None] * world
+    if world > 1:   # which device each rank really ran on (a shared-device test run shows up here)
+        dist.all_gather_object(gathered_devices, f"cuda:{local_rank}" + ("(shared)" if shared else ""))
 
     # ---- roofline of the dominant kernel (attention forward): algorithmic FLOPs per block / HIP-event duration.
     # Multi-GPU: a rank runs its batch slice (CFG axis) and its query shard (sequence axis) as two or three key-range
@@ -307,6 +334,9 @@ def main():
                      "traffic": traffic, "flop_per_launch": att_flop, "avg_launch_ms": att_ms,
                      "launches_timed": len(durs), "launches_per_block": len(durs) / max(n_blocks, 1)},
     }
+    if world > 1:
+        out["rccl"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                       "devices": sorted(set(gathered_devices)), "launched_by": os.environ.get("TORCHELASTIC_RUN_ID", "external")}
     if emu:
         P, r = emu
         out["metric"] = f"MODELLED per-rank compute-side rate, rank {r} of {P} (not a measurement of {P} GPUs)"

@@ -26,6 +26,22 @@ def invalidate_weight_cache() -> None:
     _inv()
 
 
+def observes_weight_writes(fn):
+    """Wrap a function that edits parameters through `.data` (the reference's utils/lora_utils.py merge_lora /
+    unmerge_lora): the derived-weight cache is dropped after it returns.  The pipelines also do this at the start of every
+    __call__, so `pipeline = merge_lora(pipeline, ...); pipeline(...)` needs nothing; use this when driving
+    transformer.forward / vae.decode directly."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        try:
+            return fn(*a, **kw)
+        finally:
+            invalidate_weight_cache()
+    return wrapped
+
+
 def __getattr__(name):
     if name in _LAZY:
         import importlib

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import ops
+from ._params import invalidate_weight_cache
 from .embeddings import get_3d_rotary_pos_embed, get_resize_crop_region_for_grid
 from .scheduler import FlowMatchEulerDiscreteScheduler
 
@@ -112,6 +113,55 @@ class EasyAnimatePipeline:
         if self.vae is not None:
             self.vae.to(device)
         return self
+
+    @property
+    def compute_dtype(self):
+        """dtype of latents / prompt embeddings / conditioning.  The reference takes it from the text encoder (bf16,
+        pipeline_easyanimate.py:938-944); with the transformer stored as float8_e4m3fn (predict_t2v.py's default
+        GPU_memory_mode) `transformer.dtype` is a STORAGE type nothing can be sampled or embedded in."""
+        for m in (self.text_encoder, self.text_encoder_2):
+            dt = getattr(m, "dtype", None)
+            if isinstance(dt, torch.dtype) and dt.is_floating_point and dt.itemsize >= 2:
+                return dt
+        dt = self.transformer.dtype
+        if dt.is_floating_point and dt.itemsize >= 2:
+            return dt
+        vdt = getattr(self.vae, "dtype", None)
+        return vdt if isinstance(vdt, torch.dtype) and vdt.itemsize >= 2 else torch.bfloat16
+
+    # -- diffusers DiffusionPipeline offload entry points (every GPU_memory_mode branch of predict_t2v.py:256-273 calls one) --
+    def _resident(self, gpu_id=None, device=None):
+        if isinstance(device, str) or device is None:
+            device = torch.device(device or "cuda")
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", gpu_id if gpu_id is not None else torch.cuda.current_device())
+        for name in ("transformer", "vae", "text_encoder", "text_encoder_2", "clip_image_encoder"):
+            m = getattr(self, name, None)
+            if m is not None and hasattr(m, "to"):
+                m.to(device)
+        return self
+
+    def enable_model_cpu_offload(self, gpu_id=None, device=None):
+        """diffusers moves one whole model at a time between host and GPU to fit 24-80 GB cards.  An MI355X holds all of
+        them at once (23.6 GB of DiT weights, 0.5 GB VAE, the text encoder, against 288 GB), so NOTHING IS OFFLOADED: every
+        model is made resident on the device and stays there -- no per-call PCIe traffic, no hooks."""
+        return self._resident(gpu_id, device)
+
+    def enable_sequential_cpu_offload(self, gpu_id=None, device=None):
+        """See enable_model_cpu_offload: nothing is offloaded on a 288 GB device (diffusers would page every sub-module
+        in and out per call)."""
+        return self._resident(gpu_id, device)
+
+    def maybe_free_model_hooks(self):
+        """diffusers re-arms its offload hooks here at the end of __call__; there are none."""
+        return None
+
+    def enable_vae_slicing(self):
+        return None
+
+    def enable_vae_tiling(self):
+        raise NotImplementedError("tiled VAE (autoencoder_magvit.py:339-448) blends overlapping tiles and is not exact; the "
+                                  "whole-clip kernels fit 49 x 1024^2 in 83 GB")
 
     # -- helpers --------------------------------------------------------------------------------
     def latent_shape(self, batch_size, num_channels_latents, video_length, height, width):
@@ -307,8 +357,12 @@ class EasyAnimatePipeline:
         self._guidance_scale = guidance_scale
         self._guidance_rescale = guidance_rescale
         self._interrupt = False
+        # derived weight copies (fp32 biases, packed conv / patch-embedding weights) are rebuilt once per call, so writes the
+        # version counter cannot see -- merge_lora / unmerge_lora do `weight.data += ...` between calls
+        # (predict_t2v.py:282,319; utils/lora_utils.py:369-433) -- are always observed; costs a few ms per 50-step call
+        invalidate_weight_cache()
         device = self.transformer.device
-        dtype = self.transformer.dtype
+        dtype = self.compute_dtype
         pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype, prompt, negative_prompt, 0)
         timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, mu=1)
         self._num_timesteps = len(timesteps)
@@ -380,18 +434,34 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
         return mask_lat, masked_lat
 
     @staticmethod
-    def masked_video_and_mask(video: torch.Tensor, mask_video: torch.Tensor):
+    def preprocess_video(video: torch.Tensor, height=None, width=None, normalize: bool = True) -> torch.Tensor:
+        """diffusers VaeImageProcessor.preprocess on a [B,C,F,H,W] tensor (called per frame at :1231-1233, :1340): nearest
+        resize to (height, width) when the size differs, then [0,1] -> [-1,1] -- skipped, like diffusers does, when the
+        input already has negative values."""
+        video = video.to(torch.float32)
+        if height is not None and tuple(video.shape[-2:]) != (height, width):
+            import torch.nn.functional as F
+            b, c, f = video.shape[:3]
+            frames = video.permute(0, 2, 1, 3, 4).reshape(b * f, c, *video.shape[-2:])
+            frames = F.interpolate(frames, size=(height, width))
+            video = frames.reshape(b, f, c, height, width).permute(0, 2, 1, 3, 4)
+        if normalize and video.numel() and float(video.min()) >= 0:
+            video = video * 2.0 - 1.0
+        return video
+
+    @classmethod
+    def masked_video_and_mask(cls, video: torch.Tensor, mask_video: torch.Tensor, height=None, width=None):
         """Host-side preprocessing exactly as the reference does it on CPU tensors (:1337-1346):
         video in [0,1] -> init_video in [-1,1] (VaeImageProcessor normalize); mask in [0,255] binarised at 0.5;
-        masked_video = init_video * (mask < 0.5) - (mask > 0.5)."""
-        init_video = video.to(torch.float32) * 2.0 - 1.0
-        mask_condition = (mask_video.to(torch.float32) >= 0.5).to(torch.float32)
+        masked_video = init_video * (mask < 0.5) - (mask > 0.5).  Both are first brought to (height, width)."""
+        init_video = cls.preprocess_video(video, height, width)
+        mask_condition = (cls.preprocess_video(mask_video, height, width, normalize=False) >= 0.5).to(torch.float32)
         tile = torch.tile(mask_condition, [1, 3, 1, 1, 1])
         masked_video = init_video * (tile < 0.5) + torch.ones_like(init_video) * (tile > 0.5) * -1
         return masked_video, mask_condition
 
     def inpaint_conditioning(self, video, mask_video, dtype, device, do_cfg=True, latent_shape=None, generator=None,
-                             noise_aug_strength=0.0563, masked_video_latents=None):
+                             noise_aug_strength=0.0563, masked_video_latents=None, height=None, width=None):
         """reference: pipeline_easyanimate_inpaint.py:1321-1383."""
         direct = self.transformer.resize_inpaint_mask_directly
         if mask_video is None or (self.transformer.config.get("enable_zero_in_inpaint", True) and bool((mask_video == 255).all())):
@@ -400,7 +470,7 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
             mask_latents = torch.zeros((shp[0], 1 if direct else shp[1]) + shp[2:], dtype=dtype, device=device)
             masked_latents = torch.zeros(shp, dtype=dtype, device=device)
         else:
-            masked_video, mask_condition = self.masked_video_and_mask(video.cpu(), mask_video.cpu())
+            masked_video, mask_condition = self.masked_video_and_mask(video.cpu(), mask_video.cpu(), height, width)
             if masked_video_latents is not None:
                 masked_video = masked_video_latents
             if direct:
@@ -440,8 +510,12 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
         self._guidance_scale = guidance_scale
         self._guidance_rescale = guidance_rescale
         self._interrupt = False
+        # derived weight copies (fp32 biases, packed conv / patch-embedding weights) are rebuilt once per call, so writes the
+        # version counter cannot see -- merge_lora / unmerge_lora do `weight.data += ...` between calls
+        # (predict_t2v.py:282,319; utils/lora_utils.py:369-433) -- are always observed; costs a few ms per 50-step call
+        invalidate_weight_cache()
         device = self.transformer.device
-        dtype = self.transformer.dtype
+        dtype = self.compute_dtype
         pe = self._embeds(prompt_embeds, negative_prompt_embeds, device, dtype, prompt, negative_prompt, 0)
         pe2 = None
         if prompt_embeds_2 is not None or (prompt is not None and self.tokenizer_2 is not None):
@@ -457,7 +531,7 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
             # V2V re-noising (:862-893): start from the encoded input video at the first kept timestep
             if video is None:
                 raise ValueError("strength < 1 needs `video`")
-            video_latents = self._encode(video.to(torch.float32) * 2.0 - 1.0, dtype, device)
+            video_latents = self._encode(self.preprocess_video(video.cpu(), height, width), dtype, device)
             latents = self.scheduler.scale_noise(video_latents, timesteps[:1], noise_or_latents)
         else:
             latents = noise_or_latents
@@ -466,7 +540,8 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
         if self.transformer.config.in_channels != nc:
             inpaint = self.inpaint_conditioning(video, mask_video, dtype, device, self.do_classifier_free_guidance,
                                                 latent_shape=latents.shape, generator=generator,
-                                                noise_aug_strength=noise_aug_strength, masked_video_latents=masked_video_latents)
+                                                noise_aug_strength=noise_aug_strength, masked_video_latents=masked_video_latents,
+                                                height=height, width=width)
             if inpaint.shape[1] + nc != self.transformer.config.in_channels:
                 raise ValueError(f"the transformer expects {self.transformer.config.in_channels} input channels, latents + "
                                  f"inpaint conditioning give {nc + inpaint.shape[1]} (resize_inpaint_mask_directly mismatch?)")

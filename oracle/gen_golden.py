@@ -607,6 +607,95 @@ def gen_fp8(ns, shim):
                     out_bf16=out8.float(), out_unquantised=out0), os.path.join(OUT, "transformer_fp8_storage.pt"))
 
 
+@section("config1_v0")
+def gen_config1_v0(ns, shim):
+    # ---- VERDICT r2 next #6a: the quantity that explains config 1's latent MSE -- the velocity of the FIRST forward (CFG
+    # pair, un-combined) of the declared 7B-class model at 1 x 256^2: reference fp32, and the reference's own bf16 forward
+    # from the same inputs (its per-forward noise).  Kept in its own small file (config1_7b_256.pt is unchanged).
+    import time
+    m, _ = _meta_build(lambda: ns.transformer3d.EasyAnimateTransformer3DModel(**DIT_7B), 0, "default_bf16")
+    latents, enc = config1_inputs()
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((16, 16), 45, 30)
+    rope = shim.get_3d_rotary_pos_embed(64, cc, (16, 16), 1, use_real=True)
+    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(2, device="cpu", mu=1)
+    t = s.timesteps[0]
+    li = torch.cat([latents] * 2)
+    t0 = time.time()
+    v = m(li, torch.tensor([t] * 2).to(li.dtype), encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+    print(f"  fp32 forward {time.time() - t0:.1f} s; velocity std {v.std().item():.3f}", flush=True)
+    mb = m.to(torch.bfloat16)
+    t0 = time.time()
+    vb = mb(li.bfloat16(), torch.tensor([t] * 2).to(torch.bfloat16), encoder_hidden_states=enc.bfloat16(), image_rotary_emb=rope,
+            return_dict=False)[0].float()
+    cfg_f, cfg_b = v[0] + 6.0 * (v[1] - v[0]), vb[0] + 6.0 * (vb[1] - vb[0])
+    print(f"  bf16 forward {time.time() - t0:.1f} s; reference bf16-vs-fp32: per-forward velocity MSE {_mse(vb, v):.3e}, after the CFG-6 "
+          f"combine {_mse(cfg_b, cfg_f):.3e}", flush=True)
+    torch.save(dict(timestep=float(t), v=v, v_bf16=vb, floor_mse=_mse(vb, v), floor_cfg_mse=_mse(cfg_b, cfg_f)),
+               os.path.join(OUT, "config1_7b_256_v0.pt"))
+
+
+FULL_LOOP_DIMS = (3, 40, 56, 256)      # latent frames, latent H, W, text tokens -> 3 * 20 * 28 = 1680 video tokens
+
+
+@section("loop_full_width")
+def gen_loop_full_width(ns, shim):
+    # ---- VERDICT r2 next #6b: a multi-step loop at FULL WIDTH (d = 3072, 48 heads, ff 12288; 2 layers), 1680 video + 256 text
+    # tokens, 10 Flow steps, CFG 6: the reference's loop in fp32 and in its own bf16 bookkeeping.
+    import time
+    for name, style in (("loop_full_width", "stress_bf16"), ("loop_full_width_default", "default_bf16")):
+        cfg = dict(FULL_DIT)
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+        shapes = _load_sd(m, 11, style)
+        Fr, H, W, T = FULL_LOOP_DIMS
+        g = _g(47)
+        latents = torch.randn(1, 16, Fr, H, W, generator=g).bfloat16().float()
+        enc = torch.randn(2, T, cfg["text_embed_dim"], generator=g).bfloat16().float()
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+        rope = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+        keep = (1, 5, 10)
+        t0 = time.time()
+        xf, kf = _ref_loop(ns, shim, m, latents, enc, rope, 10, 6.0, torch.float32, keep)
+        t1 = time.time()
+        xb, kb = _ref_loop(ns, shim, m, latents, enc, rope, 10, 6.0, torch.bfloat16, keep)
+        print(f"  {name}: fp32 loop {t1 - t0:.0f} s, bf16 loop {time.time() - t1:.0f} s; final latent std {xf.std().item():.3f}; reference "
+              f"bf16-vs-fp32 MSE by step", {k: _mse(kb[k], kf[k]) for k in keep}, flush=True)
+        torch.save(dict(cfg=cfg, shapes=shapes, seed=11, style=style, input_seed=47, dims=FULL_LOOP_DIMS, crops=cc, guidance=6.0, steps=10,
+                        latents=latents, enc_sum=enc.double().sum().item(), trace=kf, trace_bf16=kb), os.path.join(OUT, f"{name}.pt"))
+
+
+def loop_full_width_inputs(cfg, seed=47):
+    Fr, H, W, T = FULL_LOOP_DIMS
+    g = _g(seed)
+    latents = torch.randn(1, 16, Fr, H, W, generator=g).bfloat16().float()
+    enc = torch.randn(2, T, cfg["text_embed_dim"], generator=g).bfloat16().float()
+    return latents, enc
+
+
+@section("swa_long")
+def gen_swa_long(ns, shim):
+    # ---- VERDICT r2 next #6c: sliding-window blocks on a grid where the window TRUNCATES in all six scan orders:
+    # 9 x 16 x 16 patches = 2304 video tokens, window = 16 * 16 = 256 positions either side (F*H*W = 9 * H*W >> 2 * H*W), the
+    # strided cross keys use interval 2.  Same reference processor, flash_attn_func restated (oracle/flash_attn_shim.py).
+    from oracle import flash_attn_shim
+    ns.processor.flash_attn_func = flash_attn_shim.flash_attn_func
+    cfg = dict(TINY, num_attention_heads=6, num_layers=2, swa_layers=[0, 1])
+    m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+    shapes = _load_sd(m, 3, "stress")
+    B, Fr, H, W, T = 2, 9, 32, 32, 24
+    lat, enc = swa_inputs(cfg, 33, B, Fr, H, W, T)
+    t = torch.tensor([303.0, 303.0]).to(torch.bfloat16).float()
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+    cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+    out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), return_dict=False)[0]
+    mb = copy.deepcopy(m).to(torch.bfloat16)
+    outb = mb(lat.bfloat16(), t.bfloat16(), encoder_hidden_states=enc.bfloat16(), image_rotary_emb=(cos, sin), return_dict=False)[0]
+    print(f"  transformer_swa_long: out std {out.std().item():.3f}, floor {_mse(outb.float(), out):.3e}")
+    torch.save(dict(cfg=cfg, shapes=shapes, seed=3, style="stress", input_seed=33, dims=(B, Fr, H, W, T), t=t, crops=cc,
+                    lat_sum=lat.double().sum().item(), out=out.to(torch.float16), out_std=out.std().item(),
+                    floor_mse=_mse(outb.float(), out)), os.path.join(OUT, "transformer_swa_long.pt"))
+
+
 @torch.no_grad()
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)

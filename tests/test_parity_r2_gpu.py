@@ -133,7 +133,7 @@ def test_fp8_weight_storage_vs_reference_wrappers():
     assert mse < BAR and mse < 0.1 * _mse(g["out"], g["out_unquantised"])
 
 
-@pytest.mark.parametrize("name", ["transformer_swa", "transformer_swa_mixed"])
+@pytest.mark.parametrize("name", ["transformer_swa", "transformer_swa_mixed", "transformer_swa_long"])
 def test_transformer_swa_vs_golden(name):
     """sliding-window attention blocks (swa_layers; processor.py:320-459) -- strided cross keys (interval 2
     here), six scan orders over the head groups, band attention of +-(h*w) positions -- against the reference's own
@@ -253,3 +253,44 @@ def test_vae_decoder_512_rows_vs_golden():
     print(f"[parity] full-width decoder 5x512^2: MSE={mse:.3e} (ref std {g['dec_std']:.3f}); kernels {c}")
     assert mse < BAR
     assert c.get("conv_row16_m512", 0) >= 6 and c.get("conv_row16_256_ups", 0) >= 1 and c.get("conv_row16_256", 0) >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (e) round 3: a multi-step loop at FULL WIDTH (VERDICT r2 next #6b)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["loop_full_width", "loop_full_width_default"])
+def test_denoise_loop_full_width_meets_the_bar(name):
+    """d = 3072 (48 heads x 64, ff 12288, text 3584), 2 layers, 1680 video + 256 text tokens, 10 Flow steps, CFG 6, through
+    EasyAnimatePipeline.denoise with the production kernels (attention v3, 256^2 GEMMs, fused QKV asserted), against the
+    unchanged reference's fp32 loop (tests/golden/loop_full_width*.pt).  Bar 1e-4 on the latents, NO floor term."""
+    from easyanimate_amd import EasyAnimatePipeline, FlowMatchEulerDiscreteScheduler, _lib
+    from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
+    from oracle.gen_golden import loop_full_width_inputs
+    g = _load(name + ".pt")
+    Fr, H, W, T = g["dims"]
+    latents, enc = loop_full_width_inputs(g["cfg"], g["input_seed"])
+    assert torch.equal(latents, g["latents"]) and abs(enc.double().sum().item() - g["enc_sum"]) < 1e-4
+    rope = get_3d_rotary_pos_embed(64, g["crops"], grid_size=(H // 2, W // 2), temporal_size=Fr, use_real=True)
+    m = _model(g["cfg"], g["shapes"], g["seed"], g["style"])
+    sched = FlowMatchEulerDiscreteScheduler(shift=1.0)
+    sched.set_timesteps(g["steps"], device=DEV, mu=1)
+    pipe = EasyAnimatePipeline(vae=None, transformer=m, scheduler=sched)
+    ref, refb = g["trace"], g["trace_bf16"]
+    kept = {}
+
+    def keep(p, i, t, kw):
+        if (i + 1) in ref:
+            kept[i + 1] = kw["latents"].float().cpu().clone()
+        return {}
+    _lib.reset_counters()
+    with torch.no_grad():
+        pipe.denoise(latents.to(DEV).bfloat16(), enc.to(DEV).bfloat16(), rope, sched.timesteps, g["guidance"], callback_on_step_end=keep)
+    cnt = _lib.counters()
+    res = {k: _mse(v, ref[k]) for k, v in kept.items()}
+    floor = {k: _mse(refb[k], ref[k]) for k in ref}
+    print(f"[parity] {name} (full width d=3072, 2 layers, {Fr * (H // 2) * (W // 2)} video + {T} text tokens, {g['steps']} steps, CFG "
+          f"{g['guidance']:g}): latent MSE by step new vs ref-fp32 " + ", ".join(f"{k}: {v:.3e}" for k, v in res.items())
+          + " | ref-bf16 vs ref-fp32 (floor) " + ", ".join(f"{k}: {v:.3e}" for k, v in floor.items())
+          + f" | final latent std {ref[g['steps']].std().item():.3f} | kernels {cnt}")
+    assert cnt.get("attention_v3", 0) >= 2 * g["steps"] and cnt.get("gemm_256_mi16", 0) > 0 and cnt.get("gemm_qkv_fused", 0) > 0
+    assert all(v < BAR for v in res.values()), res

@@ -213,3 +213,32 @@ def test_emulated_rank_runs_the_rank_local_work():
             L = g["cfg"]["num_layers"]   # per block: one local-key pass (+ one pass over the gathered segments)
             assert cnt.get("attention_v3", 0) == L and cnt.get("attention_v3_segments", 0) == (0 if sp.size == 1 else L), (P, r, cnt)
     m.sequence_parallel = None
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) starts its own two ranks under
+    torch.distributed.run on 127.0.0.1 and rank 0 prints the one JSON line.  On this 1-GPU box the ranks share cuda:0 over
+    gloo (EA_BENCH_SHARED_DEVICE=1: the timing means nothing, the code path is the multi-rank one: CFG split, token shards,
+    final gather, max-over-ranks timing)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["EA_BENCH_SHARED_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-vae"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    print("[bench --gpus 2, self-launched]", {k: out[k] for k in ("value", "n_gpus", "ms_per_step", "rccl")})
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1 and out["value"] > 0
+    assert out["rccl"]["ranks_seen"] == 2 and out["rccl"]["backend"] == "gloo"
+    assert out["config"]["finite_output"] and out["config"]["parallelism"].startswith("cfg2 x sp1")
+    # without the shared-device switch a 1-GPU box refuses (one rank per GPU), with a clear message and a non-zero code
+    env.pop("EA_BENCH_SHARED_DEVICE")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "tiny"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r2.returncode != 0 and "one rank per GPU" in r2.stderr
