@@ -204,6 +204,10 @@ def main():
     ap.add_argument("--emulate-rank", default=None, metavar="P,r",
                     help="one GPU runs the per-step COMPUTE of rank r in a world of P ranks (no communication): a labelled "
                          "MODEL of the scaling curve, never a measurement of it")
+    ap.add_argument("--emulate-exchange", action="store_true",
+                    help="with --emulate-rank: also move the bytes the per-block K / V^T all-gather would bring in (P'-1 slots) "
+                         "device-to-device on a side stream under the own-slot attention pass (HBM / copy-engine contention "
+                         "enters the model; xGMI link time does not)")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE half of the metric (config 4), timed after the DiT steps at N=1")
     args = ap.parse_args()
 
@@ -244,6 +248,7 @@ def main():
             raise SystemExit("--emulate-rank is a single-process mode")
         emu = tuple(int(v) for v in args.emulate_rank.split(","))
         model.sequence_parallel = sequence_parallel.EmulatedRank(*emu)
+        model.sequence_parallel.emulate_exchange = bool(args.emulate_exchange)
         args.no_vae = args.no_cpu_baseline = True
     sched = FlowMatchEulerDiscreteScheduler(shift=1.0)
     pipe = EasyAnimatePipeline(vae=None, transformer=model, scheduler=sched)
@@ -297,7 +302,8 @@ def main():
         lo, hi = sp.shard_range()
         q_rows = 256 + (hi - lo)
         par = (f"cfg{sp.axis.cfg_degree} x sp{sp.size}: CFG pair split over rank halves, video-token sequence parallel "
-               f"inside a half, asynchronous K/V all-gather under the local-key attention pass")
+               f"inside a half; K | V projected first, in-place asynchronous K/V^T all-gather under the Q projection and the "
+               f"own-slot attention pass")
     else:
         b_loc, q_rows, par = B, S, "single GPU"
     att_ms = sum(durs) / max(n_blocks, 1)
@@ -342,7 +348,10 @@ def main():
         out["metric"] = f"MODELLED per-rank compute-side rate, rank {r} of {P} (not a measurement of {P} GPUs)"
         out["emulated"] = {"world": P, "rank": r, "what": "this rank's batch slice (CFG axis), token shard through every per-token "
                            "kernel, and its queries over all keys in the two-pass local / remote form with random remote K / V^T; "
-                           "collectives, their overlap with the local-key pass and the pack / unpack copies are NOT included",
+                           "collectives and their overlap with the own-slot pass are NOT included"
+                                   + (" -- except that the bytes of the K / V^T all-gather are moved device-to-device on a side stream "
+                                      "under the own-slot pass (--emulate-exchange)" if args.emulate_exchange else ""),
+                           "exchange_emulated": bool(args.emulate_exchange),
                            "speedup_upper_bound_needs": "T_1 / this ms_per_step, T_1 from the plain N=1 run of the same session"}
         out["config"]["step_mfma_frac"] = flop_step * K / elapsed / (PEAK_BF16_TFLOPS * 1e12 * P)
     if rank == 0 and world == 1 and not args.no_vae and args.config == "c3":

@@ -64,7 +64,7 @@ extern "C" const char* ea_last_dispatch(void) { return g_last; }
 extern "C" void ea_reset_counters(void) {
     for (int i = 0; i < g_ncounters; ++i) g_counters[i].n = 0;
 }
-extern "C" int ea_version(void) { return 100; }
+extern "C" int ea_version(void) { return 110; }   // 110: K / V^T geometry + parts in the QKV entry points, first / used rows in the segment attention
 
 // Tuning / benchmarking switches.  Each kernel file owns its switch; results never depend on them.
 #define EA_OPTION(n) int ea_##n##_set(int v); int ea_##n##_get();

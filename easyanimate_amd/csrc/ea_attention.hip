@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(
     unsigned short* __restrict__ k_out, unsigned short* __restrict__ vt_out, const float* __restrict__ nq_w,
     const float* __restrict__ nq_b, const float* __restrict__ nk_w, const float* __restrict__ nk_b,
     const float* __restrict__ cosT, const float* __restrict__ sinT, int heads, int n_tok, int seq_off, int s_pad,
-    float eps, float q_scale) {
+    int kv_off, int kv_rows, float eps, float q_scale) {
     __shared__ unsigned short vtile[64][72];  // [token][channel], padded
     const int tid = threadIdx.x;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e] * osc);
             }
             if (valid) {
-                unsigned short* dst = (which ? k_out : q_out) + (bh * s_pad + seq_off + tok) * 64 + sub * 8;
+                unsigned short* dst = which ? k_out + (bh * kv_rows + kv_off + tok) * 64 + sub * 8
+                                            : q_out + (bh * s_pad + seq_off + tok) * 64 + sub * 8;
                 *reinterpret_cast<u16x8*>(dst) = o;
             }
         }
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(
     {
         const int d = tid >> 2;
         const int t0 = (tid & 3) * 16;
-        unsigned short* dst = vt_out + (bh * 64 + d) * (int64_t)s_pad + seq_off + tok0 + t0;
-        const bool aligned = (((seq_off + tok0) & 7) == 0);
+        unsigned short* dst = vt_out + (bh * 64 + d) * (int64_t)kv_rows + kv_off + tok0 + t0;
+        const bool aligned = (((kv_off + tok0) & 7) == 0);
         if (aligned && tok0 + t0 + 16 <= n_tok) {
             u16x8 o0, o1;
 #pragma unroll
@@ -389,8 +390,11 @@ int ea_attn_variant_set(int v) {
 extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q_out, ea_bf16* k_out,
                                    ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
                                    const float* nk_b, const float* cos, const float* sin, int batch, int heads,
-                                   int n_tok, int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
+                                   int n_tok, int seq_off, int s_pad, int kv_off, int kv_rows, float ln_eps, float q_scale,
+                                   void* stream) {
     EA_REQUIRE(qkv && q_out && k_out && vt_out && nq_w && nq_b && nk_w && nk_b, "ea_qknorm_rope_bf16: null tensor");
+    if (kv_rows <= 0) { kv_rows = s_pad; kv_off = seq_off; }   // K / V^T share the geometry of Q
+    EA_REQUIRE(kv_off >= 0 && kv_rows % 8 == 0 && kv_off + n_tok <= kv_rows, "ea_qknorm_rope_bf16: K / V^T rows [kv_off, kv_off + n_tok) must fit kv_rows");
     EA_REQUIRE((cos == nullptr) == (sin == nullptr), "ea_qknorm_rope_bf16: cos/sin must come together");
     EA_REQUIRE(batch > 0 && heads > 0 && n_tok >= 0 && seq_off >= 0, "ea_qknorm_rope_bf16: bad sizes");
     EA_REQUIRE(s_pad % 64 == 0 && seq_off + n_tok <= s_pad, "ea_qknorm_rope_bf16: s_pad must be a multiple of 64 and cover the rows");
@@ -398,7 +402,7 @@ extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride,
     if (n_tok == 0) return EA_OK;
     dim3 grid((n_tok + 63) / 64, heads, batch);
     hipLaunchKernelGGL(qknorm_rope_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_batch_stride, q_out,
-                       k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, heads, n_tok, seq_off, s_pad, ln_eps, q_scale);
+                       k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, heads, n_tok, seq_off, s_pad, kv_off, kv_rows, ln_eps, q_scale);
     return ea_check_launch("ea_qknorm_rope_bf16");
 }
 
@@ -464,14 +468,19 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
 extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
                                               int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin,
                                               int q_end, int seg_rows, int n_seg, int skip_seg, int64_t seg_stride,
-                                              int kv_valid, float scale, float* state, int flags, void* stream) {
+                                              int seg_first_row, int seg_used_rows, int kv_valid, float scale, float* state,
+                                              int flags, void* stream) {
     EA_REQUIRE(q && k_seg0 && vt_seg0 && (out || (flags & 2)), "ea_attention_fwd_segments_bf16: null tensor");
     EA_REQUIRE(batch > 0 && heads > 0 && q_pad % ATT_QB == 0 && q_begin >= 0 && q_begin <= q_end && q_end <= q_pad,
                "ea_attention_fwd_segments_bf16: bad query range");
     EA_REQUIRE(seg_rows > 0 && seg_rows % ATT_KV == 0 && n_seg >= 1 && seg_stride >= 0,
                "ea_attention_fwd_segments_bf16: segment rows must be a positive multiple of 64");
+    EA_REQUIRE(seg_first_row >= 0 && seg_first_row % ATT_KV == 0 && seg_used_rows > 0 && seg_used_rows % ATT_KV == 0 &&
+               seg_first_row + seg_used_rows <= seg_rows,
+               "ea_attention_fwd_segments_bf16: the used row range of a segment must be 64-aligned and inside the segment");
     const int used = n_seg - ((skip_seg >= 0 && skip_seg < n_seg) ? 1 : 0);
-    EA_REQUIRE(used >= 1 && kv_valid > 0 && (int64_t)kv_valid <= (int64_t)used * seg_rows && kv_valid > (int64_t)(used - 1) * seg_rows,
+    EA_REQUIRE(used >= 1 && kv_valid > 0 && (int64_t)kv_valid <= (int64_t)used * seg_used_rows &&
+               kv_valid > (int64_t)(used - 1) * seg_used_rows,
                "ea_attention_fwd_segments_bf16: kv_valid must end inside the last used segment");
     EA_REQUIRE((flags & ~3) == 0 && (flags == 0 || state), "ea_attention_fwd_segments_bf16: bad flags / missing state buffer");
     EA_REQUIRE(fabsf(scale * 1.4426950408889634f - 1.0f) < 1e-6f,
@@ -484,8 +493,8 @@ extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
     EA_REQUIRE(blocks < (1ll << 31), "ea_attention_fwd_segments_bf16: grid too large");
     AttSegments sg;
-    sg.rows = seg_rows; sg.tiles = seg_rows / ATT_KV; sg.skip = (skip_seg >= 0 && skip_seg < n_seg) ? skip_seg : n_seg;
-    sg.total_tiles = used * sg.tiles; sg.stride = seg_stride;
+    sg.rows = seg_rows; sg.tiles = seg_used_rows / ATT_KV; sg.skip = (skip_seg >= 0 && skip_seg < n_seg) ? skip_seg : n_seg;
+    sg.total_tiles = used * sg.tiles; sg.stride = seg_stride; sg.first = seg_first_row / ATT_KV;
     const dim3 grid((unsigned)blocks), blk(256);
     hipStream_t st = (hipStream_t)stream;
     unsigned short* o16 = (unsigned short*)out;

@@ -798,6 +798,9 @@ struct QkvArgs {
     const float* cosT;
     const float* sinT;
     int M, K, inner, heads, seq_off, s_pad;
+    int kv_off, kv_rows;   // geometry of k_out / vt_out (rows per head, first row): equal to (seq_off, s_pad) unless the caller
+                           // lets K / V^T land in another buffer (sequence parallelism: the rank's slot of the exchange buffer)
+    int first_part;        // the launch's N axis starts at this third (0 = q | k | v, 1 = k | v): which = first_part + tn / tiles_per_w
     int64_t lda, abs_;
     float eps, q_scale;
     int tiles_m, tiles_n, rows_per_xcd;
@@ -821,8 +824,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     const int b = blockIdx.y;
     const int row0 = tm * 256;
     const int tiles_per_w = q.inner >> 8;
-    const int which = __builtin_amdgcn_readfirstlane(tn / tiles_per_w);   // 0 = q, 1 = k, 2 = v
-    const int col0 = (tn - which * tiles_per_w) * 256;                     // first output feature inside that weight
+    const int part = __builtin_amdgcn_readfirstlane(tn / tiles_per_w);
+    const int which = q.first_part + part;                                 // 0 = q, 1 = k, 2 = v
+    const int col0 = (tn - part * tiles_per_w) * 256;                      // first output feature inside that weight
     const unsigned short* Ab = q.A + b * q.abs_;
     const unsigned short* Wb = which == 0 ? q.W[0] : (which == 1 ? q.W[1] : q.W[2]);
     const float* biasb = which == 0 ? q.bias[0] : (which == 1 ? q.bias[1] : q.bias[2]);
@@ -886,12 +890,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
         }
         // wave-private image: the LDS writes above are ordered before the reads below by the waitcnt the compiler inserts
         const int r4 = lane >> 4, c16 = lane & 15;
-        unsigned short* dst = q.vt_out + (bh * 64) * (int64_t)q.s_pad + q.seq_off + tok0 + c16 * 8;
+        unsigned short* dst = q.vt_out + (bh * 64) * (int64_t)q.kv_rows + q.kv_off + tok0 + c16 * 8;
 #pragma unroll
         for (int qq = 0; qq < 16; ++qq) {
             const int n = qq * 4 + r4;
             const u16x8 o = *reinterpret_cast<const u16x8*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
-            *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.s_pad) = o;
+            *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.kv_rows) = o;
         }
         return;
     }
@@ -968,7 +972,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
         }
     }
     const int r8 = lane >> 3, c8 = lane & 7;
-    unsigned short* dst = (which ? q.k_out : q.q_out) + (bh * q.s_pad + q.seq_off + tok0) * 64 + c8 * 8;
+    unsigned short* dst = (which ? q.k_out + (bh * q.kv_rows + q.kv_off + tok0) * 64
+                                 : q.q_out + (bh * q.s_pad + q.seq_off + tok0) * 64) + c8 * 8;
 #pragma unroll
     for (int qq = 0; qq < 16; ++qq) {
         const int r = qq * 8 + r8;
@@ -1083,9 +1088,15 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
                                           ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
                                           const float* nk_w, const float* nk_b, const float* cos, const float* sin,
                                           int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
-                                          int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
+                                          int seq_off, int s_pad, int kv_off, int kv_rows, int parts, float ln_eps, float q_scale,
+                                          void* stream) {
     EA_REQUIRE(A && Wq && Wk && Wv && q_out && k_out && vt_out && nq_w && nq_b && nk_w && nk_b,
                "ea_qkv_gemm_norm_rope_bf16: null tensor");
+    if (kv_rows <= 0) { kv_rows = s_pad; kv_off = seq_off; }
+    if (parts == 0) parts = 7;
+    EA_REQUIRE(parts == 7 || parts == 1 || parts == 6, "ea_qkv_gemm_norm_rope_bf16: parts must be 7 (q|k|v), 1 (q) or 6 (k|v)");
+    EA_REQUIRE(kv_off >= 0 && kv_off % 8 == 0 && kv_rows % 8 == 0 && kv_off + M <= kv_rows,
+               "ea_qkv_gemm_norm_rope_bf16: kv_off / kv_rows must be multiples of 8 with kv_off + M <= kv_rows");
     EA_REQUIRE((cos == nullptr) == (sin == nullptr), "ea_qkv_gemm_norm_rope_bf16: cos and sin go together");
     EA_REQUIRE(batch > 0 && batch <= 65535 && heads > 0 && M > 0 && K > 0, "ea_qkv_gemm_norm_rope_bf16: bad sizes");
     EA_REQUIRE(M % 256 == 0, "ea_qkv_gemm_norm_rope_bf16: M=%d must be a multiple of 256 (use ea_gemm_bf16 + ea_qknorm_rope_bf16)", M);
@@ -1105,9 +1116,10 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
     q.q_out = q_out; q.k_out = k_out; q.vt_out = vt_out;
     q.nw[0] = nq_w; q.nb[0] = nq_b; q.nw[1] = nk_w; q.nb[1] = nk_b; q.cosT = cos; q.sinT = sin;
     q.M = M; q.K = K; q.inner = heads * 64; q.heads = heads; q.seq_off = seq_off; q.s_pad = s_pad;
+    q.kv_off = kv_off; q.kv_rows = kv_rows; q.first_part = parts == 6 ? 1 : 0;
     q.lda = lda; q.abs_ = a_batch_stride; q.eps = ln_eps; q.q_scale = q_scale;
     q.tiles_m = M / 256;
-    q.tiles_n = 3 * q.inner / 256;
+    q.tiles_n = (parts == 7 ? 3 : (parts == 6 ? 2 : 1)) * q.inner / 256;
     q.rows_per_xcd = q.tiles_m >= 64 ? (q.tiles_m + 7) / 8 : 0;
     dim3 grid(q.rows_per_xcd ? 8 * q.rows_per_xcd * q.tiles_n : q.tiles_m * q.tiles_n, batch);
     static bool attr_done = false;
@@ -1116,6 +1128,7 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
         attr_done = true;
     }
     ea_count(W8 ? "gemm_qkv_fused_w8" : "gemm_qkv_fused");
+    if (parts != 7) ea_count(parts == 6 ? "gemm_qkv_fused_kv_part" : "gemm_qkv_fused_q_part");
     hipLaunchKernelGGL(gemm256_qkv_kernel<W8>, grid, dim3(512), GEMM2_LDS, (hipStream_t)stream, q);
     return ea_check_launch(W8 ? "ea_qkv_gemm_norm_rope_bf16_w8" : "ea_qkv_gemm_norm_rope_bf16");
 }
@@ -1126,9 +1139,10 @@ extern "C" int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, c
                                           ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
                                           const float* nk_w, const float* nk_b, const float* cos, const float* sin,
                                           int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
-                                          int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
+                                          int seq_off, int s_pad, int kv_off, int kv_rows, int parts, float ln_eps,
+                                          float q_scale, void* stream) {
     return qkv_entry<false>(A, Wq, Wk, Wv, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, batch, M, heads, K, lda,
-                            a_batch_stride, seq_off, s_pad, ln_eps, q_scale, stream);
+                            a_batch_stride, seq_off, s_pad, kv_off, kv_rows, parts, ln_eps, q_scale, stream);
 }
 
 extern "C" int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq_fp8, const uint8_t* Wk_fp8, const uint8_t* Wv_fp8,
@@ -1136,9 +1150,10 @@ extern "C" int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq
                                              ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
                                              const float* nk_w, const float* nk_b, const float* cos, const float* sin,
                                              int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
-                                             int seq_off, int s_pad, float ln_eps, float q_scale, void* stream) {
+                                             int seq_off, int s_pad, int kv_off, int kv_rows, int parts, float ln_eps,
+                                             float q_scale, void* stream) {
     return qkv_entry<true>(A, Wq_fp8, Wk_fp8, Wv_fp8, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, batch, M, heads, K,
-                           lda, a_batch_stride, seq_off, s_pad, ln_eps, q_scale, stream);
+                           lda, a_batch_stride, seq_off, s_pad, kv_off, kv_rows, parts, ln_eps, q_scale, stream);
 }
 
 #ifdef EA_GEMM_TIMESTAMPS

@@ -195,8 +195,9 @@ FOLDED_ATTN_SCALE = 0.6931471805599453
 
 def qknorm_rope(qkv: torch.Tensor, q_out: torch.Tensor, k_out: torch.Tensor, vt_out: torch.Tensor,
                 nq_w, nq_b, nk_w, nk_b, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
-                seq_off: int, eps: float, q_scale: float = 1.0) -> None:
-    """qkv bf16 [B,n_tok,3*H*64]; q_out/k_out bf16 [B,H,S_pad,64]; vt_out bf16 [B,H,64,S_pad].
+                seq_off: int, eps: float, q_scale: float = 1.0, kv_off: Optional[int] = None) -> None:
+    """qkv bf16 [B,n_tok,3*H*64]; q_out bf16 [B,H,S_pad,64] (rows from seq_off); k_out bf16 [B,H,R,64], vt_out bf16
+    [B,H,64,R] (rows / columns from kv_off; R and kv_off default to q_out's geometry).
     q_scale multiplies q ahead of its bf16 rounding (FOLDED_Q_SCALE folds the softmax scale of head_dim 64)."""
     _dev(qkv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin)
     _chk(qkv, _BF16, "qkv")
@@ -204,29 +205,40 @@ def qknorm_rope(qkv: torch.Tensor, q_out: torch.Tensor, k_out: torch.Tensor, vt_
     _, H, s_pad, dh = q_out.shape
     assert dh == 64 and three_inner == 3 * H * 64 and qkv.stride(2) == 1 and qkv.stride(1) == three_inner
     assert q_out.is_contiguous() and k_out.is_contiguous() and vt_out.is_contiguous()
-    assert vt_out.shape == (B, H, 64, s_pad)
+    kv_rows = k_out.shape[2]
+    kv_off = seq_off if kv_off is None else kv_off
+    assert k_out.shape == (B, H, kv_rows, 64) and vt_out.shape == (B, H, 64, kv_rows) and kv_off + n_tok <= kv_rows
     if cos is not None:
         _chk(cos, _F32, "cos"); _chk(sin, _F32, "sin")
         assert cos.shape == (n_tok, 64) and cos.is_contiguous() and sin.is_contiguous()
     _lib.call("ea_qknorm_rope_bf16", _p(qkv), qkv.stride(0), _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b),
-              _p(nk_w), _p(nk_b), _p(cos), _p(sin), B, H, n_tok, seq_off, s_pad, float(eps), float(q_scale), _stream())
+              _p(nk_w), _p(nk_b), _p(cos), _p(sin), B, H, n_tok, seq_off, s_pad, kv_off, kv_rows, float(eps), float(q_scale),
+              _stream())
 
 
-def qkv_fused_ok(n_tok: int, inner: int, k: int, seq_off: int) -> bool:
+def qkv_fused_ok(n_tok: int, inner: int, k: int, seq_off: int, kv_off: Optional[int] = None) -> bool:
     """Shapes ea_qkv_gemm_norm_rope_bf16 serves (the video stream of every benchmark configuration)."""
-    return n_tok > 0 and n_tok % 256 == 0 and inner % 256 == 0 and k % 64 == 0 and seq_off % 8 == 0
+    return n_tok > 0 and n_tok % 256 == 0 and inner % 256 == 0 and k % 64 == 0 and seq_off % 8 == 0 and (kv_off or 0) % 8 == 0
+
+
+QKV_ALL, QKV_Q, QKV_KV = 7, 1, 6   # `parts` of qkv_gemm_norm_rope: which thirds of the q | k | v axis one launch computes
 
 
 def qkv_gemm_norm_rope(x: torch.Tensor, wq, wk, wv, bq, bk, bv, q_out: torch.Tensor, k_out: torch.Tensor,
                        vt_out: torch.Tensor, nq_w, nq_b, nk_w, nk_b, cos: Optional[torch.Tensor],
-                       sin: Optional[torch.Tensor], seq_off: int, eps: float, q_scale: float = 1.0) -> None:
-    """x bf16 [B, n_tok, K] -> rows [seq_off, seq_off+n_tok) of q_out / k_out [B,H,S_pad,64] and columns of vt_out
-    [B,H,64,S_pad]: the three projections + qk-LayerNorm + RoPE + scatter in one launch."""
+                       sin: Optional[torch.Tensor], seq_off: int, eps: float, q_scale: float = 1.0,
+                       kv_off: Optional[int] = None, parts: int = QKV_ALL) -> None:
+    """x bf16 [B, n_tok, K] -> rows [seq_off, seq_off+n_tok) of q_out [B,H,S_pad,64], rows [kv_off, kv_off+n_tok) of k_out
+    [B,H,R,64] and columns of vt_out [B,H,64,R] (R, kv_off default to q_out's geometry): the three projections +
+    qk-LayerNorm + RoPE + scatter in one launch (parts = QKV_KV / QKV_Q: two launches, K | V first)."""
     _dev(x, wq, wk, wv, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin)
     _chk(x, _BF16, "x")
     B, n_tok, K = x.shape
     _, H, s_pad, dh = q_out.shape
     assert dh == 64 and x.stride(2) == 1 and q_out.is_contiguous() and k_out.is_contiguous() and vt_out.is_contiguous()
+    kv_rows = k_out.shape[2]
+    kv_off = seq_off if kv_off is None else kv_off
+    assert k_out.shape == (B, H, kv_rows, 64) and vt_out.shape == (B, H, 64, kv_rows) and kv_off + n_tok <= kv_rows
     w8 = wq.dtype == _FP8          # fp8 weight storage: all three or none
     for w in (wq, wk, wv):
         _chk(w, _FP8 if w8 else _BF16, "W")
@@ -236,8 +248,8 @@ def qkv_gemm_norm_rope(x: torch.Tensor, wq, wk, wv, bq, bk, bv, q_out: torch.Ten
         assert cos.shape == (n_tok, 64) and cos.is_contiguous() and sin.is_contiguous()
     _timed("gemm", lambda: _lib.call("ea_qkv_gemm_norm_rope_bf16_w8" if w8 else "ea_qkv_gemm_norm_rope_bf16", _p(x), _p(wq), _p(wk), _p(wv), _p(bq), _p(bk), _p(bv),
                                      _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b), _p(nk_w), _p(nk_b), _p(cos),
-                                     _p(sin), B, n_tok, H, K, x.stride(1), x.stride(0), seq_off, s_pad, float(eps),
-                                     float(q_scale), _stream()))
+                                     _p(sin), B, n_tok, H, K, x.stride(1), x.stride(0), seq_off, s_pad, kv_off, kv_rows,
+                                     int(parts), float(eps), float(q_scale), _stream()))
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scale: float,
@@ -258,14 +270,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scal
 
 def attention_segments(q: torch.Tensor, gathered: torch.Tensor, n_seg: int, skip_seg: int, seg_rows: int, kv_valid: int,
                        q_begin: int, q_end: int, state: Optional[torch.Tensor] = None, load_state: bool = False,
-                       store_state: bool = False, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """Attention of query rows [q_begin, q_end) over the key segments of an all-gathered buffer `gathered`
+                       store_state: bool = False, out: Optional[torch.Tensor] = None, first_row: int = 0,
+                       used_rows: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Attention of query rows [q_begin, q_end) over the key segments of an exchange buffer `gathered`
     [n_seg, 2, B, H, seg_rows*64] (per rank: K rows [B,H,seg_rows,64], then V^T [B,H,64,seg_rows]), skipping segment
-    skip_seg; softmax scale folded into Q."""
+    skip_seg; of every segment the rows [first_row, first_row + used_rows) are keys; softmax scale folded into Q."""
     _dev(q, gathered, out, state)
     B, H, q_pad, dh = q.shape
     assert dh == 64 and q.is_contiguous() and gathered.is_contiguous() and gathered.dtype == _BF16
     assert gathered.numel() == n_seg * 2 * B * H * seg_rows * 64
+    used_rows = seg_rows - first_row if used_rows is None else used_rows
     flags = (1 if load_state else 0) | (2 if store_state else 0)
     if flags:
         assert state is not None and state.dtype == _F32 and state.numel() * 4 >= _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)
@@ -275,7 +289,8 @@ def attention_segments(q: torch.Tensor, gathered: torch.Tensor, n_seg: int, skip
     base = gathered.data_ptr()
     _timed("attention", lambda: _lib.call("ea_attention_fwd_segments_bf16", _p(q), ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * half),
                                           _p(out), out.stride(0) if out is not None else 0, B, H, q_pad, q_begin, q_end, seg_rows,
-                                          n_seg, skip_seg, 2 * half, kv_valid, FOLDED_ATTN_SCALE, _p(state), flags, _stream()))
+                                          n_seg, skip_seg, 2 * half, first_row, used_rows, kv_valid, FOLDED_ATTN_SCALE, _p(state),
+                                          flags, _stream()))
     return out
 
 

@@ -26,13 +26,25 @@ def _workspace(B: int, H: int, s_pad: int, device) -> dict:
     key = (B, H, s_pad, str(device))
     ws = _ws.get(key)
     if ws is None:
-        for k in [k for k in _ws if k[0] != "state"]:  # one live shape at a time keeps the footprint bounded
+        for k in [k for k in _ws if k[0] not in ("state", "q")]:  # one live shape at a time keeps the footprint bounded
             del _ws[k]
         ws = dict(q=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
                   k=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
                   vt=torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=device))
         _ws[key] = ws
     return ws
+
+
+def _workspace_q(B: int, H: int, q_pad: int, device) -> torch.Tensor:
+    """q staging buffer of the sequence-parallel path (K / V^T live in the exchange buffer), zero-initialised once."""
+    key = ("q", B, H, q_pad, str(device))
+    q = _ws.get(key)
+    if q is None:
+        for k in [k for k in _ws if k[0] == "q"]:
+            del _ws[k]
+        q = torch.zeros(B, H, q_pad, 64, dtype=torch.bfloat16, device=device)
+        _ws[key] = q
+    return q
 
 
 def _attention_state(B: int, H: int, q_end: int, device) -> torch.Tensor:
@@ -68,32 +80,45 @@ def _bf16c(x):
 class EasyAnimateAttnProcessor2_0:
     fuse_qkv = os.environ.get("EA_FUSE_QKV", "1") != "0"   # False / EA_FUSE_QKV=0: always take the three-GEMM + ea_qknorm_rope_bf16 path (same roundings; tests)
 
+    exchange_in_attend = False   # the SWA processor exchanges differently (heads, not keys): it starts nothing here
+
     def __init__(self):
         pass
 
-    def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid):
+    kv_first = os.environ.get("EA_SP_KV_FIRST", "1") != "0"  # sequence parallel: project K | V first, start the exchange, project Q under it
+
+    def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid, pending=None):
         """softmax(QK^T)V over the rows staged in ws -> bf16 [B, S, d]."""
         # ---- joint attention (processor.py:287-291): queries = text rows + this rank's video rows
         o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
-        if lay is not None and lay.remote_end > lay.remote_begin:
-            # sequence-parallel: attend the local keys while the K / V^T all-gather is in flight, then resume the
-            # online-softmax state over the remote keys (ea_attention_fwd_range_bf16)
-            pending = sp.exchange_start(ws, v_off)
+        if lay is not None and sp.exchanges(lay):
+            # sequence-parallel: attend the OWN slot (text + own shard) while the in-place K / V^T all-gather is in flight,
+            # then resume the online-softmax state over the other ranks' slots where the all-gather left them
+            buf = ws["kv"]
             state = _attention_state(B, H, S, dev)
-            for i, (lo, hi) in enumerate(lay.local_ranges):
-                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
-                                    store_state=True)
-            gathered = sp.exchange_finish(pending, ws, v_off)
-            if gathered is None:
+            own = buf[sp.rank]          # [2, B, H, rows * 64]: one segment
+            for i, (lo, hi) in enumerate(lay.own_ranges):
+                ops.attention_segments(ws["q"], own, 1, -1, lay.rows, hi - lo, 0, S, state=state, load_state=i > 0, store_state=True,
+                                       first_row=lo, used_rows=ops.round_up(hi - lo, 64))
+            sp.exchange_finish(pending)
+            if lay.bringup_ranges is not None:
                 # bring-up mode (a world of one rank with force_exchange): the "remote" keys are the second half of its own rows
-                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lay.remote_begin, lay.remote_end,
-                                    state=state, load_state=True, out=o)
+                (lo, hi), = lay.bringup_ranges
+                ops.attention_segments(ws["q"], own, 1, -1, lay.rows, hi - lo, 0, S, state=state, load_state=True, out=o,
+                                       first_row=lo, used_rows=ops.round_up(hi - lo, 64))
             else:
-                # the other ranks' shards are read where the all-gather left them (rank order, own segment skipped)
-                ops.attention_segments(ws["q"], gathered, sp.size, sp.rank, sp.n_loc, lay.remote_end - lay.remote_begin, 0, S,
-                                       state=state, load_state=True, out=o)
+                ops.attention_segments(ws["q"], buf, sp.size, sp.rank, lay.rows, lay.remote_valid, 0, S, state=state, load_state=True,
+                                       out=o, first_row=lay.t_pad, used_rows=lay.n_loc)
+        elif lay is not None:
+            # one sequence rank (CFG split only): the own slot is all there is
+            own = ws["kv"][sp.rank]
+            state = _attention_state(B, H, S, dev) if len(lay.own_ranges) > 1 else None
+            for i, (lo, hi) in enumerate(lay.own_ranges):
+                last = i == len(lay.own_ranges) - 1
+                ops.attention_segments(ws["q"], own, 1, -1, lay.rows, hi - lo, 0, S, state=state, load_state=i > 0,
+                                       store_state=not last, out=o if last else None, first_row=lo, used_rows=ops.round_up(hi - lo, 64))
         elif v_off != T:
-            # single sequence rank with unaligned text: rows [T, v_off) are padding between the two key ranges
+            # single GPU with unaligned text: rows [T, v_off) are padding between the two key ranges
             state = _attention_state(B, H, S, dev)
             ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, 0, T, state=state, store_state=True)
             ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, v_off, S, state=state, load_state=True, out=o)
@@ -133,12 +158,16 @@ class EasyAnimateAttnProcessor2_0:
         # ---- row layout of the attention operands: text rows first, then video (torch.cat at :277-279)
         lay = None
         if sp is not None:
-            lay = sp.layout(T, N)   # per-rank rows: [text | own shard | remote shards | pad]
-            S, s_pad, v_off = lay.q_end, lay.s_pad, lay.v_off
+            # per-rank rows: [text | gap | own shard]; K / V^T live in the rank's slot of the exchange buffer
+            lay = sp.layout(T, N)
+            S, v_off = lay.q_end, lay.t_pad
+            kvb = sp.kv_buffer(B, H, lay, dev)
+            k_own, vt_own = sp.slot_views(kvb)
+            ws = dict(q=_workspace_q(B, H, lay.q_pad, dev), k=k_own, vt=vt_own, kv=kvb)
         else:
             S = T + N
             s_pad, v_off = ops.round_up(S, 256), T
-        ws = _workspace(B, H, s_pad, dev)
+            ws = _workspace(B, H, s_pad, dev)
         cos = sin = None
         if image_rotary_emb is not None:
             cos, sin = rope_to_device(image_rotary_emb, dev)
@@ -146,27 +175,40 @@ class EasyAnimateAttnProcessor2_0:
             raise NotImplementedError("qk_norm=None is not supported by the HIP processor")
 
         # ---- QKV projections + qk LayerNorm + RoPE + head-major scatter (processor.py:244-285)
-        def qkv_stream(inp, mod, n_tok, seq_off, c, s_):
+        exchange = lay is not None and sp.exchanges(lay)
+        pending = None
+
+        def qkv_stream(inp, mod, n_tok, seq_off, c, s_, start_exchange=False):
+            """rows [seq_off, seq_off + n_tok) of q (workspace) and of K / V^T (workspace, or the rank's exchange slot: the
+            row numbering is the same).  start_exchange: the K / V^T all-gather starts as soon as K | V exist."""
+            nonlocal pending
             lq, lk, lv = mod.to_q, mod.to_k, mod.to_v
             nq, nk = mod.norm_q, mod.norm_k
             if self.fuse_qkv and ops.qkv_fused_ok(n_tok, d, inp.shape[2], seq_off):
-                # one launch: the [B, n, 3d] QKV buffer never exists (ea_qkv_gemm_norm_rope_bf16)
-                ops.qkv_gemm_norm_rope(inp, gemm_weight(lq.weight), gemm_weight(lk.weight), gemm_weight(lv.weight),
-                                       f32(lq.bias), f32(lk.bias), f32(lv.bias), ws["q"], ws["k"], ws["vt"],
-                                       f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias), c, s_, seq_off, nq.eps,
-                                       q_scale=ops.FOLDED_Q_SCALE)
-                return
-            # three GEMMs into one [B, n, 3d] buffer, then one normalise / rotate / scatter pass
-            qkv = torch.empty(B, n_tok, 3 * d, dtype=torch.bfloat16, device=dev)
-            for i, lin in enumerate((lq, lk, lv)):
-                ops.gemm(inp, gemm_weight(lin.weight), f32(lin.bias), ops.EPI_BIAS, out=qkv[:, :, i * d:(i + 1) * d])
-            ops.qknorm_rope(qkv, ws["q"], ws["k"], ws["vt"], f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias),
-                            c, s_, seq_off, nq.eps, q_scale=ops.FOLDED_Q_SCALE)
+                # one launch: the [B, n, 3d] QKV buffer never exists (ea_qkv_gemm_norm_rope_bf16) -- or two, K | V first
+                args = (inp, gemm_weight(lq.weight), gemm_weight(lk.weight), gemm_weight(lv.weight),
+                        f32(lq.bias), f32(lk.bias), f32(lv.bias), ws["q"], ws["k"], ws["vt"],
+                        f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias), c, s_, seq_off, nq.eps)
+                if start_exchange and self.kv_first:
+                    ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE, parts=ops.QKV_KV)
+                    pending = sp.exchange_start(ws["kv"])
+                    ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE, parts=ops.QKV_Q)
+                    return
+                ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE)
+            else:
+                # three GEMMs into one [B, n, 3d] buffer, then one normalise / rotate / scatter pass
+                qkv = torch.empty(B, n_tok, 3 * d, dtype=torch.bfloat16, device=dev)
+                for i, lin in enumerate((lq, lk, lv)):
+                    ops.gemm(inp, gemm_weight(lin.weight), f32(lin.bias), ops.EPI_BIAS, out=qkv[:, :, i * d:(i + 1) * d])
+                ops.qknorm_rope(qkv, ws["q"], ws["k"], ws["vt"], f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias),
+                                c, s_, seq_off, nq.eps, q_scale=ops.FOLDED_Q_SCALE)
+            if start_exchange:
+                pending = sp.exchange_start(ws["kv"])
 
         qkv_stream(e, tattn, T, 0, None, None)      # text rows: no RoPE
-        qkv_stream(x, attn, N, v_off, cos, sin)
+        qkv_stream(x, attn, N, v_off, cos, sin, start_exchange=exchange and self.exchange_in_attend is False)
 
-        o = self._attend(ws, B, H, T, N, S, v_off, d, dev, lay, sp, (num_frames, height, width))
+        o = self._attend(ws, B, H, T, N, S, v_off, d, dev, lay, sp, (num_frames, height, width), pending)
         o_t, o_v = o[:, :T], o[:, v_off:]
 
         # ---- output projections (:293-311), optionally with the gated residual fused (attention.py:1140-1141)
@@ -215,38 +257,88 @@ class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
             self._perm = {key: [(hs, base.permute(*o).reshape(-1).contiguous()) for hs, o in zip(groups, self._ORDERS) if hs.numel()]}
         return self._perm[key]
 
-    def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid):
-        if sp is not None:
-            raise NotImplementedError("sliding-window attention blocks under sequence parallelism")
+    exchange_in_attend = True   # under sequence parallelism this processor exchanges HEADS (all-to-all), not keys
+
+    def _swa(self, q, k, vt, B, Hl, head0, H_total, T, N, dev, grid):
+        """The two passes on explicit operands: q / k [B, Hl, S_pad, 64], vt [B, Hl, 64, S_pad] hold the heads
+        [head0, head0 + Hl) of H_total, rows = [text 0..T | all N video tokens in (f h w) order] -> bf16 [B, T + N, Hl * 64]."""
         F_, Hh, Ww = grid
         if F_ is None or F_ * Hh * Ww != N:
             raise ValueError("EasyAnimateSWAttnProcessor2_0 needs num_frames / height / width of the token grid")
-        q, k, vt = ws["q"], ws["k"], ws["vt"]
+        S = T + N
         # ---- cross pass
         interval = max(N // (self.cross_attention_size - T), 1)
         idx = torch.cat([torch.arange(T, device=dev), T + torch.arange(0, N, interval, device=dev)])
         kc, vtc = torch.zeros_like(k), torch.zeros_like(vt)
         kc[:, :, :idx.numel()] = k[:, :, idx]
         vtc[:, :, :, :idx.numel()] = vt[:, :, :, idx]
-        cross = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        cross = torch.empty(B, S, Hl * 64, dtype=torch.bfloat16, device=dev)
         ops.attention_range(q, kc, vtc, ops.FOLDED_ATTN_SCALE, 0, S, 0, idx.numel(), out=cross)
         # ---- window pass over the re-ordered video tokens
         n_pad = ops.round_up(N, 256)
-        qp = torch.zeros(B, H, n_pad, 64, dtype=torch.bfloat16, device=dev)
+        qp = torch.zeros(B, Hl, n_pad, 64, dtype=torch.bfloat16, device=dev)
         kp = torch.zeros_like(qp)
-        vtp = torch.zeros(B, H, 64, n_pad, dtype=torch.bfloat16, device=dev)
-        orders = self._scan_orders(F_, Hh, Ww, H, dev)
+        vtp = torch.zeros(B, Hl, 64, n_pad, dtype=torch.bfloat16, device=dev)
+        orders = []
+        for hs, src in self._scan_orders(F_, Hh, Ww, H_total, dev):   # head groups are defined over ALL heads (:400-417)
+            hs = hs[(hs >= head0) & (hs < head0 + Hl)] - head0
+            if hs.numel():
+                orders.append((hs, src))
         for hs, src in orders:
             rows = T + src
             qp[:, hs, :N] = q[:, hs][:, :, rows]
             kp[:, hs, :N] = k[:, hs][:, :, rows]
             vtp[:, hs, :, :N] = vt[:, hs][:, :, :, rows]
-        win = ops.attention_window(qp, kp, vtp, N, Hh * Ww, ops.FOLDED_ATTN_SCALE).view(B, N, H, 64)
+        win = ops.attention_window(qp, kp, vtp, N, Hh * Ww, ops.FOLDED_ATTN_SCALE).view(B, N, Hl, 64)
         back = torch.empty_like(win)
         for hs, src in orders:
             back[:, src[:, None], hs[None, :]] = win[:, :, hs]
         # ---- text rows: cross + cross; video rows: window + cross
-        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        o = torch.empty(B, S, Hl * 64, dtype=torch.bfloat16, device=dev)
         o[:, :T] = ops.bf16_add_(cross[:, :T].contiguous(), cross[:, :T].contiguous())
-        o[:, T:] = ops.bf16_add_(back.view(B, N, d), cross[:, T:].contiguous())
+        o[:, T:] = ops.bf16_add_(back.view(B, N, Hl * 64), cross[:, T:].contiguous())
+        return o
+
+    def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid, pending=None):
+        if sp is None:
+            return self._swa(ws["q"], ws["k"], ws["vt"], B, H, 0, H, T, N, dev, grid)
+        # ---- sequence parallelism: the six scan orders scatter a rank's contiguous (f h w) shard over the whole sequence, so
+        # the window pass is not a halo exchange.  The block switches to HEAD parallelism instead (all-to-all): every rank
+        # receives the q / k / v^T rows of ALL tokens for H / P' heads, runs the single-GPU passes on them, and a second
+        # all-to-all returns every rank's query rows for all heads; the replicated text rows are computed by the head's
+        # owner and all-gathered (bit-identical on every rank).
+        P = sp.size
+        if H % P:
+            raise NotImplementedError(f"sliding-window blocks under sequence parallelism need heads ({H}) % sequence ranks ({P}) == 0")
+        Hl, nl, tp, Nt = H // P, lay.n_loc, lay.t_pad, sp.n_total
+        head0 = sp.rank * Hl
+        q, k, vt = ws["q"], ws["k"], ws["vt"]
+        send = torch.zeros(P, 3, B, Hl, nl * 64, dtype=torch.bfloat16, device=dev)
+        sv = send.view(P, 3, B, Hl, nl, 64)
+        sv[:, 0] = q[:, :, tp:tp + nl].reshape(B, P, Hl, nl, 64).transpose(0, 1)
+        sv[:, 1] = k[:, :, tp:tp + nl].reshape(B, P, Hl, nl, 64).transpose(0, 1)
+        send[:, 2] = vt[:, :, :, tp:tp + nl].reshape(B, P, Hl, 64 * nl).transpose(0, 1)
+        recv = sp.all_to_all(send)                                   # [source rank, 3, B, Hl, nl * 64]
+        s_pad = ops.round_up(T + Nt, 256)
+        qf = torch.zeros(B, Hl, s_pad, 64, dtype=torch.bfloat16, device=dev)
+        kf = torch.zeros_like(qf)
+        vf = torch.zeros(B, Hl, 64, s_pad, dtype=torch.bfloat16, device=dev)
+        hsl = slice(head0, head0 + Hl)
+        qf[:, :, :T], kf[:, :, :T], vf[:, :, :, :T] = q[:, hsl, :T], k[:, hsl, :T], vt[:, hsl, :, :T]
+        for g in range(P):
+            lo, hi = sp.shard_range(g)
+            qf[:, :, T + lo:T + hi] = recv[g, 0].view(B, Hl, nl, 64)[:, :, :hi - lo]
+            kf[:, :, T + lo:T + hi] = recv[g, 1].view(B, Hl, nl, 64)[:, :, :hi - lo]
+            vf[:, :, :, T + lo:T + hi] = recv[g, 2].view(B, Hl, 64, nl)[:, :, :, :hi - lo]
+        ol = self._swa(qf, kf, vf, B, Hl, head0, H, T, Nt, dev, grid)   # [B, T + Nt, Hl * 64]
+        back = torch.zeros(P, B, nl, Hl * 64, dtype=torch.bfloat16, device=dev)
+        for g in range(P):
+            lo, hi = sp.shard_range(g)
+            back[g, :, :hi - lo] = ol[:, T + lo:T + hi]
+        mine = sp.all_to_all(back)                                    # [head owner, B, nl, Hl * 64]
+        text = sp.all_gather(ol[:, :T].contiguous())                  # [head owner, B, T, Hl * 64]
+        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        n_own = lay.n_own
+        o[:, :T] = text.permute(1, 2, 0, 3).reshape(B, T, d)
+        o[:, tp:tp + n_own] = mine.permute(1, 2, 0, 3).reshape(B, nl, d)[:, :n_own]
         return o

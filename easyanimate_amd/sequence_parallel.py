@@ -11,17 +11,16 @@ Two orthogonal axes, chosen per forward call:
 * **Sequence axis** (the remaining P' = P or P/2 ranks of a half): rank r owns a contiguous shard of the N video
   tokens (shard stride n_loc, a multiple of 64; only the last rank may be short).  All per-token work (norms,
   QKV / out / FFN GEMMs, RoPE, residuals) is local.  The one exchange per block is an all-gather of the K rows /
-  V^T columns of the shards.  It is *asynchronous*: while it is in flight the rank already attends its queries over
-  its LOCAL keys (text + own shard) with `ea_attention_fwd_range_bf16(..., flags=store state)`; when the remote
-  shards have landed a second launch resumes from that state over the REMOTE keys, which it reads straight out of the
-  all-gather's output buffer (segment addressing, ea_attention_fwd_segments_bf16: no unpack copies between the two
-  passes).  Softmax does not care about the key order, so each rank keeps a private row layout
-
-        [ text 0..T | (gap to a multiple of 64) | own shard | remote shards in rank order | pad ]
-
-  in which the query range and the remote key range are contiguous (the local keys are one range, or two when T is not
-  a multiple of 64); padding inside a short last shard is never part of a key range (a range may end anywhere, it only
-  has to start on a multiple of 64).
+  V^T columns of the shards, and it costs no copies: the exchange buffer is [P, 2, B, H, rows * 64] -- one SLOT per rank,
+  a slot holding K as [B, H, rows, 64] then V^T as [B, H, 64, rows], rows = [ text 0..T | gap to a multiple of 64 | shard ]
+  -- the projections write K / V^T of the rank's tokens straight into its own slot (kv_off / kv_rows of
+  ea_qkv_gemm_norm_rope_bf16), the all-gather runs IN PLACE on the buffer, and the attention kernel reads every slot where
+  it lies (segment addressing, ea_attention_fwd_segments_bf16).  It is *asynchronous* and starts EARLY: the K | V thirds
+  of the fused QKV launch run first, the all-gather starts, and the Q third, then the attention over the OWN slot (text
+  + own shard, state stored) run while it is in flight; when the remote slots have landed a second launch resumes from
+  that state over their shard rows (the replicated text rows of a remote slot are skipped).  Softmax does not care about
+  the key order; padding inside a short last shard is never part of a key range (a range may end anywhere, it only has
+  to start on a multiple of 64).
 
 One more all-gather (whole world) returns the velocity prediction of both batch elements / all shards to every rank,
 so that all ranks run the identical scheduler step.
@@ -48,16 +47,26 @@ def _round_up(x: int, m: int) -> int:
 
 @dataclass
 class Layout:
-    """Row layout of this rank's attention buffers for one block (see module docstring)."""
+    """Rows of this rank's attention operands for one block.
+
+    Every rank owns one SLOT of the exchange buffer [P, 2, B, H, rows * 64] (per slot: K as [B, H, rows, 64], then V^T as
+    [B, H, 64, rows]); a slot's rows are [ text 0..T | gap to t_pad | shard rows t_pad .. t_pad + n_loc ).  The projections
+    write K / V^T straight into the own slot, the all-gather runs IN PLACE on the buffer, and the attention reads every
+    slot where it lies (no pack, no unpack).  The q workspace [B, H, q_pad, 64] uses the same row numbering."""
     T: int             # text rows [0, T)
-    v_off: int         # first row of the own shard = round_up(T, 64): key ranges must start on a multiple of 64
+    t_pad: int         # first shard row = round_up(T, 64): key ranges must start on a multiple of 64
     n_own: int         # valid rows of the own shard
     n_loc: int         # shard stride
-    s_pad: int         # rows of the q / k / v^T workspaces
+    rows: int          # rows per (batch, head) of a slot = t_pad + n_loc
+    q_pad: int         # rows of the q workspace (multiple of 256)
     q_end: int         # queries are rows [0, q_end) (text, [alignment gap,] own shard)
-    local_ranges: List[Tuple[int, int]]  # local keys: [0, T + n_own) or, if T % 64 != 0, [0, T) and [v_off, v_off + n_own)
-    remote_begin: int  # remote keys [remote_begin, remote_end)   (empty when the sequence axis has one rank)
-    remote_end: int
+    own_ranges: List[Tuple[int, int]]   # key ranges inside the OWN slot: [0, T + n_own) or, if T % 64 != 0, [0, T) and [t_pad, t_pad + n_own)
+    remote_valid: int  # keys in the other ranks' shards (all full except possibly the last one in rank order)
+    bringup_ranges: Optional[List[Tuple[int, int]]] = None   # world-of-one bring-up: the own keys attended AFTER the exchange
+
+    @property
+    def v_off(self) -> int:   # first row of the video queries / keys
+        return self.t_pad
 
 
 class _Axis:
@@ -96,6 +105,7 @@ class SequenceParallel:
         self.axis = self._flat
         self.n_total = 0
         self.n_loc = 0
+        self._kv = None
 
     # ---- per-call mode ------------------------------------------------------------------------
     def begin(self, batch: int) -> Tuple[int, int]:
@@ -144,76 +154,90 @@ class SequenceParallel:
         lo, hi = self.shard_range()
         assert hi - lo == n_own, "hidden-state shard does not match the plan"
         nl, P = self.n_loc, self.size
-        v_off = _round_up(T, 64)
-        s_pad = _round_up(v_off + P * nl, 256)
+        t_pad = _round_up(T, 64)
+        rows = t_pad + nl
         last = self.shard_range(P - 1)
         n_last = last[1] - last[0]
         remote_valid = 0 if P == 1 else ((P - 1) * nl if self.rank == P - 1 else (P - 2) * nl + n_last)
-        local = [(0, T + n_own)] if v_off == T else [(0, T), (v_off, v_off + n_own)]
-        if P == 1 and self.force_exchange and v_off == T and T + n_own >= 128:
+        own = [(0, T + n_own)] if t_pad == T else [(0, T), (t_pad, t_pad + n_own)]
+        bring = None
+        if P == 1 and self.force_exchange and t_pad == T and T + n_own >= 128:
             # bring-up mode: the second half of the rank's own keys plays the part of the remote shards
             split = (T + n_own) // 2 // 64 * 64
-            return Layout(T=T, v_off=v_off, n_own=n_own, n_loc=nl, s_pad=s_pad, q_end=v_off + n_own, local_ranges=[(0, split)],
-                          remote_begin=split, remote_end=T + n_own)
-        return Layout(T=T, v_off=v_off, n_own=n_own, n_loc=nl, s_pad=s_pad, q_end=v_off + n_own, local_ranges=local,
-                      remote_begin=v_off + nl, remote_end=v_off + nl + remote_valid)
+            own, bring = [(0, split)], [(split, T + n_own)]
+        return Layout(T=T, t_pad=t_pad, n_own=n_own, n_loc=nl, rows=rows, q_pad=_round_up(rows, 256), q_end=t_pad + n_own,
+                      own_ranges=own, remote_valid=remote_valid, bringup_ranges=bring)
 
-    def slot(self, src_rank: int) -> int:
-        """Row-slot (in units of n_loc after the text rows) of rank src_rank's shard in THIS rank's buffers."""
-        if src_rank == self.rank:
-            return 0
-        return 1 + (src_rank if src_rank < self.rank else src_rank - 1)
+    def exchanges(self, lay: Layout) -> bool:
+        """Does a block of this layout exchange K / V^T (more than one sequence rank, or the bring-up mode)?"""
+        return self.size > 1 or lay.bringup_ranges is not None
+
+    def kv_buffer(self, B: int, H: int, lay: Layout, device, dtype=torch.bfloat16) -> torch.Tensor:
+        """The exchange buffer [P, 2, B, H, rows * 64], zero-initialised ONCE and kept (one live shape): rows nobody writes --
+        the gap behind unaligned text, the tail of a short last shard -- stay zero (the attention kernel masks them as keys
+        but needs a finite V^T there)."""
+        key = (self.size, B, H, lay.rows, str(device), dtype)
+        if self._kv is None or self._kv[0] != key:
+            self._kv = (key, torch.zeros((self.size, 2, B, H, lay.rows * 64), dtype=dtype, device=device))
+        return self._kv[1]
+
+    def slot_views(self, buf: torch.Tensor, rank: Optional[int] = None):
+        """(K [B, H, rows, 64], V^T [B, H, 64, rows]) views of one rank's slot (default: the own slot)."""
+        r = self.rank if rank is None else rank
+        _, _, B, H, n = buf.shape
+        rows = n // 64
+        return buf[r, 0].view(B, H, rows, 64), buf[r, 1].view(B, H, 64, rows)
 
     def _gloo_device_staging(self, t: torch.Tensor) -> bool:
         return t.is_cuda and dist.get_backend(self.axis.group) == "gloo"
 
-    def exchange_start(self, ws: dict, v_off: int):
-        """Start the all-gather of every rank's own K rows / V^T columns (rows [v_off, v_off+n_loc) of its buffers).
-        Returns a handle for exchange_finish.  With RCCL the collective runs on the process group's stream, behind
-        everything already queued on the current stream, and the caller keeps launching compute."""
+    def exchange_start(self, buf: torch.Tensor):
+        """Start the IN-PLACE all-gather of the slots: every rank contributes its own slot (written by its projections),
+        receives the others'.  With RCCL the collective runs on the process group's stream, behind everything already
+        queued on the current stream, and the caller keeps launching compute (the Q projection, the own-slot attention
+        pass).  Returns a handle for exchange_finish."""
         if self.size == 1 and not self.force_exchange:
             return None
-        k, vt = ws["k"], ws["vt"]
-        B, H = k.shape[0], k.shape[1]
-        nl = self.n_loc
-        send = torch.empty((2, B, H, nl * 64), dtype=k.dtype, device=k.device)
-        send[0] = k[:, :, v_off:v_off + nl].reshape(B, H, nl * 64)
-        send[1] = vt[:, :, :, v_off:v_off + nl].reshape(B, H, 64 * nl)
-        if self._gloo_device_staging(send):
-            # gloo (CPU / shared-GPU tests only) cannot gather device tensors into one buffer: stage through the host
-            r = torch.empty((self.size * send.numel(),), dtype=send.dtype, device="cpu")
-            dist.all_gather_into_tensor(r, send.view(-1).cpu(), group=self.axis.group)
-            return (None, r.to(send.device), send)
-        recv = torch.empty((self.size * send.numel(),), dtype=k.dtype, device=k.device)
-        work = dist.all_gather_into_tensor(recv, send.view(-1), group=self.axis.group, async_op=True)
-        return (work, recv, send)
+        own = buf[self.rank].view(-1)
+        if self.size > 1 and (not buf.is_cuda or self._gloo_device_staging(buf)):
+            # gloo (CPU tests / ranks sharing one GPU in tests): gather through a host buffer, then fill the remote slots
+            r = torch.empty((self.size,) + tuple(buf.shape[1:]), dtype=buf.dtype, device="cpu")
+            dist.all_gather_into_tensor(r.view(-1), own.cpu(), group=self.axis.group)
+            for g in range(self.size):
+                if g != self.rank:
+                    buf[g].copy_(r[g])
+            return (None,)
+        work = dist.all_gather_into_tensor(buf.view(-1), own, group=self.axis.group, async_op=True)
+        return (work,)
 
-    def exchange_finish(self, handle, ws: dict, v_off: int, unpack: Optional[bool] = None):
-        """Wait for the all-gather (a stream-level wait with RCCL).  Returns the gathered buffer viewed as
-        [P, 2, B, H, n_loc*64] (per rank: its K rows, then its V^T columns): on the GPU the attention kernel reads the
-        remote shards straight out of it (ea_attention_fwd_segments_bf16 -- no unpack copies on the critical path between the
-        local-key and the remote-key pass).  unpack=True (the default on CPU tensors: the gloo tests and the oracle
-        arithmetic they run) additionally scatters the remote shards into their slots of the rank-private layout."""
-        if handle is None:
-            return None
-        work, recv, send = handle
-        if work is not None:
-            work.wait()
-        if self.size == 1:      # bring-up mode: the collective ran, its result (== what was sent) is not needed
-            return None
-        k, vt = ws["k"], ws["vt"]
-        B, H = k.shape[0], k.shape[1]
-        nl = self.n_loc
-        recv = recv.view((self.size,) + tuple(send.shape))
-        if unpack is None:
-            unpack = not k.is_cuda
-        if unpack:
-            for r in range(self.size):
-                if r == self.rank:
-                    continue
-                o = v_off + self.slot(r) * nl
-                k[:, :, o:o + nl] = recv[r, 0].reshape(B, H, nl, 64)
-                vt[:, :, :, o:o + nl] = recv[r, 1].reshape(B, H, 64, nl)
+    def exchange_finish(self, handle) -> None:
+        """Wait for the all-gather (a stream-level wait with RCCL): the remote slots are then readable in place."""
+        if handle is not None and handle[0] is not None:
+            handle[0].wait()
+
+    # ---- head parallelism of the sliding-window blocks -------------------------------------------
+    def all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+        """send[g] goes to sequence rank g; returns recv with recv[g] = what rank g sent here (equal chunks)."""
+        if self.size == 1:
+            return send
+        if not send.is_cuda or self._gloo_device_staging(send):
+            h, r = send.cpu().contiguous(), torch.empty(send.shape, dtype=send.dtype, device="cpu")
+            dist.all_to_all_single(r.view(-1), h.view(-1), group=self.axis.group)
+            return r.to(send.device)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1), group=self.axis.group)
+        return recv
+
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        """[...] -> [P', ...] over the sequence ranks."""
+        if self.size == 1:
+            return x[None]
+        if not x.is_cuda or self._gloo_device_staging(x):
+            r = torch.empty((self.size,) + tuple(x.shape), dtype=x.dtype, device="cpu")
+            dist.all_gather_into_tensor(r.view(-1), x.cpu().contiguous().view(-1), group=self.axis.group)
+            return r.to(x.device)
+        recv = torch.empty((self.size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(recv.view(-1), x.contiguous().view(-1), group=self.axis.group)
         return recv
 
     def all_reduce_sums(self, sums: torch.Tensor, n: int):
@@ -266,19 +290,45 @@ class EmulatedRank(SequenceParallel):
         self.axis = self._flat
         self.n_total = 0
         self.n_loc = 0
-        self._filled = {}
+        self._kv = None
+        self._scratch = None
+        self.emulate_exchange = False
 
-    def exchange_start(self, ws: dict, v_off: int):
+    def kv_buffer(self, B: int, H: int, lay: Layout, device, dtype=torch.bfloat16) -> torch.Tensor:
+        key = (self.size, B, H, lay.rows, str(device), dtype)
+        if self._kv is None or self._kv[0] != key:
+            # the remote slots: N(0,1) keys / values, written once (zeros would run at a higher clock); own slot zero
+            buf = torch.randn((self.size, 2, B, H, lay.rows * 64), device=device).to(dtype)
+            buf[self.rank].zero_()
+            self._kv = (key, buf)
+            self._scratch = None
+        return self._kv[1]
+
+    def exchange_start(self, buf: torch.Tensor):
         if self.size == 1:
             return None
-        k = ws["k"]
-        key = (tuple(k.shape), self.size, self.n_loc, str(k.device))
-        if key not in self._filled:   # the gathered buffer: N(0,1) keys / values, written once (zeros would run at a higher clock)
-            self._filled = {key: torch.randn((self.size, 2, k.shape[0], k.shape[1], self.n_loc * 64), device=k.device).to(k.dtype)}
-        return self._filled[key]
+        if not self.emulate_exchange:
+            return (None,)
+        # --emulate-exchange: the bytes the all-gather would bring in (P' - 1 slots) are moved device-to-device on a side
+        # stream while the own-slot attention pass runs: HBM / copy-engine contention is in the model, link time is not
+        if self._scratch is None:
+            self._scratch = torch.randn((self.size - 1,) + tuple(buf.shape[1:]), device=buf.device).to(buf.dtype)
+            self._side = torch.cuda.Stream(device=buf.device)
+        cur = torch.cuda.current_stream(buf.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            j = 0
+            for g in range(self.size):
+                if g != self.rank:
+                    buf[g].copy_(self._scratch[j], non_blocking=True)
+                    j += 1
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return (ev,)
 
-    def exchange_finish(self, handle, ws: dict, v_off: int, unpack: Optional[bool] = None):
-        return handle
+    def exchange_finish(self, handle) -> None:
+        if handle is not None and handle[0] is not None:
+            torch.cuda.current_stream().wait_event(handle[0])
 
     def all_reduce_sums(self, sums: torch.Tensor, n: int):
         return sums.to(torch.float64) * self.world, n * self.world

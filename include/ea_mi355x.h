@@ -138,11 +138,15 @@ int ea_gemm_bf16_w8(const ea_bf16* A, const uint8_t* W_fp8, const float* bias, e
  *   q_scale: multiplies q (not k) in fp32 ahead of its bf16 rounding; 1.0 reproduces the reference's q.  Passing
  *            scale*log2(e) here and scale = ln(2) to ea_attention_fwd_* folds the softmax scale into Q: the
  *            attention kernel then exponentiates the raw MFMA scores (one VALU instruction per score less).
+ *   kv_off, kv_rows: geometry of k_out [batch, heads, kv_rows, 64] / vt_out [batch, heads, 64, kv_rows], rows / columns
+ *            [kv_off, kv_off + n_tok) are written; kv_rows <= 0 means "the same as q_out" (seq_off, s_pad).  Sequence
+ *            parallelism lets K / V^T land directly in the rank's slot of the exchange buffer (no pack copy).
  * s_pad % 64 == 0. */
 int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q_out, ea_bf16* k_out,
                         ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
                         const float* nk_b, const float* cos, const float* sin, int batch, int heads,
-                        int n_tok, int seq_off, int s_pad, float ln_eps, float q_scale, void* stream);
+                        int n_tok, int seq_off, int s_pad, int kv_off, int kv_rows, float ln_eps, float q_scale,
+                        void* stream);
 
 /* The three QKV projections of one token stream and everything up to the attention operands in ONE launch:
  *   q, k, v = A.Wq^T + bq, A.Wk^T + bk, A.Wv^T + bv   (processor.py:244-246 / 261-263)
@@ -153,21 +157,24 @@ int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q
  *   A: bf16 [batch, M, K] (row stride lda);  Wq/Wk/Wv: bf16 [heads*64, K] (three separate nn.Linear weights);
  *   bq/bk/bv: fp32 [heads*64] or NULL;  q_out/k_out: bf16 [batch, heads, s_pad, 64];  vt_out: bf16 [batch, heads, 64, s_pad];
  *   rows / columns [seq_off, seq_off + M) are written;  cos/sin: fp32 [M, 64] or NULL.
- * Requirements: M % 256 == 0, (heads*64) % 256 == 0, K % 64 == 0, seq_off % 8 == 0; other shapes (the 256-token text
- * stream, test-size models) use ea_gemm_bf16 + ea_qknorm_rope_bf16. */
+ *   kv_off, kv_rows: as in ea_qknorm_rope_bf16 (k_out / vt_out may have their own rows-per-head and first row).
+ *   parts: which thirds of the q | k | v output axis this launch computes: 7 (or 0) = all, 6 = k | v, 1 = q.  The
+ *          sequence-parallel step projects K | V first, starts the K / V^T exchange, and projects Q under it.
+ * Requirements: M % 256 == 0, (heads*64) % 256 == 0, K % 64 == 0, seq_off % 8 == 0, kv_off % 8 == 0; other shapes
+ * (test-size models) use ea_gemm_bf16 + ea_qknorm_rope_bf16. */
 int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
                                const float* bq, const float* bk, const float* bv, ea_bf16* q_out, ea_bf16* k_out,
                                ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
                                const float* nk_b, const float* cos, const float* sin, int batch, int M, int heads,
-                               int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, float ln_eps,
-                               float q_scale, void* stream);
+                               int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, int kv_off,
+                               int kv_rows, int parts, float ln_eps, float q_scale, void* stream);
 /* ... with the three weights stored as fp8 (see ea_gemm_bf16_w8): bit-identical to ea_qkv_gemm_norm_rope_bf16 on the up-cast weights. */
 int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq_fp8, const uint8_t* Wk_fp8, const uint8_t* Wv_fp8,
                                   const float* bq, const float* bk, const float* bv, ea_bf16* q_out, ea_bf16* k_out,
                                   ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,
                                   const float* nk_b, const float* cos, const float* sin, int batch, int M, int heads,
-                                  int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, float ln_eps,
-                                  float q_scale, void* stream);
+                                  int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, int kv_off,
+                                  int kv_rows, int parts, float ln_eps, float q_scale, void* stream);
 
 /* Non-causal, unmasked softmax(Q K^T * scale) V, head_dim 64, bf16 in/out, fp32 softmax state.
  * Replaces F.scaled_dot_product_attention at processor.py:287-289 plus the transpose/reshape at :291.
@@ -180,18 +187,19 @@ int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt,
                           int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
                           int q_begin, int q_end, float scale, void* stream);
 
-/* The resumable attention over keys that live in SEGMENTS: the other ranks' K / V^T shards exactly where
- * all_gather_into_tensor left them (sequence parallelism; no unpack copies into a contiguous key layout).  Segment g
- * (g = 0 .. n_seg-1, rank order) holds K as [batch*heads, seg_rows, 64] at k_seg0 + g*seg_stride and V^T as
- * [batch*heads, 64, seg_rows] at vt_seg0 + g*seg_stride (elements); segment skip_seg (the caller's own shard, already
- * attended from its local buffers; pass -1 to use every segment) is left out.  kv_valid = number of valid keys over the
- * used segments in order (all full except possibly the last).  q / out / state / flags / q_begin / q_end as
- * ea_attention_fwd_range_bf16 (q: [batch, heads, q_pad, 64]); the softmax scale must be folded into Q (scale = ln 2).
- * seg_rows % 64 == 0. */
+/* The resumable attention over keys that live in SEGMENTS: the ranks' K / V^T slots exactly where the (in-place)
+ * all_gather_into_tensor left them (sequence parallelism; no pack / unpack copies).  Segment g (g = 0 .. n_seg-1, rank
+ * order) holds K as [batch*heads, seg_rows, 64] at k_seg0 + g*seg_stride and V^T as [batch*heads, 64, seg_rows] at
+ * vt_seg0 + g*seg_stride (elements); segment skip_seg (pass -1 to use every segment) is left out.  Of every used segment
+ * the rows [seg_first_row, seg_first_row + seg_used_rows) are keys (a slot is [text rows | shard rows]: the remote pass
+ * skips the replicated text rows, the own-slot pass -- n_seg = 1, k_seg0 / vt_seg0 at the own slot -- takes both).
+ * kv_valid = number of valid keys over the used segments in order (all full except possibly the last).  q / out / state /
+ * flags / q_begin / q_end as ea_attention_fwd_range_bf16 (q: [batch, heads, q_pad, 64]); the softmax scale must be folded
+ * into Q (scale = ln 2).  seg_rows, seg_first_row, seg_used_rows % 64 == 0. */
 int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
                                    int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin, int q_end,
-                                   int seg_rows, int n_seg, int skip_seg, int64_t seg_stride, int kv_valid, float scale,
-                                   float* state, int flags, void* stream);
+                                   int seg_rows, int n_seg, int skip_seg, int64_t seg_stride, int seg_first_row,
+                                   int seg_used_rows, int kv_valid, float scale, float* state, int flags, void* stream);
 
 /* Sliding-window (band) attention of EasyAnimateSWAttnProcessor2_0 (processor.py:420: flash_attn_func(q, k, v,
  * window_size=(w, w)) on the six re-ordered head groups): query row i attends key rows j with |i - j| <= window, rows

@@ -800,3 +800,109 @@ def test_errors_are_reported_not_fatal():
         ops.gemm(A, W, None, 0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm(A.cpu(), W.cpu(), None, 0)
+
+
+# ---- round 3: K / V^T land in the rank's slot of the exchange buffer; K | V first; slot-relative key ranges ------------------
+@pytest.mark.parametrize("fused", [True, False])
+def test_qkv_projection_into_an_exchange_slot(fused):
+    """ea_qkv_gemm_norm_rope_bf16 / ea_qknorm_rope_bf16 with their own K / V^T geometry (kv_off, kv_rows): q goes to the
+    workspace rows [seq_off, ..), K / V^T to rows [kv_off, ..) of a buffer with another number of rows per head -- bit-identical
+    to the same launch into buffers of Q's geometry, nothing else written; the fused launch split into parts (K | V, then Q)
+    writes the same bits as the single launch."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(23)
+    B, H, M, K = 2, 4, 512 if fused else 200, 256
+    d = H * 64
+    x = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+    ws = [_bf(torch.randn(d, K, generator=g) / K ** 0.5).to(DEV) for _ in range(3)]
+    bs = [(0.3 * torch.randn(d, generator=g)).to(DEV) for _ in range(3)]
+    nq_w, nk_w = [(1 + 0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    nq_b, nk_b = [(0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    ang = torch.rand(M, 32, generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV), ang.sin().repeat_interleave(2, 1).contiguous().to(DEV)
+    seq_off, kv_off = 64, 128
+    s_pad, kv_rows = ops.round_up(seq_off + M, 256), kv_off + M + 64
+    full = lambda *shape: torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
+
+    def run(q, k, vt, **kw):
+        if fused:
+            assert ops.qkv_fused_ok(M, d, K, seq_off, kw.get("kv_off"))
+            ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q, k, vt, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off, 1e-6,
+                                   q_scale=ops.FOLDED_Q_SCALE, **kw)
+        else:
+            assert "parts" not in kw
+            qkv = torch.empty(B, M, 3 * d, dtype=torch.bfloat16, device=DEV)
+            for i in range(3):
+                ops.gemm(x, ws[i], bs[i], ops.EPI_BIAS, out=qkv[:, :, i * d:(i + 1) * d])
+            ops.qknorm_rope(qkv, q, k, vt, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off, 1e-6, q_scale=ops.FOLDED_Q_SCALE, **kw)
+    q0, k0, vt0 = full(B, H, s_pad, 64), full(B, H, s_pad, 64), full(B, H, 64, s_pad)
+    run(q0, k0, vt0)
+    q1, k1, vt1 = full(B, H, s_pad, 64), full(B, H, kv_rows, 64), full(B, H, 64, kv_rows)
+    run(q1, k1, vt1, kv_off=kv_off)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q0)
+    assert torch.equal(k1[:, :, kv_off:kv_off + M], k0[:, :, seq_off:seq_off + M]) and torch.equal(vt1[:, :, :, kv_off:kv_off + M], vt0[:, :, :, seq_off:seq_off + M])
+    assert (k1[:, :, :kv_off] == 7).all() and (k1[:, :, kv_off + M:] == 7).all() and (vt1[:, :, :, :kv_off] == 7).all() and (vt1[:, :, :, kv_off + M:] == 7).all()
+    if fused:
+        q2, k2, vt2 = full(B, H, s_pad, 64), full(B, H, kv_rows, 64), full(B, H, 64, kv_rows)
+        _lib.reset_counters()
+        run(q2, k2, vt2, kv_off=kv_off, parts=ops.QKV_KV)
+        torch.cuda.synchronize()
+        assert (q2 == 7).all() and torch.equal(k2, k1) and torch.equal(vt2, vt1)      # K | V first: q untouched
+        run(q2, k2, vt2, kv_off=kv_off, parts=ops.QKV_Q)
+        torch.cuda.synchronize()
+        assert torch.equal(q2, q1) and torch.equal(k2, k1) and torch.equal(vt2, vt1)
+        assert _lib.counters() == {"gemm_qkv_fused": 2, "gemm_qkv_fused_kv_part": 1, "gemm_qkv_fused_q_part": 1}
+
+
+@pytest.mark.parametrize("P,rank,T,nl,n_last", [(4, 1, 64, 192, 192), (4, 3, 128, 192, 100), (2, 0, 64, 128, 70), (3, 0, 192, 64, 64)])
+def test_attention_segments_slot_rows(P, rank, T, nl, n_last):
+    """The slot layout of the sequence-parallel exchange buffer: every segment is [text rows 0..T | shard rows T..T+nl];
+    the own-slot pass (n_seg = 1 at the own slot, first_row = 0) attends text + own shard, the remote pass skips the own
+    slot and the text rows of the others (first_row = T, used_rows = nl).  Both against ea_attention_fwd_range_bf16 over
+    the same keys copied into one contiguous layout -- same key order, same tiles: bit-identical, state carried through."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(77 + P + rank)
+    B, H = 2, 3
+    rows = T + nl
+    shard_rows = [nl] * (P - 1) + [n_last]
+    n_own = shard_rows[rank]
+    S_q = T + n_own
+    q_pad = ops.round_up(rows, 256)
+    q = torch.zeros(B, H, q_pad, 64, dtype=torch.bfloat16, device=DEV)
+    q[:, :, :S_q] = _bf(torch.randn(B, H, S_q, 64, generator=g) * 0.3).to(DEV)
+    buf = torch.zeros(P, 2, B, H, rows * 64, dtype=torch.bfloat16, device=DEV)
+    for r in range(P):
+        n = T + shard_rows[r]       # every slot carries (its own copy of) the text rows: remote copies must never be read
+        buf[r, 0].view(B, H, rows, 64)[:, :, :n] = _bf(torch.randn(B, H, n, 64, generator=g)).to(DEV)
+        buf[r, 1].view(B, H, 64, rows)[:, :, :, :n] = _bf(torch.randn(B, H, 64, n, generator=g)).to(DEV)
+    others = [r for r in range(P) if r != rank]
+    remote_valid = sum(nl for r in others[:-1]) + shard_rows[others[-1]]
+    # contiguous copy: [own slot rows 0..S_q | pad to 64 | remote shard rows ...]
+    own_pad = ops.round_up(S_q, 64)
+    s_pad = ops.round_up(max(own_pad + len(others) * nl, q_pad), 256)
+    kk = torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=DEV)
+    vv = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=DEV)
+    qq = torch.zeros_like(kk)
+    qq[:, :, :q_pad] = q
+    kk[:, :, :S_q] = buf[rank, 0].view(B, H, rows, 64)[:, :, :S_q]
+    vv[:, :, :, :S_q] = buf[rank, 1].view(B, H, 64, rows)[:, :, :, :S_q]
+    for i, r in enumerate(others):
+        kk[:, :, own_pad + i * nl:own_pad + (i + 1) * nl] = buf[r, 0].view(B, H, rows, 64)[:, :, T:]
+        vv[:, :, :, own_pad + i * nl:own_pad + (i + 1) * nl] = buf[r, 1].view(B, H, 64, rows)[:, :, :, T:]
+    st_a, st_b = ops.attention_state(B, H, 0, S_q, DEV), ops.attention_state(B, H, 0, S_q, DEV)
+    o_ref, o_seg = (torch.empty(B, S_q, H * 64, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    ops.attention_range(qq, kk, vv, ops.FOLDED_ATTN_SCALE, 0, S_q, 0, S_q, state=st_a, store_state=True)
+    ops.attention_range(qq, kk, vv, ops.FOLDED_ATTN_SCALE, 0, S_q, own_pad, own_pad + remote_valid, state=st_a, load_state=True, out=o_ref)
+    ops.attention_segments(q, buf[rank], 1, -1, rows, S_q, 0, S_q, state=st_b, store_state=True, first_row=0, used_rows=ops.round_up(S_q, 64))
+    ops.attention_segments(q, buf, P, rank, rows, remote_valid, 0, S_q, state=st_b, load_state=True, out=o_seg, first_row=T, used_rows=nl)
+    torch.cuda.synchronize()
+    assert torch.equal(o_seg, o_ref)
+    # against fp64 softmax over exactly those keys (the text rows of the remote slots excluded)
+    keys = torch.cat([kk[:, :, :S_q], kk[:, :, own_pad:own_pad + remote_valid]], 2).double()
+    vals = torch.cat([vv[:, :, :, :S_q], vv[:, :, :, own_pad:own_pad + remote_valid]], 3).double().transpose(2, 3)
+    qd = q[:, :, :S_q].double() / ops.FOLDED_Q_SCALE
+    ref = (torch.softmax(qd @ keys.transpose(2, 3) / 8.0, -1) @ vals).transpose(1, 2).reshape(B, S_q, H * 64)
+    err, rel = _report(f"segment attention over exchange slots P{P} r{rank}", o_seg, ref)
+    assert rel < 8e-3

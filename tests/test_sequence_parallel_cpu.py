@@ -68,13 +68,13 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
         cl, sl = sp.shard_rope((cos, sin), "cpu")
         lay = sp.layout(T, n)
         nl = sp.n_loc
-        vo = lay.v_off
-        assert vo % 64 == 0 and 0 <= vo - T < 64 and lay.q_end == vo + n and lay.remote_begin == vo + nl
-        assert lay.local_ranges == ([(0, T + n)] if vo == T else [(0, T), (vo, vo + n)])
-        assert all(lo % 64 == 0 for lo, _ in lay.local_ranges) and lay.remote_begin % 64 == 0
-        assert lay.s_pad % 256 == 0 and lay.s_pad >= vo + sp.size * nl
-        assert lay.remote_end - lay.remote_begin == n_video - n   # every other token, exactly once
-        assert sorted(sp.slot(r) for r in range(sp.size)) == list(range(sp.size)) and sp.slot(sp.rank) == 0
+        vo = lay.t_pad
+        assert vo % 64 == 0 and 0 <= vo - T < 64 and lay.q_end == vo + n and lay.rows == vo + nl and lay.v_off == vo
+        assert lay.own_ranges == ([(0, T + n)] if vo == T else [(0, T), (vo, vo + n)])
+        assert all(lo % 64 == 0 for lo, _ in lay.own_ranges)
+        assert lay.q_pad % 256 == 0 and lay.q_pad >= lay.rows
+        assert lay.remote_valid == n_video - n     # every other token, exactly once
+        assert sp.exchanges(lay) == (sp.size > 1)
 
         # ---- local per-token work (oracle arithmetic), per-rank K/V layout, asynchronous exchange
         nh, ne, gate, egate = R.layernorm_zero(sd, "norm1.", hl, e, temb, 1e-6)
@@ -91,28 +91,44 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
 
         qv, kv, vv = qkv("attn1.", nh, (cl, sl))
         qt, kt, vt_ = qkv("attn2.", ne, None)
-        ws = dict(q=torch.zeros(Bl, H, lay.s_pad, 64), k=torch.zeros(Bl, H, lay.s_pad, 64), vt=torch.zeros(Bl, H, 64, lay.s_pad))
-        ws["q"][:, :, :T], ws["k"][:, :, :T], ws["vt"][:, :, :, :T] = qt, kt, vt_.transpose(2, 3)
-        ws["q"][:, :, vo:vo + n], ws["k"][:, :, vo:vo + n] = qv, kv
-        ws["vt"][:, :, :, vo:vo + n] = vv.transpose(2, 3)
-        pending = sp.exchange_start(ws, vo)
+        # q workspace + the exchange buffer: the projections land in the rank's OWN slot, rows [text | gap | shard]
+        qws = torch.zeros(Bl, H, lay.q_pad, 64)
+        buf = sp.kv_buffer(Bl, H, lay, "cpu", torch.float32)
+        assert buf.shape == (sp.size, 2, Bl, H, lay.rows * 64) and sp.kv_buffer(Bl, H, lay, "cpu", torch.float32) is buf
+        k_own, vt_own = sp.slot_views(buf)
+        assert k_own.data_ptr() == buf[sp.rank, 0].data_ptr() and vt_own.shape == (Bl, H, 64, lay.rows)
+        qws[:, :, :T], k_own[:, :, :T], vt_own[:, :, :, :T] = qt, kt, vt_.transpose(2, 3)
+        qws[:, :, vo:vo + n], k_own[:, :, vo:vo + n] = qv, kv
+        vt_own[:, :, :, vo:vo + n] = vv.transpose(2, 3)
+        pending = sp.exchange_start(buf)
         assert (pending is None) == (sp.size == 1)
-        sp.exchange_finish(pending, ws, vo)
+        sp.exchange_finish(pending)
 
-        # every remote shard sits in its slot: compare with the unsharded projection of this batch slice
+        # every rank's shard sits in its slot, in place: compare with the unsharded projection of this batch slice
         nh_full, _, _, _ = R.layernorm_zero(sd, "norm1.", h, e, temb, 1e-6)
         _, k_full, v_full = qkv("attn1.", nh_full, (cos, sin))
         for r in range(sp.size):
             rlo, rhi = sp.shard_range(r)
-            o_ = vo + sp.slot(r) * nl
-            assert torch.allclose(ws["k"][:, :, o_:o_ + rhi - rlo], k_full[:, :, rlo:rhi], atol=1e-5)
-            assert torch.allclose(ws["vt"][:, :, :, o_:o_ + rhi - rlo], v_full[:, :, rlo:rhi].transpose(2, 3), atol=1e-5)
-            assert ws["k"][:, :, o_ + rhi - rlo:o_ + nl].abs().max().item() == 0 if rhi - rlo < nl else True
+            kr, vtr = sp.slot_views(buf, r)
+            assert torch.allclose(kr[:, :, vo:vo + rhi - rlo], k_full[:, :, rlo:rhi], atol=1e-5)
+            assert torch.allclose(vtr[:, :, :, vo:vo + rhi - rlo], v_full[:, :, rlo:rhi].transpose(2, 3), atol=1e-5)
+            assert kr[:, :, vo + rhi - rlo:].abs().max().item() == 0 if rhi - rlo < nl else True   # tail of a short shard: zero
 
-        # ---- queries = text rows + own rows; keys = local range + remote range of the rank-private layout
-        keys = [i for lo_, hi_ in lay.local_ranges for i in range(lo_, hi_)] + list(range(lay.remote_begin, lay.remote_end))
-        assert len(keys) == T + n_video
-        K_, V_ = ws["k"][:, :, keys], ws["vt"][:, :, :, keys].transpose(2, 3)
+        # ---- queries = text rows + own rows; keys = the own slot's ranges, then the shard rows of every other slot
+        Ks = [k_own[:, :, lo_:hi_] for lo_, hi_ in lay.own_ranges]
+        Vs = [vt_own[:, :, :, lo_:hi_] for lo_, hi_ in lay.own_ranges]
+        left = lay.remote_valid
+        for r in range(sp.size):
+            if r == sp.rank:
+                continue
+            kr, vtr = sp.slot_views(buf, r)
+            take = min(nl, left)
+            Ks.append(kr[:, :, vo:vo + take]); Vs.append(vtr[:, :, :, vo:vo + take])
+            left -= take
+        assert left == 0
+        K_, V_ = torch.cat(Ks, 2), torch.cat(Vs, 3).transpose(2, 3)
+        assert K_.shape[2] == T + n_video
+        ws = dict(q=qws)
         oo = F.scaled_dot_product_attention(ws["q"][:, :, :lay.q_end], K_, V_)
         o = oo.transpose(1, 2).reshape(Bl, lay.q_end, d)
         o_t, o_v = o[:, :T], o[:, vo:]

