@@ -136,6 +136,11 @@ class Decoder(nn.Module):
         x = self.mid_block(x)
         for blk in self.up_blocks:
             x = blk(x)
+        if getattr(x, "tvirt", False):
+            # a temporal up-sampler in the LAST up block (not a V5 / V5.1 layout): nobody left to address the duplicated
+            # frames virtually -- materialise them
+            idx = (torch.arange(2 * x.shape[0] - 1, device=x.device) + 1) >> 1
+            x = x[idx].contiguous()
         x = _gn(self.conv_norm_out, x, act=True)
         return self.conv_out(x)
 

@@ -33,6 +33,10 @@ struct ConvArgs {
     int T_in, H_in, W_in, C_in, C_out;
     int T_out, H_out, W_out;
     int kt, kh, kw, st, ss, pad, ups, tdup;
+    // virtual temporal x2 (SpatialTemporalUpsampler3D's nearest duplication kept un-materialised): vin -- x holds the T
+    // frames the up-sampler computed, the LOGICAL input has 2T-1, logical frame f lives in physical frame (f + 1) >> 1;
+    // vres -- the same for the residual operand (the block's shortcut, computed on the physical frames)
+    int vin, vres;
     int tiles_m, tiles_n;
     int64_t M;
     float* gn_partial;   // optional (row-slab 16x16x32 kernel): per-(frame, row tile, wave row, 4-channel bundle) (sum, sumsq)
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
             }
             int ti = vt[i] * p.st + dt - (p.kt - 1);
             ti = ti < 0 ? 0 : ti;  // causal replicate padding
+            ti = p.vin ? (ti + 1) >> 1 : ti;
             int hh = vh[i] * p.ss + dh - p.pad;
             int ww = vw[i] * p.ss + dw - p.pad;
             const bool ok = (unsigned)hh < (unsigned)H_eff && (unsigned)ww < (unsigned)W_eff && (!C8 || tap < ntaps);
@@ -237,7 +242,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
                     }
                 }
                 if (p.res) {
-                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + m * p.C_out + n0);
+                    int64_t mr = m;
+                    if (p.vres) {   // the residual holds the physical frames of a virtually duplicated clip
+                        const int64_t tr = m / frame;
+                        mr = m - (tr - ((tr + 1) >> 1)) * frame;
+                    }
+                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + mr * p.C_out + n0);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(rr[e]);
                 }
@@ -359,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
         for (int i = 0; i < AP; ++i) {
             int ti = vt[i] + dt;
             ti = ti < 0 ? 0 : ti;                       // causal replicate padding
+            ti = p.vin ? (ti + 1) >> 1 : ti;
             int hh = vh[i] + dh, ww = vw[i] + dw;
             const bool ok = (unsigned)hh < (unsigned)H_eff && (unsigned)ww < (unsigned)W_eff;
             hh >>= ups_sh;
@@ -507,7 +518,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
                     }
                 }
                 if (p.res) {
-                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + m * p.C_out + n0);
+                    int64_t mr = m;
+                    if (p.vres) {   // the residual holds the physical frames of a virtually duplicated clip
+                        const int64_t tr = m / frame;
+                        mr = m - (tr - ((tr + 1) >> 1)) * frame;
+                    }
+                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + mr * p.C_out + n0);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(rr[e]);
                 }
@@ -621,6 +637,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
         const int dt = dtdh / 3, dh = dtdh - dt * 3;
         int ti = t_out + dt - 2;
         ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
+        ti = p.vin ? (ti + 1) >> 1 : ti;                       // virtual temporal x2
         const int hu = h_out + dh - 1;                         // row in the (up-sampled) padded input
         slab_ok = hu >= 0 && hu < p.H_out;                     // wave-uniform (stride 1, pad 1: H_out rows)
         const int hh = UPS ? hu >> 1 : hu;
@@ -748,7 +765,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
                     }
                 }
                 if (p.res) {
-                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + m * p.C_out + n0);
+                    int64_t mr = m;
+                    if (p.vres) {   // the residual holds the physical frames of a virtually duplicated clip
+                        const int64_t tr = m / frame;
+                        mr = m - (tr - ((tr + 1) >> 1)) * frame;
+                    }
+                    const u16x8 rr = *reinterpret_cast<const u16x8*>(p.res + mr * p.C_out + n0);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(rr[e]);
                 }
@@ -858,6 +880,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         const int dt = dtdh / 3, dh = dtdh - dt * 3;
         int ti = t_out + dt - 2;
         ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
+        ti = p.vin ? (ti + 1) >> 1 : ti;                       // virtual temporal x2
         const int hu = h_out + dh - 1;                         // row in the (up-sampled) padded input
         slab_ok = hu >= 0 && hu < p.H_out;                     // wave-uniform (stride 1, pad 1: H_out rows)
         const int hh = UPS ? hu >> 1 : hu;
@@ -1008,19 +1031,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     const int ch0 = col0 + wc * 64 + lq * 4;
     const int64_t e_res = m_base * p.C_out + ch0;              // + i * e_step + j * 16
     const int64_t e_step = (int64_t)16 * p.C_out;
+    // virtual residual: logical frame t_out lives in physical frame (t_out + 1) >> 1 of p.res
+    const unsigned short* const resp = p.res ? p.res - (p.vres ? (int64_t)(t_out - ((t_out + 1) >> 1)) * frame * p.C_out : 0) : nullptr;
     // with tdup the frame t_out >= 1 is stored twice: frames 2t - 1 and 2t of y
     const int64_t e_dst0 = dup_t ? e_res + ((int64_t)t_out - 1) * frame * p.C_out : e_res;
     const int64_t e_dup = frame * p.C_out;
     bf16x4 rr[2][4];
     if (has_res) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rr[0][j] = *reinterpret_cast<const bf16x4*>(p.res + e_res + j * 16);
+        for (int j = 0; j < 4; ++j) rr[0][j] = *reinterpret_cast<const bf16x4*>(resp + e_res + j * 16);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         if (has_res && i + 1 < MT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rr[(i + 1) & 1][j] = *reinterpret_cast<const bf16x4*>(p.res + e_res + (i + 1) * e_step + j * 16);
+            for (int j = 0; j < 4; ++j) rr[(i + 1) & 1][j] = *reinterpret_cast<const bf16x4*>(resp + e_res + (i + 1) * e_step + j * 16);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1190,6 +1215,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
         const int dt = dtdh / 3, dh = dtdh - dt * 3;
         int ti = (S2 ? t_out * p.st : t_out) + dt - 2;
         ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
+        ti = p.vin ? (ti + 1) >> 1 : ti;                       // virtual temporal x2
         const int hu = S2 ? 2 * h_out + dh : h_out + dh - 1;   // S2: pad 0, one zero row below the last one
         slab_ok = hu >= 0 && hu < p.H_in;
         slab_row = p.x + ((int64_t)ti * p.H_in + (slab_ok ? hu : 0)) * p.W_in * p.C_in;
@@ -1286,16 +1312,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
     const int64_t m_base = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + lr;
     const int64_t e_base = m_base * p.C_out + col0 + wc * 64 + lq * 4;   // + i * 16 * C_out + j * 16
     const int64_t e_step = (int64_t)16 * p.C_out;
+    // virtual residual: logical frame t_out lives in physical frame (t_out + 1) >> 1 of p.res
+    const unsigned short* const resp =
+        p.res ? p.res - (p.vres ? (int64_t)(t_out - ((t_out + 1) >> 1)) * p.H_out * p.W_out * p.C_out : 0) : nullptr;
     bf16x4 rr[2][4];
     if (has_res) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rr[0][j] = *reinterpret_cast<const bf16x4*>(p.res + e_base + j * 16);
+        for (int j = 0; j < 4; ++j) rr[0][j] = *reinterpret_cast<const bf16x4*>(resp + e_base + j * 16);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         if (has_res && i + 1 < MT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rr[(i + 1) & 1][j] = *reinterpret_cast<const bf16x4*>(p.res + e_base + (i + 1) * e_step + j * 16);
+            for (int j = 0; j < 4; ++j) rr[(i + 1) & 1][j] = *reinterpret_cast<const bf16x4*>(resp + e_base + (i + 1) * e_step + j * 16);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1416,7 +1445,15 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     p.gn_partial = nullptr; p.gn_nblk = 0;
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y; p.zeros = zeros;
     p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.C_in = C_in; p.C_out = C_out;
-    p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.ss = ss; p.pad = pad; p.ups = ups; p.tdup = tdup;
+    p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.ss = ss; p.pad = pad; p.ups = ups;
+    // tdup flags: 1 = store every output frame but the first twice; 2 = the input's frames are virtually duplicated (x holds
+    // T_in physical frames, the convolution sees 2 T_in - 1); 4 = the residual's frames are virtually duplicated
+    EA_REQUIRE((tdup & ~7) == 0, "ea_conv3d_cl_bf16: tdup is a bit set of 1 (duplicate store), 2 (virtual input), 4 (virtual residual)");
+    p.tdup = tdup & 1; p.vin = (tdup >> 1) & 1; p.vres = (tdup >> 2) & 1;
+    EA_REQUIRE(!(p.vin && (kt != 3 || st != 1 || C_in == 8)), "ea_conv3d_cl_bf16: virtual input frames need a 3x3x3 temporal-stride-1 layer");
+    EA_REQUIRE(!(p.vres && !res), "ea_conv3d_cl_bf16: virtual residual without a residual");
+    if (p.vin) T_in = T_in > 1 ? 2 * T_in - 1 : T_in;      // logical frames from here on
+    p.T_in = T_in;
     const int He = ups ? 2 * H_in : H_in, We = ups ? 2 * W_in : W_in;
     // temporal: kt-1 replicated leading frames; spatial: `pad` zeros low, and for the strided (pad 0) convs one
     // zero row/column high (downsamplers.py:44-46 F.pad(x,(0,1,0,1)))

@@ -38,15 +38,31 @@ def _pad_bias(b: Optional[torch.Tensor], n_pad: int) -> Optional[torch.Tensor]:
     return b.contiguous()
 
 
+VIRTUAL_TDUP = True   # False: SpatialTemporalUpsampler3D materialises its duplicated frames (A/B, tests)
+
+
+def is_virtual(x: Optional[torch.Tensor]) -> bool:
+    """x holds the physical frames of a virtually duplicated clip (logical frame f = physical (f + 1) >> 1)."""
+    return bool(getattr(x, "tvirt", False))
+
+
 def conv_cl(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None, ups: bool = False,
             tdup: bool = False) -> torch.Tensor:
     """Apply a (Causal)Conv3d module's parameters to a channels-last clip x [T,H,W,Cin] -> [T',H',W',Cout_pad8].
     Under a temporal split (vae_parallel) a rank that is not the first prepends its left neighbour's last frames and drops
-    the outputs that belong to them: every retained output sees exactly the inputs of the whole-clip evaluation."""
+    the outputs that belong to them: every retained output sees exactly the inputs of the whole-clip evaluation.
+    x / res may be VIRTUAL clips (is_virtual): a 1x1x1 layer then runs on the physical frames and its output stays virtual, a
+    3x3x3 layer addresses the logical frames inside the kernel and returns a real clip."""
     from . import vae_parallel
     tp = vae_parallel.current()
     if tp is None or conv.weight.shape[2] == 1:
+        if conv.weight.shape[2] == 1 and is_virtual(x):
+            assert res is None and not ups and not tdup
+            y = _conv_cl_local(conv, x, None, False, False)
+            y.tvirt = True
+            return y
         return _conv_cl_local(conv, x, res, ups, tdup)
+    assert not is_virtual(x) and not is_virtual(res), "virtual clips are not produced under a temporal split"
     st = conv.stride[0]
     n = tp.halo_frames(st)
     halo = tp.exchange(x, n)
@@ -82,6 +98,8 @@ def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor]
     pad = conv.padding[1] if kt == 3 else 0
     n_pad = ops.round_up(co, 8)
     c8 = ci <= 8 and kt == 3 and x.shape[-1] == 8 and res is None and not ups and not tdup
+    if is_virtual(x) or is_virtual(res):
+        assert ci % 64 == 0 and not (co <= 4 and kt == 3), "virtual clips feed the wide 3x3x3 / 1x1x1 layers of the up blocks only"
     if x.shape[-1] != ci and not c8:
         raise ValueError(f"conv expects {ci} input channels, got {x.shape[-1]}")
     if c8:
@@ -99,7 +117,9 @@ def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor]
     if ci % 64 == 0:
         w = derived(conv.weight, f"cl{n_pad}", lambda t: _pack_conv_weight(t, None, n_pad))
         b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None
-        return ops.conv3d_cl(x, w, b, kt, st, sh, pad, ups=ups, tdup=tdup, res=res)
+        return ops.conv3d_cl(x, w, b, kt, st, sh, pad, ups=ups, tdup=tdup, res=res, vin=is_virtual(x) and kt == 3,
+                             vres=is_virtual(res))
+    assert not is_virtual(x) and not is_virtual(res)
     # small C_in: explicit im2col + GEMM
     assert res is None and not ups and not tdup
     k = kt * kh * kw * ci
@@ -138,7 +158,11 @@ class CausalConv3d(nn.Conv3d):
 
 
 def _gn(norm: nn.GroupNorm, x: torch.Tensor, act: bool) -> torch.Tensor:
-    return ops.groupnorm_silu(x, f32(norm.weight), f32(norm.bias), norm.num_groups, norm.eps, act=act)
+    """Per-frame GroupNorm: a virtual clip is normalised on its physical frames (duplicated frames have equal statistics)."""
+    y = ops.groupnorm_silu(x, f32(norm.weight), f32(norm.bias), norm.num_groups, norm.eps, act=act)
+    if is_virtual(x):
+        y.tvirt = True
+    return y
 
 
 class ResidualBlock3D(nn.Module):
@@ -214,6 +238,13 @@ class SpatialTemporalUpsampler3D(nn.Module):
         self.set_3dgroupnorm = True
 
     def forward(self, x):
+        from . import vae_parallel
+        if VIRTUAL_TDUP and vae_parallel.current() is None and x.shape[0] > 1:
+            # the duplicated frames are never written: the consumers (the next block's GroupNorm, 1x1x1 shortcut, first
+            # 3x3x3 convolution and the residual add of its second one) address frame (t + 1) >> 1
+            y = self.conv(x, ups=True, tdup=False)
+            y.tvirt = True
+            return y
         return self.conv(x, ups=True, tdup=True)
 
 

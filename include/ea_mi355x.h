@@ -289,9 +289,14 @@ int ea_gated_residual_bf16(const ea_bf16* x, const ea_bf16* res, const float* ga
  * property 1); spatial padding `pad` zeros on the low side and, for the pad-0 strided convs, one zero
  * row/column on the high side (F.pad(x,(0,1,0,1))).  st / ss = temporal / spatial stride in {1,2}.
  * ups = 1: the input is read through a nearest x2 spatial up-sampling (never materialised).
- * tdup = 1: output frame t >= 1 is written to frames 2t-1 and 2t of y (y then has 2*T_out-1 frames): the
- *           temporal nearest x2 of SpatialTemporalUpsampler3D under spatial_group_norm.
- * res (optional, same shape as the un-duplicated output): y = conv + bias + res.
+ * tdup is a bit set:
+ *   1: output frame t >= 1 is written to frames 2t-1 and 2t of y (y then has 2*T_out-1 frames): the temporal nearest x2
+ *      of SpatialTemporalUpsampler3D under spatial_group_norm (upsamplers.py:146-152), materialised;
+ *   2: the same duplication kept VIRTUAL on the input side: x holds the T_in frames an up-sampler computed, the layer
+ *      convolves the 2*T_in-1 logical frames (logical frame f = physical frame (f+1)>>1) -- the duplicated frames are
+ *      never written, normalised or read twice from HBM (3x3x3, temporal stride 1 layers);
+ *   4: the residual operand is such a virtual clip ((T_out+1)/2 physical frames).
+ * res (optional, same shape as the un-duplicated output -- or its physical frames with tdup & 4): y = conv + bias + res.
  * zeros: any device buffer holding >= 128 zero bytes (source of the spatial zero padding). */
 int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
                       const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,

@@ -560,3 +560,75 @@ def test_vae_frame_bookkeeping_gpu():
         _, rel_m = _rep(f"vae enc {f}f", m.float(), mr)
         _, rel_d = _rep(f"vae dec {fl}->{f}f", d.float(), dr)
         assert rel_m < 4e-2 and rel_d < 4e-2
+
+
+# ---- round 3: temporal nearest x2 kept virtual (upsamplers.py:146-152 never materialised) -----------------------------------
+VIRT_CASES = [
+    # T_phys, H, W, Ci, Co, forced conv_tile, expected kernel family
+    (3, 6, 10, 64, 64, 0, None),                 # 128^2 generic kernel
+    (4, 4, 256, 128, 256, 1024, "conv_row16_256"),   # 256-voxel row slab
+    (3, 3, 512, 256, 128, 1024, "conv_row16_m512"),  # 512-voxel row slab (decoder block 3, conv1 of the first ResidualBlock3D)
+    (3, 20, 24, 128, 128, 256, "conv_pp"),        # ping-pong kernel
+    (1, 5, 6, 64, 64, 0, None),                   # one physical frame: nothing to duplicate
+]
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,tile,kern", VIRT_CASES)
+def test_conv3d_virtual_temporal_duplication(T, H, W, Ci, Co, tile, kern):
+    """tdup bits 2 / 4 (virtual input frames / virtual residual frames) against the same convolution on the materialised
+    clip: identical arithmetic in the identical order -> bit-identical, in every kernel family the up blocks use."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight
+    g = torch.Generator().manual_seed(13)
+    x = _bf(torch.randn(T, H, W, Ci, generator=g)).to(DEV)
+    w = _pack_conv_weight(_bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    r = _bf(torch.randn(T, H, W, Co, generator=g)).to(DEV)
+    idx = ((torch.arange(2 * T - 1, device=DEV) + 1) >> 1) if T > 1 else torch.zeros(1, dtype=torch.long, device=DEV)
+    xm, rm = x[idx].contiguous(), r[idx].contiguous()
+    _lib.set_option("conv_tile", tile)
+    try:
+        _lib.reset_counters()
+        y_ref = ops.conv3d_cl(xm, w, b, 3, 1, 1, 1, res=rm)
+        c_ref = _lib.counters()
+        _lib.reset_counters()
+        y_v = ops.conv3d_cl(x, w, b, 3, 1, 1, 1, res=r, vin=True, vres=True)
+        c_v = _lib.counters()
+        y_v2 = ops.conv3d_cl(x, w, b, 3, 1, 1, 1, res=rm, vin=True)          # virtual input, real residual
+        y_v3 = ops.conv3d_cl(xm, w, b, 3, 1, 1, 1, res=r, vres=True)          # real input, virtual residual
+    finally:
+        _lib.set_option("conv_tile", 0)
+    torch.cuda.synchronize()
+    assert c_ref == c_v and (kern is None or any(k.startswith(kern) for k in c_v)), (c_ref, c_v)
+    assert y_v.shape == y_ref.shape == (2 * T - 1 if T > 1 else 1, H, W, Co)
+    assert torch.equal(y_v, y_ref) and torch.equal(y_v2, y_ref) and torch.equal(y_v3, y_ref)
+    # the GroupNorm partial sums of the epilogue ride along unchanged
+    pv, pr = getattr(y_v, "gn_partial", None), getattr(y_ref, "gn_partial", None)
+    assert (pv is None) == (pr is None)
+    if pv is not None:
+        n = y_ref.shape[0] * pr[1] * (Co // 4) * 2
+        assert pv[1] == pr[1] and torch.equal(pv[0][:n], pr[0][:n])
+
+
+def test_vae_decode_virtual_equals_materialised_temporal_duplication():
+    """The decoder with the up-samplers' duplicated frames kept virtual (GroupNorm, 1x1x1 shortcut, first 3x3x3 convolution
+    and the residual add of the next block address frame (t+1)>>1) against the decoder that writes them: every kernel does
+    the same arithmetic on the same values -> the decoded clips are bit-identical."""
+    from easyanimate_amd import AutoencoderKLMagvit, vae_modules
+    from easyanimate_amd.synthetic import synth_state_dict
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
+    vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    gen = torch.Generator().manual_seed(4)
+    for fl, hw in ((3, 8), (4, 16), (1, 8)):
+        z = torch.randn(1, 16, fl, hw, hw, generator=gen).to(DEV).bfloat16()
+        with torch.no_grad():
+            assert vae_modules.VIRTUAL_TDUP
+            a = vae.decode(z)[0]
+            vae_modules.VIRTUAL_TDUP = False
+            try:
+                b = vae.decode(z)[0]
+            finally:
+                vae_modules.VIRTUAL_TDUP = True
+        assert a.shape == b.shape == (1, 3, 4 * (fl - 1) + 1, 8 * hw, 8 * hw) and torch.equal(a, b)
