@@ -70,6 +70,7 @@ extern "C" int ea_version(void) { return 110; }   // 110: K / V^T geometry + par
 #define EA_OPTION(n) int ea_##n##_set(int v); int ea_##n##_get();
 EA_OPTION(gemm_tile)      // ea_gemm.hip:      0 (auto) | 128 | 256
 EA_OPTION(gemm_mfma)      // ea_gemm.hip:      16 | 32
+EA_OPTION(gemm_w4)        // ea_gemm.hip:      0 | 1  (four-wave 128x128-wave-tile kernel for the 256^2 tiles)
 EA_OPTION(conv_mfma)      // ea_conv.hip:      16 | 32
 EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
 EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1
@@ -78,7 +79,7 @@ EA_OPTION(attn_variant)   // ea_attention.hip: 1 | 2
 namespace {
 struct Option { const char* name; int (*set)(int); int (*get)(); };
 #define EA_OPTION(n) {#n, ea_##n##_set, ea_##n##_get}
-const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(conv_mfma),
+const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(gemm_w4), EA_OPTION(conv_mfma),
                             EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(attn_variant)};
 #undef EA_OPTION
 const Option* find_option(const char* name) {

@@ -1450,6 +1450,7 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     // T_in physical frames, the convolution sees 2 T_in - 1); 4 = the residual's frames are virtually duplicated
     EA_REQUIRE((tdup & ~7) == 0, "ea_conv3d_cl_bf16: tdup is a bit set of 1 (duplicate store), 2 (virtual input), 4 (virtual residual)");
     p.tdup = tdup & 1; p.vin = (tdup >> 1) & 1; p.vres = (tdup >> 2) & 1;
+    tdup = p.tdup;   // from here on `tdup` is the duplicate-store flag alone (the kernel choice below tests it)
     EA_REQUIRE(!(p.vin && (kt != 3 || st != 1 || C_in == 8)), "ea_conv3d_cl_bf16: virtual input frames need a 3x3x3 temporal-stride-1 layer");
     EA_REQUIRE(!(p.vres && !res), "ea_conv3d_cl_bf16: virtual residual without a residual");
     if (p.vin) T_in = T_in > 1 ? 2 * T_in - 1 : T_in;      // logical frames from here on

@@ -906,3 +906,39 @@ def test_attention_segments_slot_rows(P, rank, T, nl, n_last):
     ref = (torch.softmax(qd @ keys.transpose(2, 3) / 8.0, -1) @ vals).transpose(1, 2).reshape(B, S_q, H * 64)
     err, rel = _report(f"segment attention over exchange slots P{P} r{rank}", o_seg, ref)
     assert rel < 8e-3
+
+
+# ---- round 3: the four-wave 256^2 GEMM (128 x 128 wave tiles, accumulators in AGPRs) -----------------------------------------
+@pytest.mark.parametrize("B,M,N,K", GEMM256_SHAPES + [(1, 256, 256, 320), (1, 4096, 3072, 3072)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_w4_equals_the_eight_wave_kernel(B, M, N, K, epi):
+    """gemm256_w4_kernel against fp64 (through test_gemm) and against gemm256_mi16_kernel: the same 16x16x32 products summed
+    in the same order per output element -> bit-identical, M / N tails, odd and even K-tile counts, strided batches;
+    repeated launches bit-identical (race screen for the one-barrier-per-tile schedule)."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    w4_default = _lib.get_option("gemm_w4")
+    _lib.set_option("gemm_tile", 256)
+    try:
+        _lib.set_option("gemm_w4", 1)
+        _lib.reset_counters()
+        test_gemm(B, M, N, K, epi)
+        assert _lib.counters().get("gemm_256_w4", 0) == 1, _lib.counters()
+        g = torch.Generator(device="cpu").manual_seed(8)
+        A = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+        W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        res = _bf(torch.randn(B, M, N, generator=g)).to(DEV)
+        gate = torch.randn(B, N, generator=g).to(DEV)
+        run = lambda: ops.gemm(A, W, bias, epi, res=res if epi == 2 else None, gate=gate if epi == 2 else None)
+        y1 = run()
+        for _ in range(3):
+            assert torch.equal(run(), y1)
+        _lib.set_option("gemm_w4", 0)
+        _lib.reset_counters()
+        y0 = run()
+        assert _lib.counters().get("gemm_256_mi16", 0) == 1
+        assert torch.equal(y0, y1)
+    finally:
+        _lib.set_option("gemm_tile", 0)
+        _lib.set_option("gemm_w4", w4_default)
