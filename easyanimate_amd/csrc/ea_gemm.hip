@@ -839,50 +839,36 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
 #define EA_W4_MFMA1(BUF, N)                                                                                       \
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                        \
                  : "+a"(acc[(N) & 7][(N) >> 3]) : "v"(fw[BUF][(N) >> 3]), "v"(fa[BUF][(N) & 7]));
-    // fragment x of (STAGE, KS) -> buffer BUF: even x = W fragment x / 2, odd x = activation fragment x / 2
-#define EA_W4_READ1(BUF, STAGE, KS, X)                                                                            \
-    if (((X) & 1) == 0) fw[BUF][(X) >> 1] = *reinterpret_cast<const bf16x8*>(smem + (w_k[KS] + (STAGE) * OPER2 + ((X) >> 1) * 2048)); \
-    else fa[BUF][(X) >> 1] = *reinterpret_cast<const bf16x8*>(smem + (a_k[KS] + (STAGE) * OPER2 + ((X) >> 1) * 2048));
-    // DMA piece x (0..7) of both operands of the next K tile into stage STAGE (the source pointers advance by one tile)
-#define EA_W4_ISSUE1(STAGE, X)                                                                                    \
+    // fragment x of K step KS -> buffer BUF from the stage at byte offset SOFF: even x = W fragment x / 2, odd x = activation
+    // fragment x / 2
+#define EA_W4_READ1(BUF, SOFF, KS, X)                                                                             \
+    if (((X) & 1) == 0) fw[BUF][(X) >> 1] = *reinterpret_cast<const bf16x8*>(smem + (w_k[KS] + (SOFF) + ((X) >> 1) * 2048)); \
+    else fa[BUF][(X) >> 1] = *reinterpret_cast<const bf16x8*>(smem + (a_k[KS] + (SOFF) + ((X) >> 1) * 2048));
+    // DMA piece x (0..7) of both operands of the next K tile into the stage at SOFF (the source pointers advance by one tile)
+#define EA_W4_ISSUE1(SOFF, X)                                                                                     \
     {                                                                                                             \
         asrc[X] += BK;                                                                                            \
         wsrc[X] += BK;                                                                                            \
-        glds16(asrc[X], dma_a + (STAGE) * OPER2 + (X) * 1024);                                                    \
-        glds16(wsrc[X], dma_w + (STAGE) * OPER2 + (X) * 1024);                                                    \
+        glds16(asrc[X], dma_a + (SOFF) + (X) * 1024);                                                             \
+        glds16(wsrc[X], dma_w + (SOFF) + (X) * 1024);                                                             \
     }
     // one k32 step: 64 MFMAs on buffer BUFC in 16 groups of four.  Groups 1..8 are each preceded by two fragment reads into
-    // buffer BUFL (READ): all 16 are issued in the first half of the step and have returned when it ends (the closing
-    // lgkmcnt(0) is free, and nothing is in flight when the next step's first MFMAs wait for THEIR fragments); the odd
-    // groups by one DMA piece pair of the K tile after next (ISSUE)
-#define EA_W4_STEP(BUFC, BUFL, STAGE_L, KS_L, READ, ISSUE, STAGE_I)                                               \
+    // buffer BUFL: all 16 are issued in the first half of the step and have returned when it ends (the closing lgkmcnt(0)
+    // is free, and nothing is in flight when the next step's first MFMAs wait for THEIR fragments); the odd groups by one DMA
+    // piece pair of the K tile after next (ISSUE, wave-uniform)
+#define EA_W4_STEP(BUFC, BUFL, SOFF_L, KS_L, ISSUE, SOFF_I)                                                       \
     _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                              \
-        if ((READ) && g >= 1 && g <= 8) {                                                                         \
-            EA_W4_READ1(BUFL, STAGE_L, KS_L, 2 * (g - 1))                                                         \
-            EA_W4_READ1(BUFL, STAGE_L, KS_L, 2 * (g - 1) + 1)                                                     \
+        if (g >= 1 && g <= 8) {                                                                                   \
+            EA_W4_READ1(BUFL, SOFF_L, KS_L, 2 * (g - 1))                                                          \
+            EA_W4_READ1(BUFL, SOFF_L, KS_L, 2 * (g - 1) + 1)                                                      \
         }                                                                                                         \
-        if ((ISSUE) && (g & 1)) EA_W4_ISSUE1(STAGE_I, g >> 1)                                                     \
+        if ((g & 1) && (ISSUE)) EA_W4_ISSUE1(SOFF_I, g >> 1)                                                      \
         EA_W4_MFMA1(BUFC, g * 4 + 0)                                                                              \
         EA_W4_MFMA1(BUFC, g * 4 + 1)                                                                              \
         EA_W4_MFMA1(BUFC, g * 4 + 2)                                                                              \
         EA_W4_MFMA1(BUFC, g * 4 + 3)                                                                              \
     }                                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // one K tile in stage ST that has a successor: step 0 = MFMAs on buffer 0 while its step-1 fragments -> buffer 1; then
-    // "tile t + 1 complete, stage ST free" (own pieces by vmcnt, the others' by the barrier); step 1 = MFMAs on buffer 1 while
-    // the first fragments of tile t + 1 -> buffer 0 and (ISSUE) tile t + 2 -> stage ST
-#define EA_W4_TILE(ST, ISSUE)                                                                                     \
-    {                                                                                                             \
-        EA_W4_STEP(0, 1, ST, 1, true, false, 0)                                                                   \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
-        __builtin_amdgcn_s_barrier();                                                                             \
-        EA_W4_STEP(1, 0, (ST) ^ 1, 0, true, ISSUE, ST)                                                            \
-    }
-#define EA_W4_LAST(ST)                                                                                            \
-    {                                                                                                             \
-        EA_W4_STEP(0, 1, ST, 1, true, false, 0)                                                                   \
-        EA_W4_STEP(1, 0, 0, 0, false, false, 0)                                                                   \
-    }
 
     // ---- prologue: tile 0 -> stage 0, its first fragments -> buffer 0, tile 1 -> stage 1
 #pragma unroll
@@ -895,22 +881,27 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     if (nk > 1) {
 #pragma unroll
-        for (int x = 0; x < 8; ++x) EA_W4_ISSUE1(1, x)
+        for (int x = 0; x < 8; ++x) EA_W4_ISSUE1(OPER2, x)
     }
 #pragma unroll
     for (int x = 0; x < 16; ++x) { EA_W4_READ1(0, 0, 0, x) }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
-    int t = 0;
-    for (; t + 2 < nk; t += 2) {       // tiles t (stage 0) and t + 1 (stage 1) both have a successor
-        EA_W4_TILE(0, true)
-        EA_W4_TILE(1, t + 3 < nk)
-    }
-    if (t + 1 < nk) {
-        EA_W4_TILE(0, false)
-        EA_W4_LAST(1)
-    } else {
-        EA_W4_LAST(0)
+    // ---- ONE loop body for every K tile (the MFMA code exists once: no second copy whose register assignment the compiler
+    // would have to reconcile with copies -- it cannot see that an asm statement is an MFMA whose result needs wait states).
+    // Tile t lives in the stage at `so` (0 / OPER2, toggled).  Step 0: MFMAs on buffer 0 while its step-1 fragments -> buffer
+    // 1.  Then "tile t + 1 complete, this tile's stage free" (own pieces by vmcnt, the others' by the barrier).  Step 1: MFMAs
+    // on buffer 1 while the first fragments of tile t + 1 -> buffer 0 (after the last tile: a harmless read of stale LDS)
+    // and tile t + 2 -> this tile's stage.
+    unsigned so = 0;
+    for (int t = 0; t < nk; ++t) {
+        const bool issue = t + 2 < nk;                       // wave-uniform
+        EA_W4_STEP(0, 1, so, 1, false, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        EA_W4_STEP(1, 0, so ^ OPER2, 0, issue, so)
+        so ^= OPER2;
     }
     // the last MFMAs' results must have left the pipe before the epilogue reads the accumulators (inline asm: the hazard
     // recogniser does not see the producer)
@@ -919,8 +910,6 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
 #undef EA_W4_READ1
 #undef EA_W4_ISSUE1
 #undef EA_W4_STEP
-#undef EA_W4_TILE
-#undef EA_W4_LAST
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the LDS becomes the epilogue images
 
