@@ -220,11 +220,13 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
     def _clear_conv_cache(self):
         pass  # whole-clip evaluation keeps no chunk caches
 
-    def enable_temporal_parallel(self, group=None):
+    def enable_temporal_parallel(self, group=None, spatial: int = 1):
         """Exact multi-GPU encode / decode: every rank of `group` holds the same weights and passes the same input; each
-        evaluates a contiguous range of frames and all ranks return the whole result (easyanimate_amd/vae_parallel.py)."""
+        evaluates a contiguous range of frames -- and, with spatial = P_s > 1, H / P_s rows of them: 8 ranks on 13 latent
+        frames run as 4 (time) x 2 (rows) with every rank busy -- and all ranks return the whole result
+        (easyanimate_amd/vae_parallel.py)."""
         from .vae_parallel import TemporalParallel
-        self.temporal_parallel = TemporalParallel(group)
+        self.temporal_parallel = TemporalParallel(group, spatial=spatial)
         return self.temporal_parallel
 
     def disable_temporal_parallel(self):
@@ -275,12 +277,14 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
             for _ in range(n_temporal):
                 fr = tp.finer(fr)
             m_loc = None
+            tp.rows(xb.shape[2] // 8)                  # the latent rows must divide over the spatial ranks
+            r0, r1 = tp.rows(xb.shape[2])
             if tp.is_active:
                 with vae_parallel.activate(tp):
-                    h = self.encoder(ops.ncdhw_to_ndhwc(xb[:, fr[0]:fr[1]].contiguous(), self._enc_c_pad))
+                    h = self.encoder(ops.ncdhw_to_ndhwc(xb[:, fr[0]:fr[1], r0:r1].contiguous(), self._enc_c_pad))
                     m_loc = ops.ndhwc_to_ncdhw(conv_cl(self.quant_conv, h), self.quant_conv.out_channels, odt)
             like = torch.empty((self.quant_conv.out_channels, 1, xb.shape[2] // 8, xb.shape[3] // 8), dtype=odt, device=xb.device)
-            moments.append(tp.gather_frames(m_loc, ranges, 1, like))
+            moments.append(tp.gather_frames(m_loc, ranges, 1, like, row_dim=2))
         posterior = DiagonalGaussianDistribution(torch.stack(moments).to(in_dtype))
         if not return_dict:
             return (posterior,)
@@ -307,13 +311,14 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         for _ in range(n_temporal):
             out_ranges = [tp.finer(r) for r in out_ranges]
         y = None
+        r0, r1 = tp.rows(z.shape[2])
         if tp.is_active:
             a, b = ranges[tp.rank]
             with vae_parallel.activate(tp):
-                y = self._decode_local(z[:, a:b], out_dtype, post)
+                y = self._decode_local(z[:, a:b, r0:r1], out_dtype, post)
         s_ = 2 ** (len(self.decoder.up_blocks) - 1)
         like = torch.empty((self.out_channels, 1, z.shape[2] * s_, z.shape[3] * s_), dtype=out_dtype, device=z.device)
-        return tp.gather_frames(y, out_ranges, 1, like)
+        return tp.gather_frames(y, out_ranges, 1, like, row_dim=2)
 
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None, postprocess: bool = False
                ) -> Union[DecoderOutput, Tuple[torch.Tensor]]:

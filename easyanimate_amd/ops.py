@@ -544,6 +544,43 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
 FUSED_GN_STATS = True   # False: always run the separate statistics pass (A/B, tests)
 
 
+def groupnorm_local_sums(x: torch.Tensor, groups: int) -> torch.Tensor:
+    """fp64 [T, groups, 2] = (sum, sum of squares) of x bf16 [T, H, W, C] per frame and group over THIS tensor's voxels: the
+    additive half of the GroupNorm statistics (a spatially split VAE all-reduces it over the ranks that share a frame)."""
+    _dev(x)
+    _chk(x, _BF16, "x")
+    assert x.is_contiguous()
+    T, C = x.shape[0], x.shape[-1]
+    hw = x.numel() // (T * C)
+    nblk = max(1, min(256, hw // 2048))
+    partial = torch.empty((T, nblk, C // 4, 2), dtype=_F32, device=x.device)
+    stats = torch.empty((T, groups, 2), dtype=_F32, device=x.device)
+    _lib.call("ea_groupnorm_stats_bf16", _p(x), _p(partial), _p(stats), T, hw, C, groups, nblk, 1e-6, _stream())
+    return partial.double().sum(1).view(T, groups, C // 4 // groups, 2).sum(2)
+
+
+def groupnorm_stats_from_sums(sums: torch.Tensor, n: int, eps: float) -> torch.Tensor:
+    """(sum, sumsq) fp64 [T, groups, 2] over n elements per (frame, group) -> fp32 [T, groups, 2] = (mean, rstd), the
+    arithmetic of gn_finalize_kernel."""
+    mean = sums[..., 0] / n
+    var = (sums[..., 1] / n - mean * mean).clamp_min(0)
+    return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], -1).to(torch.float32).contiguous()
+
+
+def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                    act: bool = True) -> torch.Tensor:
+    """y = act((x - mean) * rstd * gamma + beta) with given per-(frame, group) statistics fp32 [T, groups, 2]."""
+    _dev(x, stats, gamma, beta)
+    _chk(x, _BF16, "x"); _chk(stats, _F32, "stats"); _chk(gamma, _F32, "gamma"); _chk(beta, _F32, "beta")
+    assert x.is_contiguous() and stats.is_contiguous()
+    T, C = x.shape[0], x.shape[-1]
+    hw = x.numel() // (T * C)
+    assert stats.shape == (T, groups, 2)
+    y = torch.empty_like(x)
+    _lib.call("ea_groupnorm_apply_bf16", _p(x), _p(y), _p(stats), _p(gamma), _p(beta), T, hw, C, groups, int(act), _stream())
+    return y
+
+
 def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(x * scale) per row; x bf16 or fp32 [rows, cols] -> bf16."""
     _dev(x, out)

@@ -63,18 +63,37 @@ def conv_cl(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None
             return y
         return _conv_cl_local(conv, x, res, ups, tdup)
     assert not is_virtual(x) and not is_virtual(res), "virtual clips are not produced under a temporal split"
-    st = conv.stride[0]
+    st, ss = conv.stride[0], conv.stride[1]
+    # ---- time: the left neighbour's last frames in front (none on the first temporal rank)
+    drop = 0
     n = tp.halo_frames(st)
     halo = tp.exchange(x, n)
-    if halo is None:
-        return _conv_cl_local(conv, x, res, ups, tdup)
-    if res is not None:
-        res = torch.cat([res.new_zeros((n,) + tuple(res.shape[1:])), res])
-    y = _conv_cl_local(conv, torch.cat([halo, x]), res, ups, tdup)
-    drop = tp.dropped_outputs(st, n, tdup)
-    out = y[drop:]
+    if halo is not None:
+        if res is not None:
+            res = torch.cat([res.new_zeros((n,) + tuple(res.shape[1:])), res])
+        x = torch.cat([halo, x])
+        drop = tp.dropped_outputs(st, n, tdup)
+    # ---- rows (spatial split): one input row from the neighbours above / below (stride 2: from below only), convolved
+    # with the kernel's own zero padding at the outer edges; the rows this rank owns are kept
+    keep = None
+    if tp.ps > 1:
+        h_loc = x.shape[1]
+        above, below = tp.exchange_rows(x, 0 if ss == 2 else 1, 1)
+        ra = above.shape[1] if above is not None else 0
+        rb = below.shape[1] if below is not None else 0
+        x = torch.cat([t for t in (above, x, below) if t is not None], dim=1)
+        if res is not None:
+            z = lambda r: res.new_zeros((res.shape[0], r) + tuple(res.shape[2:]))
+            res = torch.cat([t for t in (z(ra) if ra else None, res, z(rb) if rb else None) if t is not None], dim=1).contiguous()
+        if ss == 1:
+            f = 2 if ups else 1
+            keep = (f * ra, f * h_loc)
+    y = _conv_cl_local(conv, x.contiguous(), res, ups, tdup)
     fused = getattr(y, "gn_partial", None)
-    if fused is not None:   # the per-frame partial sums of the retained frames
+    out = y[drop:]
+    if keep is not None:
+        out = out[:, keep[0]:keep[0] + keep[1]].contiguous()      # the fused statistics covered the halo rows: dropped
+    elif fused is not None and tp.ps == 1:   # the per-frame partial sums of the retained frames
         partial, nblk = fused
         out.gn_partial = (partial.view(-1)[drop * nblk * (y.shape[-1] // 4) * 2:], nblk)
     return out
@@ -159,6 +178,14 @@ class CausalConv3d(nn.Conv3d):
 
 def _gn(norm: nn.GroupNorm, x: torch.Tensor, act: bool) -> torch.Tensor:
     """Per-frame GroupNorm: a virtual clip is normalised on its physical frames (duplicated frames have equal statistics)."""
+    from . import vae_parallel
+    tp = vae_parallel.current()
+    if tp is not None and tp.ps > 1:
+        # spatial split: the statistics are over the WHOLE frame -- all-reduce the additive half over the frame's ranks
+        sums = tp.all_reduce_rows(ops.groupnorm_local_sums(x, norm.num_groups))
+        n = (x.numel() // (x.shape[0] * x.shape[-1])) * tp.ps * (x.shape[-1] // norm.num_groups)
+        stats = ops.groupnorm_stats_from_sums(sums, n, norm.eps)
+        return ops.groupnorm_apply(x, stats, f32(norm.weight), f32(norm.bias), norm.num_groups, act=act)
     y = ops.groupnorm_silu(x, f32(norm.weight), f32(norm.bias), norm.num_groups, norm.eps, act=act)
     if is_virtual(x):
         y.tvirt = True
@@ -379,12 +406,18 @@ class SpatialAttention(nn.Module):
         # the P.V product runs over K = n keys and the GEMMs want K % 64 == 0 / N % 8 == 0: 576x1008 gives n = 9072, 480x720
         # gives 5400.  Keys / values are then padded to n_pad rows of zeros; the pad columns of the logits are set
         # to -inf before the row softmax (probability exactly 0) and the pad columns of V^T are zero (to_v's bias is folded out).
-        n_pad = ops.round_up(n, 64)
-        if n_pad != n:
+        from . import vae_parallel
+        tp = vae_parallel.current()
+        xa = xn
+        if tp is not None and tp.ps > 1:
+            xa = tp.all_gather_rows(xn, 1)      # spatial split: queries = this rank's rows, keys / values = the whole frame
+        n_keys = xa.shape[1]
+        n_pad = ops.round_up(n_keys, 64)
+        if n_pad != n_keys:
             xk = torch.zeros((T, n_pad, C), dtype=xn.dtype, device=xn.device)
-            xk[:, :n] = xn
+            xk[:, :n_keys] = xa
         else:
-            xk = xn
+            xk = xa
         q = ops.gemm(xn, bf16_weight(self.to_q.weight), f32(self.to_q.bias), ops.EPI_BIAS)
         k = ops.gemm(xk, bf16_weight(self.to_k.weight), f32(self.to_k.bias), ops.EPI_BIAS)
         wv = bf16_weight(self.to_v.weight)
@@ -399,8 +432,8 @@ class SpatialAttention(nn.Module):
         for f in range(T):  # one frame at a time: [n, n] fp32 logits (1 GiB at 1024^2) stay a reusable buffer
             vt = ops.gemm(wv, xk[f], None, ops.EPI_BIAS)                      # V^T [C, n_pad]
             ops.gemm(q[f], k[f], None, ops.EPI_F32_OUT, out=logits)           # Q K^T
-            if n_pad != n:
-                logits[:, n:] = float("-inf")
+            if n_pad != n_keys:
+                logits[:, n_keys:] = float("-inf")
             p = ops.softmax_rows(logits, self.scale)
             o = ops.gemm(p, vt, None, ops.EPI_BIAS)                            # P V  [n, C]
             ops.gemm(o, wo, b_eff, ops.EPI_BIAS_GATE_RES, out=out[f], res=xr[f], gate=ones)

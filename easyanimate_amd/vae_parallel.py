@@ -1,19 +1,33 @@
-"""Exact multi-GPU evaluation of the causal 3-D VAE by a TEMPORAL split (new capability: SURVEY.md 8(f) rank 4; the
-reference decodes on one GPU, and its own spatial tiling -- autoencoder_magvit.py:339-448 -- is not exact).
+"""Exact multi-GPU evaluation of the causal 3-D VAE by a TEMPORAL split, optionally composed with a SPATIAL split (new
+capability: SURVEY.md 8(f) rank 4; the reference decodes on one GPU, and its own spatial tiling -- autoencoder_magvit.py:
+339-448 -- is not exact).
 
-Why time and not space: under the V5 / V5.1 settings GroupNorm is per frame and the mid-block attention is per frame
+Time first: under the V5 / V5.1 settings GroupNorm is per frame and the mid-block attention is per frame
 (common.py:301-305, vaemodules/attention.py:391-423), so the ONLY operators that look across frames are the causal
 3x3x3 convolutions -- and they only look BACKWARDS, by two frames (one for the stride-2 down-samplers).  A rank that owns a
 contiguous range of frames therefore needs, per convolution, the last two (one) input frames of its left neighbour and
 nothing else: no all-reduce of statistics, no K/V exchange, no halo in space.
 
-  * partition: the latent frames [0, T_lat) in contiguous ranges of at least two frames (P' = min(world, T_lat // 2) ranks
-    are active, the rest only join the final gather).  Through a temporal x2 up-sampler a range [a, b) becomes
+  * partition: the latent frames [0, T_lat) in contiguous ranges of at least two frames (P_t = min(world / P_s, T_lat // 2)
+    temporal ranks are active, the rest only join the final gather).  Through a temporal x2 up-sampler a range [a, b) becomes
     [2a-1, 2b-1) (frame 0 is never duplicated, upsamplers.py:146-152), through a stride-2 down-sampler the inverse -- so the
     ranges stay contiguous at every resolution of the encoder and the decoder;
   * per causal convolution: receive the neighbour's last frames (one point-to-point message), prepend them, convolve, drop
     the outputs that belong to the halo (2; 3 under the temporal duplication; 1 for stride 2).  The first rank keeps the
     kernel's replicate padding.  Every retained output sees exactly the inputs it sees in the whole-clip evaluation.
+
+Space second (`spatial` = P_s > 1; world = P_t x P_s, the P_s ranks of a temporal range are consecutive): 13 latent frames
+keep only 6 temporal ranks busy, so an 8-GPU node runs 4 (time) x 2 (rows).  A rank owns H / P_s consecutive rows of its
+frames at every resolution.  Then
+  * every 3x3x3 convolution also exchanges ONE input row with the row neighbours above / below (stride-2 layers: only from
+    below, downsamplers.py:44-46 pad on the high side), convolves the extended slab with the kernel's own zero padding at
+    the outer edges, and keeps the rows it owns (x2 under the folded nearest up-sampling);
+  * GroupNorm (per frame, over the WHOLE frame) all-reduces its additive statistics -- (sum, sum of squares) per frame and
+    group, in fp64 -- over the P_s ranks of the frame, then normalises locally;
+  * the mid-block attention (per frame, one head over all H x W tokens) all-gathers the normalised tokens of the frame over
+    the P_s ranks (at latent resolution: 16 MB per frame at 1024^2) and attends its own rows' queries over all keys.
+Every retained value is computed from exactly the inputs of the whole-clip evaluation; only the fp64 order of the GroupNorm
+sums differs.
 
 Communication and indexing only (no arithmetic): works on any device; covered by gloo tests on CPU tensors
 (tests/test_vae_parallel_cpu.py) and by ranks sharing the one GPU of the test box (tests/test_vae_parallel_gpu.py).
@@ -33,25 +47,45 @@ def current() -> Optional["TemporalParallel"]:
 
 
 class TemporalParallel:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, spatial: int = 1):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.active_ranks = self.world
-        self.messages = 0            # halo messages received (tests / diagnostics)
+        if spatial < 1 or self.world % spatial:
+            raise ValueError(f"the spatial degree ({spatial}) must divide the world size ({self.world})")
+        self.ps = spatial                      # ranks along the rows of a frame
+        self.pt = self.world // spatial        # temporal ranks
+        self.rank_t, self.rank_s = self.rank // spatial, self.rank % spatial
+        self.active_ranks = self.pt            # ACTIVE temporal ranks (set by plan())
+        self.messages = 0            # temporal halo messages received (tests / diagnostics)
+        self.row_messages = 0        # row halo messages received
+        self.row_group = None
+        if spatial > 1:
+            base = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
+            for t in range(self.pt):           # every rank creates every sub-group (collective call)
+                g = dist.new_group([base[t * spatial + i] for i in range(spatial)])
+                if t == self.rank_t:
+                    self.row_group = g
 
     # ---- partition ---------------------------------------------------------------------------------------------
     def plan(self, latent_frames: int) -> List[Tuple[int, int]]:
-        """Latent-frame range [a, b) of every rank; inactive ranks get (T, T)."""
-        p = max(1, min(self.world, latent_frames // 2))
+        """Latent-frame range [a, b) of every WORLD rank (the P_s ranks of a temporal rank share it); inactive ranks get (T, T)."""
+        p = max(1, min(self.pt, latent_frames // 2))
         self.active_ranks = p
         base, extra = divmod(latent_frames, p)
         out, a = [], 0
-        for r in range(self.world):
+        for r in range(self.pt):
             n = (base + (1 if r < extra else 0)) if r < p else 0
-            out.append((a, a + n))
+            out.extend([(a, a + n)] * self.ps)
             a += n
         return out
+
+    def rows(self, H: int, rank_s: Optional[int] = None) -> Tuple[int, int]:
+        """Row range of a spatial rank in a frame of H rows."""
+        if H % self.ps:
+            raise ValueError(f"spatially split VAE: {H} rows do not divide over {self.ps} ranks")
+        r = self.rank_s if rank_s is None else rank_s
+        return r * (H // self.ps), (r + 1) * (H // self.ps)
 
     @staticmethod
     def finer(rng: Tuple[int, int]) -> Tuple[int, int]:
@@ -61,14 +95,14 @@ class TemporalParallel:
 
     @property
     def is_active(self) -> bool:
-        return self.rank < self.active_ranks
+        return self.rank_t < self.active_ranks
 
     # ---- halo exchange -----------------------------------------------------------------------------------------
     def exchange(self, x: torch.Tensor, n: int) -> Optional[torch.Tensor]:
         """Send this rank's last n frames of x [T, ...] to the right neighbour, receive the left neighbour's.
         Returns the received halo [n, ...], or None on the first rank."""
-        send_to = self.rank + 1 if self.rank + 1 < self.active_ranks else None
-        recv_from = self.rank - 1 if self.rank > 0 else None
+        send_to = self.rank + self.ps if self.rank_t + 1 < self.active_ranks else None      # same rows, next frame range
+        recv_from = self.rank - self.ps if self.rank_t > 0 else None
         if x.shape[0] < n and send_to is not None:
             raise ValueError(f"temporal parallel VAE: rank {self.rank} owns {x.shape[0]} frames, fewer than the halo of {n}")
         staged = x.is_cuda and dist.get_backend(self.group) == "gloo"      # gloo moves host tensors (tests on a shared GPU)
@@ -87,6 +121,58 @@ class TemporalParallel:
             return recv.to(x.device) if staged else recv
         return None
 
+    def exchange_rows(self, x: torch.Tensor, n_above: int, n_below: int):
+        """Row halo of x [T, H_loc, W, C]: returns (the upper neighbour's last n_above rows or None, the lower neighbour's
+        first n_below rows or None); sends this rank's last n_above rows down and its first n_below rows up."""
+        if self.ps == 1:
+            return None, None
+        up = self.rank - 1 if self.rank_s > 0 else None
+        down = self.rank + 1 if self.rank_s + 1 < self.ps else None
+        staged = x.is_cuda and dist.get_backend(self.group) == "gloo"
+        dev = "cpu" if staged else x.device
+        ops_, above, below = [], None, None
+        mk = lambda t: t.contiguous().cpu() if staged else t.contiguous()
+        if up is not None and n_below > 0:
+            ops_.append(dist.P2POp(dist.isend, mk(x[:, :n_below]), self._global(up), self.group))
+        if down is not None and n_above > 0:
+            ops_.append(dist.P2POp(dist.isend, mk(x[:, -n_above:]), self._global(down), self.group))
+        if up is not None and n_above > 0:
+            above = torch.empty((x.shape[0], n_above) + tuple(x.shape[2:]), dtype=x.dtype, device=dev)
+            ops_.append(dist.P2POp(dist.irecv, above, self._global(up), self.group))
+        if down is not None and n_below > 0:
+            below = torch.empty((x.shape[0], n_below) + tuple(x.shape[2:]), dtype=x.dtype, device=dev)
+            ops_.append(dist.P2POp(dist.irecv, below, self._global(down), self.group))
+        if ops_:
+            for w in dist.batch_isend_irecv(ops_):
+                w.wait()
+        self.row_messages += (above is not None) + (below is not None)
+        if staged:
+            above = None if above is None else above.to(x.device)
+            below = None if below is None else below.to(x.device)
+        return above, below
+
+    def all_reduce_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum over the P_s ranks that share this rank's frames (GroupNorm statistics)."""
+        if self.ps == 1:
+            return t
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, group=self.row_group)
+            return h.to(t.device)
+        dist.all_reduce(t, group=self.row_group)
+        return t
+
+    def all_gather_rows(self, x: torch.Tensor, dim: int) -> torch.Tensor:
+        """Concatenate the P_s ranks' equally sized slabs along `dim` (tokens of a frame for the mid-block attention)."""
+        if self.ps == 1:
+            return x
+        staged = x.is_cuda and dist.get_backend(self.group) == "gloo"
+        src = x.contiguous().cpu() if staged else x.contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.ps)]
+        dist.all_gather(parts, src, group=self.row_group)
+        out = torch.cat(parts, dim=dim)
+        return out.to(x.device) if staged else out
+
     def _global(self, r: int) -> int:
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
@@ -102,14 +188,19 @@ class TemporalParallel:
         return 2 * halo - 1 if tdup else halo
 
     # ---- gather ------------------------------------------------------------------------------------------------
-    def gather_frames(self, x: Optional[torch.Tensor], ranges: List[Tuple[int, int]], frame_dim: int, like: torch.Tensor) -> torch.Tensor:
-        """Concatenate the ranks' frame ranges along frame_dim on every rank.  x: this rank's frames (None if inactive);
-        `like` gives shape (with any frame count) / dtype / device."""
-        total = ranges[-1][1] if ranges else 0
+    def gather_frames(self, x: Optional[torch.Tensor], ranges: List[Tuple[int, int]], frame_dim: int, like: torch.Tensor,
+                      row_dim: Optional[int] = None) -> torch.Tensor:
+        """Concatenate the ranks' frame ranges along frame_dim (and, under a spatial split, the row slabs along row_dim) on
+        every rank.  x: this rank's block (None if inactive); `like` gives the FULL-frame shape (with any frame count) /
+        dtype / device."""
         total = max(b for _, b in ranges)
         mx = max(b - a for a, b in ranges)
         shape = list(like.shape)
         shape[frame_dim] = mx
+        if self.ps > 1:
+            assert row_dim is not None
+            lo, hi = self.rows(shape[row_dim])
+            shape[row_dim] = hi - lo
         buf = torch.zeros(shape, dtype=like.dtype, device=like.device)
         if x is not None and x.shape[frame_dim] > 0:
             buf.narrow(frame_dim, 0, x.shape[frame_dim]).copy_(x)
@@ -117,6 +208,9 @@ class TemporalParallel:
         src = buf.cpu() if staged else buf
         parts = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(parts, src.contiguous(), group=self.group)
+        if self.ps > 1:   # the P_s consecutive ranks of a temporal range: their row slabs side by side
+            parts = [torch.cat(parts[i:i + self.ps], dim=row_dim) for i in range(0, self.world, self.ps)]
+            ranges = ranges[::self.ps]
         out = torch.cat([p.narrow(frame_dim, 0, b - a) for p, (a, b) in zip(parts, ranges) if b > a], dim=frame_dim)
         assert out.shape[frame_dim] == total
         return out.to(like.device) if staged else out

@@ -114,3 +114,145 @@ def test_partition_and_level_mapping():
     assert f((0, 2)) == (0, 3) and f((2, 4)) == (3, 7) and f(f((2, 4))) == (5, 13) and f(f((0, 13))) == (0, 49)
     assert TemporalParallel.dropped_outputs(1, 2, False) == 2 and TemporalParallel.dropped_outputs(1, 2, True) == 3
     assert TemporalParallel.dropped_outputs(2, 1, False) == 1
+
+
+# ---- space x time: the row split composed with the temporal split (8 GPUs on 13 latent frames = 4 x 2) -------------------
+def _conv_hw(x, w, stride=1, sstride=1, ups=False):
+    """whole-clip causal convolution with the VAE's spatial conventions: pad 1 (stride 1), or pad 0 + one zero row / column on
+    the high side (stride 2, downsamplers.py:44-46); ups = nearest x2 in space first.  x [T, C, H, W]."""
+    xx = x.permute(1, 0, 2, 3)[None]
+    if ups:
+        xx = F.interpolate(xx, scale_factor=(1, 2, 2), mode="nearest")
+    if sstride == 2:
+        xx = F.pad(xx, (0, 1, 0, 1))
+    xx = F.pad(xx, (0, 0, 0, 0, 2, 0), mode="replicate")
+    return F.conv3d(xx, w, stride=(stride, sstride, sstride), padding=(0, 0 if sstride == 2 else 1, 0 if sstride == 2 else 1))[0].permute(1, 0, 2, 3)
+
+
+def _gn(x, groups=2, eps=1e-6):
+    """per-frame GroupNorm, frames first: x [T, C, H, W]"""
+    return F.group_norm(x, groups, eps=eps)
+
+
+def _grid_conv(tp, x, w, stride=1, sstride=1, ups=False, tdup=False):
+    """what vae_modules.conv_cl does under the space x time split (rows = dim 2 here), oracle convolution inside"""
+    n = tp.halo_frames(stride)
+    halo = tp.exchange(x, n)
+    drop = 0
+    if halo is not None:
+        x = torch.cat([halo, x])
+        drop = tp.dropped_outputs(stride, n, tdup)
+    keep = None
+    if tp.ps > 1:
+        h_loc = x.shape[2]
+        xr = x.permute(0, 2, 3, 1)        # exchange_rows works on [T, H, W, C]
+        above, below = tp.exchange_rows(xr, 0 if sstride == 2 else 1, 1)
+        ra = 0 if above is None else above.shape[1]
+        x = torch.cat([t for t in (above, xr, below) if t is not None], dim=1).permute(0, 3, 1, 2)
+        # the oracle pads both outer edges itself; at an INNER edge the halo row takes the pad's place, so the extra output
+        # rows the halo produces are dropped
+        if sstride == 1:
+            f = 2 if ups else 1
+            keep = (f * ra, f * h_loc)
+    y = _conv_hw(x, w, stride, sstride, ups)
+    if tdup:
+        y = _tdup(y)
+    y = y[drop:]
+    if keep is not None:
+        y = y[:, :, keep[0]:keep[0] + keep[1]]
+    elif tp.ps > 1 and sstride == 2:
+        y = y[:, :, :h_loc // 2]
+    return y
+
+
+def _grid_gn(tp, x, groups=2, eps=1e-6):
+    """the statistics half of GroupNorm all-reduced over the ranks of a frame (vae_modules._gn under a spatial split)"""
+    T, C = x.shape[0], x.shape[1]
+    xg = x.reshape(T, groups, -1).double()
+    sums = torch.stack([xg.sum(-1), (xg * xg).sum(-1)], -1)
+    sums = tp.all_reduce_rows(sums)
+    n = xg.shape[-1] * tp.ps
+    mean = sums[..., 0] / n
+    rstd = 1.0 / torch.sqrt((sums[..., 1] / n - mean * mean).clamp_min(0) + eps)
+    return ((xg - mean[..., None]) * rstd[..., None]).reshape(x.shape).to(x.dtype)
+
+
+def _grid_attn(tp, x):
+    """per-frame single-head attention over all H x W tokens: queries = own rows, keys = the all-gathered frame"""
+    T, C, H, W = x.shape
+    tok = x.permute(0, 2, 3, 1).reshape(T, H * W, C)
+    keys = tp.all_gather_rows(tok, 1) if tp is not None else tok
+    o = F.scaled_dot_product_attention(tok, keys, keys)
+    return x + o.reshape(T, H, W, C).permute(0, 3, 1, 2)
+
+
+def _net(conv, gn, attn, x, w, decode):
+    if decode:      # mid attention, then x2 space, x2 space + time (twice), like Decoder
+        x = conv(x, w[0])
+        x = attn(gn(x))
+        x = torch.tanh(gn(conv(x, w[1], ups=True)))
+        x = torch.tanh(gn(conv(x, w[2], ups=True, tdup=True)))
+        x = torch.tanh(gn(conv(x, w[3], ups=True, tdup=True)))
+        return conv(x, w[4])
+    x = torch.tanh(gn(conv(x, w[5])))                       # Encoder: spatial down, two space-time downs, mid attention
+    x = torch.tanh(gn(conv(x, w[6], sstride=2)))
+    x = torch.tanh(gn(conv(x, w[7], stride=2, sstride=2)))
+    x = torch.tanh(gn(conv(x, w[0], stride=2, sstride=2)))
+    x = attn(gn(x))
+    return conv(x, w[1])
+
+
+def _worker_grid(rank, world, port, frames, spatial, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easyanimate_amd.vae_parallel import TemporalParallel
+        w = _weights()
+        g = torch.Generator().manual_seed(11)
+        Hp, Wp = 32, 24
+        video = torch.randn(frames, 4, Hp, Wp, generator=g, dtype=torch.float64)
+        t_lat = (frames - 1) // 4 + 1
+        z = torch.randn(t_lat, 4, Hp // 8, Wp // 8, generator=g, dtype=torch.float64)
+        full_conv = lambda x, ww, stride=1, sstride=1, ups=False, tdup=False: (_tdup(_conv_hw(x, ww, stride, sstride, ups)) if tdup else _conv_hw(x, ww, stride, sstride, ups))
+        ref_e = _net(full_conv, _gn, lambda x: _grid_attn(None, x), video, w, False)
+        ref_d = _net(full_conv, _gn, lambda x: _grid_attn(None, x), z, w, True)
+        assert ref_e.shape == (t_lat, 4, Hp // 8, Wp // 8) and ref_d.shape == (frames, 4, Hp, Wp)
+        tp = TemporalParallel(spatial=spatial)
+        ranges = tp.plan(t_lat)
+        assert len(ranges) == world and ranges[rank] == ranges[(rank // spatial) * spatial]
+        assert tp.active_ranks == min(world // spatial, t_lat // 2) and (tp.rank_t, tp.rank_s) == divmod(rank, spatial)
+        fr = tp.finer(tp.finer(ranges[rank]))
+        conv = lambda x, ww, stride=1, sstride=1, ups=False, tdup=False: _grid_conv(tp, x, ww, stride, sstride, ups, tdup)
+        gn = lambda x: _grid_gn(tp, x)
+        attn = lambda x: _grid_attn(tp, x)
+        e_loc = d_loc = None
+        if tp.is_active:
+            r0, r1 = tp.rows(Hp)
+            e_loc = _net(conv, gn, attn, video[fr[0]:fr[1], :, r0:r1], w, False)
+            l0, l1 = tp.rows(Hp // 8)
+            d_loc = _net(conv, gn, attn, z[ranges[rank][0]:ranges[rank][1], :, l0:l1], w, True)
+            assert e_loc.shape == (ranges[rank][1] - ranges[rank][0], 4, (Hp // 8) // spatial, Wp // 8)
+            assert d_loc.shape == (fr[1] - fr[0], 4, Hp // spatial, Wp)
+        e = tp.gather_frames(e_loc, ranges, 0, ref_e[:1], row_dim=2)
+        d = tp.gather_frames(d_loc, [tp.finer(tp.finer(r)) for r in ranges], 0, ref_d[:1], row_dim=2)
+        ret[rank] = ((e - ref_e).abs().max().item(), (d - ref_d).abs().max().item(), tp.messages, tp.row_messages, tp.active_ranks)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames,spatial", [(2, 9, 2), (4, 17, 2), (8, 49, 2), (4, 9, 4), (6, 25, 2)])
+def test_space_time_split_equals_whole_clip(world, frames, spatial):
+    """8 ranks on 49 frames (13 latent) = 4 temporal ranges x 2 row halves: every rank is active (the pure temporal split
+    keeps 6 of 8 busy).  Exact on the oracle arithmetic up to the fp64 order of the GroupNorm sums."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_grid, args=(world, _free_port(), frames, spatial, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    active = ret[0][4]
+    if (world, frames, spatial) == (8, 49, 2):
+        assert active == 4      # all eight ranks busy
+    for r in range(world):
+        err_e, err_d, msgs, row_msgs, _ = ret[r]
+        assert err_e < 1e-10 and err_d < 1e-10, (r, ret[r])
+        if r // spatial < active:
+            assert row_msgs > 0

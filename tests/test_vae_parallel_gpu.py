@@ -64,3 +64,52 @@ def test_temporal_parallel_vae_equals_single_rank(world, frames):
         # the same) -> expected 0, allowed one bf16 ulp
         assert err_m <= 2 ** -7 * max(1.0, mx) and err_d <= 2 ** -7
     assert ret[0][4] == 0 and ret[1][4] > 20
+
+
+def _worker_grid(rank, world, port, frames, spatial, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easyanimate_amd import AutoencoderKLMagvit
+        from easyanimate_amd.synthetic import synth_state_dict
+        g = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
+        vae = AutoencoderKLMagvit.from_config(g["cfg"])
+        vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+        vae = vae.to(torch.bfloat16).to("cuda:0").eval()
+        gen = torch.Generator().manual_seed(frames)
+        video = (torch.rand(1, 3, frames, 64, 96, generator=gen) * 2 - 1).to("cuda:0").bfloat16()
+        z = torch.randn(1, 16, (frames - 1) // 4 + 1, 8, 12, generator=gen).to("cuda:0").bfloat16()
+        with torch.no_grad():
+            m_ref = vae.encode(video)[0].parameters
+            d_ref = vae.decode(z, postprocess=True)[0]
+            tp = vae.enable_temporal_parallel(spatial=spatial)
+            m = vae.encode(video)[0].parameters
+            d = vae.decode(z, postprocess=True)[0]
+            vae.disable_temporal_parallel()
+        assert m.shape == m_ref.shape and d.shape == d_ref.shape == (1, 3, frames, 64, 96)
+        ret[rank] = ((m.float() - m_ref.float()).abs().max().item(), (d.float() - d_ref.float()).abs().max().item(),
+                     m_ref.float().abs().max().item(), tp.active_ranks, tp.messages, tp.row_messages, (tp.rank_t, tp.rank_s))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames,spatial", [(2, 9, 2), (4, 17, 2), (4, 5, 4), (3, 9, 1)])
+def test_space_time_parallel_vae_equals_single_rank(world, frames, spatial):
+    """The temporal split composed with a spatial (row) split -- 8 GPUs on 13 latent frames run 4 x 2 with every rank busy:
+    one-row halos per 3x3x3 convolution, GroupNorm statistics all-reduced over the ranks of a frame, mid-block attention
+    over the all-gathered tokens of the frame.  Against the single-rank product result."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_grid, args=(world, _free_port(), frames, spatial, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    print(f"[parity] space-time parallel VAE world {world} = {world // spatial} (time) x {spatial} (rows), {frames} frames vs single rank "
+          f"(max |d| moments, frames in [0,1]; active temporal ranks, frame / row halo messages, (rank_t, rank_s)):",
+          {r: tuple(ret[r][i] for i in (0, 1, 3, 4, 5, 6)) for r in range(world)})
+    for r in range(world):
+        err_m, err_d, mx, active, msgs, row_msgs, (rt, rs) = ret[r]
+        assert active == min(world // spatial, ((frames - 1) // 4 + 1) // 2)
+        # identical arithmetic per retained voxel; the GroupNorm sums are combined in another (fp64) order: a rare last-bit
+        # difference of a statistic moves a few outputs by one bf16 ulp
+        assert err_m <= 2 ** -6 * max(1.0, mx) and err_d <= 2 ** -6
+        if spatial > 1 and rt < active:
+            assert row_msgs > 20
