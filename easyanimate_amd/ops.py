@@ -500,10 +500,27 @@ def conv3d_narrow(x: torch.Tensor, wz: torch.Tensor, bias: Optional[torch.Tensor
     _chk(x, _BF16, "x"); _chk(wz, _BF16, "wz")
     assert x.is_contiguous() and x.dim() == 4 and wz.is_contiguous() and wz.shape == (27 * c_out, x.shape[-1])
     T, H, W, Cin = x.shape
-    z = gemm(wz, x.view(T * H * W, Cin), None, EPI_F32_OUT)              # fp32 [27*c_out, voxels]
     y = torch.empty((T, H, W, c_pad), dtype=_BF16, device=x.device)
-    _timed("conv3d", lambda: _lib.call("ea_conv3d_tap_gather_f32", _p(z), _p(bias), _p(y), T, H, W, z.stride(0), c_out, c_pad, _stream()))
+    # the fp32 tap planes cost 27 * c_out * 4 bytes per voxel (16.6 GB at 49 x 1024^2): above NARROW_SCRATCH_BYTES the clip is
+    # processed in frame chunks; a chunk brings the two frames in front of it along (the causal taps look back two frames) and
+    # the outputs of those two are dropped
+    per_frame = H * W * 27 * c_out * 4
+    chunk = T if T * per_frame <= NARROW_SCRATCH_BYTES else max(4, NARROW_SCRATCH_BYTES // per_frame - 2)
+    for a in range(0, T, chunk):
+        b = min(T, a + chunk)
+        lo = max(0, a - 2)
+        xs = x[lo:b]
+        n = b - lo
+        z = gemm(wz, xs.reshape(n * H * W, Cin), None, EPI_F32_OUT)          # fp32 [27*c_out, voxels of the chunk]
+        yc = y if (a == 0 and b == T) else torch.empty((n, H, W, c_pad), dtype=_BF16, device=x.device)
+        _timed("conv3d", lambda: _lib.call("ea_conv3d_tap_gather_f32", _p(z), _p(bias), _p(yc), n, H, W, z.stride(0), c_out, c_pad, _stream()))
+        if yc is not y:
+            y[a:b] = yc[a - lo:]
+        del z
     return y
+
+
+NARROW_SCRATCH_BYTES = 9 << 30   # fp32 scratch bound of conv3d_narrow: 49 x 1024^2 runs as two chunks (8.8 GB instead of 16.6)
 
 
 def im2col3d(x: torch.Tensor, k: int, st: int, ss: int, pad: int, k_pad: int):

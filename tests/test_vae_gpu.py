@@ -632,3 +632,22 @@ def test_vae_decode_virtual_equals_materialised_temporal_duplication():
             finally:
                 vae_modules.VIRTUAL_TDUP = True
         assert a.shape == b.shape == (1, 3, 4 * (fl - 1) + 1, 8 * hw, 8 * hw) and torch.equal(a, b)
+
+
+def test_conv3d_narrow_n_chunked_equals_whole_clip():
+    """conv3d_narrow bounds its fp32 tap-plane scratch by processing frame chunks (each with the two frames in front of it):
+    bit-identical to the whole-clip evaluation, first chunk (causal replicate padding) included."""
+    from easyanimate_amd import ops
+    g = torch.Generator().manual_seed(21)
+    T, H, W, Ci, Co = 11, 16, 24, 128, 3
+    x = _bf(torch.randn(T, H, W, Ci, generator=g)).to(DEV)
+    wz = _bf(torch.randn(27 * Co, Ci, generator=g) / (27 * Ci) ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    whole = ops.conv3d_narrow(x, wz, b, Co, 8)
+    lim = ops.NARROW_SCRATCH_BYTES
+    ops.NARROW_SCRATCH_BYTES = 6 * H * W * 27 * Co * 4        # chunks of four frames (+ two in front)
+    try:
+        chunked = ops.conv3d_narrow(x, wz, b, Co, 8)
+    finally:
+        ops.NARROW_SCRATCH_BYTES = lim
+    assert torch.equal(chunked, whole)
