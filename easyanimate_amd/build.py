@@ -19,6 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # per-file extras: the one-wave-per-SIMD attention kernel keeps its MFMA accumulators in arch VGPRs (they are read by
 # the softmax VALU code every block); without this hipcc parks them in AGPRs and copies ~340 registers per tile.
 FLAGS += os.environ.get("EA_HIPCC_EXTRA", "").split()   # diagnostic builds, e.g. EA_HIPCC_EXTRA=-DEA_GEMM_TIMESTAMPS
+if os.environ.get("EA_BUILD_VARIANTS", "0") not in ("", "0"):
+    # also compile the superseded kernel generations (attention v1, 32x32x16 row-slab conv, four-wave GEMM) as cross-checks
+    FLAGS += ["-DEA_BUILD_VARIANTS=1"]
 # -fno-slp-vectorize: the attention main loop is scheduled by hand in source (fenced groups); the SLP vectoriser would
 # re-pair its adds / packs across the fences' dataflow and spill.
 EXTRA_FLAGS = {"ea_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}

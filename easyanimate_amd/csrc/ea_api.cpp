@@ -5,6 +5,9 @@
 #include <string.h>
 
 #include "../../include/ea_mi355x.h"
+#ifndef EA_BUILD_VARIANTS
+#define EA_BUILD_VARIANTS 0   // see ea_common.h
+#endif
 
 static thread_local char g_err[512] = "no error";
 
@@ -76,11 +79,14 @@ EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
 EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1
 EA_OPTION(attn_variant)   // ea_attention.hip: 1 | 2
 #undef EA_OPTION
+// read-only: was this library built with EA_BUILD_VARIANTS=1 (the cross-check kernel generations are present)?
+int ea_build_variants_get() { return EA_BUILD_VARIANTS; }
+int ea_build_variants_set(int v) { return v == EA_BUILD_VARIANTS ? 0 : -1; }
 namespace {
 struct Option { const char* name; int (*set)(int); int (*get)(); };
 #define EA_OPTION(n) {#n, ea_##n##_set, ea_##n##_get}
 const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(gemm_w4), EA_OPTION(conv_mfma),
-                            EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(attn_variant)};
+                            EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(attn_variant), EA_OPTION(build_variants)};
 #undef EA_OPTION
 const Option* find_option(const char* name) {
     for (const Option& o : g_options)

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
 
 int ea_attn_variant_get() { return g_attn_variant; }
 int ea_attn_variant_set(int v) {
-    if (v != 1 && v != 2 && v != 3) return -1;
+    if (v != 2 && v != 3 && !(v == 1 && EA_BUILD_VARIANTS)) return -1;   // v1 over plain keys: EA_BUILD_VARIANTS=1 libraries only
     g_attn_variant = v;
     return 0;
 }
@@ -427,11 +427,14 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     hipStream_t st = (hipStream_t)stream;
     unsigned short* o16 = (unsigned short*)out;
     f32x4* st4 = reinterpret_cast<f32x4*>(state);
+#if EA_BUILD_VARIANTS
     if (variant == 1) {
         ea_count("attention_v1");
         hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh, kv_end,
                            s_pad, q_begin, q_end, nqb, scale_log2e, 0);
-    } else {
+    } else
+#endif
+    {
         // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
         const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;
         ea_count(variant == 3 && folded ? "attention_v3" : "attention_v2");

@@ -1,5 +1,12 @@
 // Shared device/host helpers for libea_mi355x (gfx950 only; wave = 64 lanes).
 #pragma once
+// EA_BUILD_VARIANTS=1 (python -m easyanimate_amd.build with EA_BUILD_VARIANTS=1 in the environment) also compiles the kernel
+// generations that no product call reaches any more -- attention v1 over plain keys, the 32x32x16 row-slab convolution, the
+// four-wave GEMM experiment -- and lets ea_set_option select them; they exist as bitwise / numerical cross-checks of the
+// kernels that replaced them.  The default library carries one kernel per job.
+#ifndef EA_BUILD_VARIANTS
+#define EA_BUILD_VARIANTS 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -1406,7 +1406,7 @@ __global__ void im2col3d_kernel(const unsigned short* __restrict__ x, unsigned s
 
 int ea_conv_mfma_get() { return g_conv_mfma; }
 int ea_conv_mfma_set(int v) {
-    if (v != 16 && v != 32) return -1;
+    if (v != 16 && !(v == 32 && EA_BUILD_VARIANTS)) return -1;   // the 32x32x16 row-slab kernel: EA_BUILD_VARIANTS=1 libraries only
     g_conv_mfma = v;
     return 0;
 }
@@ -1535,10 +1535,12 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
         const int lds3 = 2 * 34 * 1024 + 2 * bn * 128;
         static bool attr3_done = false;
         if (!attr3_done) {
+#if EA_BUILD_VARIANTS
             (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 128 * 128);
             (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 256 * 128);
             (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 128 * 128);
             (void)hipFuncSetAttribute((const void*)conv3d_cl_row_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 2 * 256 * 128);
+#endif
             attr3_done = true;
         }
         const dim3 g3((unsigned)grid3), b3(512);
@@ -1611,6 +1613,7 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
                 hipLaunchKernelGGL((conv3d_cl_row16_kernel<128, false>), g3, b3, lds3, (hipStream_t)stream, p);
             return ea_check_launch("ea_conv3d_cl_bf16");
         }
+#if EA_BUILD_VARIANTS
         ea_count(bn == 256 ? (ups ? "conv_row32_256_ups" : "conv_row32_256") : (ups ? "conv_row32_128_ups" : "conv_row32_128"));
         if (bn == 256 && ups)
             hipLaunchKernelGGL((conv3d_cl_row_kernel<256, true>), g3, b3, lds3, (hipStream_t)stream, p);
@@ -1621,6 +1624,10 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
         else
             hipLaunchKernelGGL((conv3d_cl_row_kernel<128, false>), g3, b3, lds3, (hipStream_t)stream, p);
         return ea_check_launch("ea_conv3d_cl_bf16");
+#else
+        ea_set_error("ea_conv3d_cl_bf16: the 32x32x16 row-slab kernel is built with EA_BUILD_VARIANTS=1 only");
+        return EA_ERR_ARG;
+#endif
     }
     if (pp) {
         // 512 x 128 when there are enough 512-voxel tiles (or when forced: g_conv_tile == 256 tests every variant by size)

@@ -1210,6 +1210,7 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done[1] = true;
         }
+#if EA_BUILD_VARIANTS
         if (g_gemm_w4 && g_gemm_mfma == 16 && !W8 && EPI != EA_EPI_F32_OUT) {
             static bool attrw4_done = false;
             if (!attrw4_done) {
@@ -1218,7 +1219,9 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             }
             ea_count("gemm_256_w4");
             hipLaunchKernelGGL((gemm256_w4_kernel<EPI>), grid, dim3(256), lds, st, p);
-        } else if ((g_gemm_mfma == 16 || W8) && EPI != EA_EPI_F32_OUT) {
+        } else
+#endif
+        if ((g_gemm_mfma == 16 || W8) && EPI != EA_EPI_F32_OUT) {
             static bool attr16_done = false;
             if (!attr16_done) {
                 hipFuncSetAttribute((const void*)gemm256_mi16_kernel<EPI, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1388,7 +1391,7 @@ int ea_gemm_tile_set(int v) {
 }
 int ea_gemm_w4_get() { return g_gemm_w4; }
 int ea_gemm_w4_set(int v) {
-    if (v != 0 && v != 1) return -1;
+    if (v != 0 && !(v == 1 && EA_BUILD_VARIANTS)) return -1;   // the four-wave kernel exists in EA_BUILD_VARIANTS=1 libraries only
     g_gemm_w4 = v;
     return 0;
 }

@@ -96,27 +96,24 @@ class EasyAnimateAttnProcessor2_0:
             # then resume the online-softmax state over the other ranks' slots where the all-gather left them
             buf = ws["kv"]
             state = _attention_state(B, H, S, dev)
-            own = buf[sp.rank]          # [2, B, H, rows * 64]: one segment
-            for i, (lo, hi) in enumerate(lay.own_ranges):
-                ops.attention_segments(ws["q"], own, 1, -1, lay.rows, hi - lo, 0, S, state=state, load_state=i > 0, store_state=True,
-                                       first_row=lo, used_rows=ops.round_up(hi - lo, 64))
+            for i, (lo, hi) in enumerate(lay.own_ranges):       # the own slot is a plain K / V^T operand (same rows as q)
+                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
+                                    store_state=True)
             sp.exchange_finish(pending)
             if lay.bringup_ranges is not None:
                 # bring-up mode (a world of one rank with force_exchange): the "remote" keys are the second half of its own rows
                 (lo, hi), = lay.bringup_ranges
-                ops.attention_segments(ws["q"], own, 1, -1, lay.rows, hi - lo, 0, S, state=state, load_state=True, out=o,
-                                       first_row=lo, used_rows=ops.round_up(hi - lo, 64))
+                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=True, out=o)
             else:
                 ops.attention_segments(ws["q"], buf, sp.size, sp.rank, lay.rows, lay.remote_valid, 0, S, state=state, load_state=True,
                                        out=o, first_row=lay.t_pad, used_rows=lay.n_loc)
         elif lay is not None:
             # one sequence rank (CFG split only): the own slot is all there is
-            own = ws["kv"][sp.rank]
             state = _attention_state(B, H, S, dev) if len(lay.own_ranges) > 1 else None
             for i, (lo, hi) in enumerate(lay.own_ranges):
                 last = i == len(lay.own_ranges) - 1
-                ops.attention_segments(ws["q"], own, 1, -1, lay.rows, hi - lo, 0, S, state=state, load_state=i > 0,
-                                       store_state=not last, out=o if last else None, first_row=lo, used_rows=ops.round_up(hi - lo, 64))
+                ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
+                                    store_state=not last, out=o if last else None)
         elif v_off != T:
             # single GPU with unaligned text: rows [T, v_off) are padding between the two key ranges
             state = _attention_state(B, H, S, dev)

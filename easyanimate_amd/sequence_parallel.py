@@ -57,8 +57,8 @@ class Layout:
     t_pad: int         # first shard row = round_up(T, 64): key ranges must start on a multiple of 64
     n_own: int         # valid rows of the own shard
     n_loc: int         # shard stride
-    rows: int          # rows per (batch, head) of a slot = t_pad + n_loc
-    q_pad: int         # rows of the q workspace (multiple of 256)
+    rows: int          # rows per (batch, head) of a slot = round_up(t_pad + n_loc, 256)
+    q_pad: int         # rows of the q workspace (= rows: q and the own slot's K share one geometry)
     q_end: int         # queries are rows [0, q_end) (text, [alignment gap,] own shard)
     own_ranges: List[Tuple[int, int]]   # key ranges inside the OWN slot: [0, T + n_own) or, if T % 64 != 0, [0, T) and [t_pad, t_pad + n_own)
     remote_valid: int  # keys in the other ranks' shards (all full except possibly the last one in rank order)
@@ -155,7 +155,7 @@ class SequenceParallel:
         assert hi - lo == n_own, "hidden-state shard does not match the plan"
         nl, P = self.n_loc, self.size
         t_pad = _round_up(T, 64)
-        rows = t_pad + nl
+        rows = _round_up(t_pad + nl, 256)     # = the q workspace's rows: the own slot is then a plain [B, H, rows, 64] operand
         last = self.shard_range(P - 1)
         n_last = last[1] - last[0]
         remote_valid = 0 if P == 1 else ((P - 1) * nl if self.rank == P - 1 else (P - 2) * nl + n_last)
@@ -165,7 +165,7 @@ class SequenceParallel:
             # bring-up mode: the second half of the rank's own keys plays the part of the remote shards
             split = (T + n_own) // 2 // 64 * 64
             own, bring = [(0, split)], [(split, T + n_own)]
-        return Layout(T=T, t_pad=t_pad, n_own=n_own, n_loc=nl, rows=rows, q_pad=_round_up(rows, 256), q_end=t_pad + n_own,
+        return Layout(T=T, t_pad=t_pad, n_own=n_own, n_loc=nl, rows=rows, q_pad=rows, q_end=t_pad + n_own,
                       own_ranges=own, remote_valid=remote_valid, bringup_ranges=bring)
 
     def exchanges(self, lay: Layout) -> bool:

@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _needs_variants():
+    """The superseded kernel generations (attention v1, four-wave GEMM, 32x32x16 row-slab conv) are compiled into
+    EA_BUILD_VARIANTS=1 libraries only; their cross-check tests skip on the default library."""
+    from easyanimate_amd import _lib
+    if _lib.get_option("build_variants") != 1:
+        pytest.skip("cross-check kernel generation: build with EA_BUILD_VARIANTS=1")
+
+
 def _ops():
     from easyanimate_amd import ops
     return ops
@@ -514,6 +522,8 @@ def test_attention_extreme_dynamic_range(variant):
     the rescale path: the running max came from the lower key half only, finite until the halves differ by 2^127.)"""
     from easyanimate_amd import _lib
     ops = _ops()
+    if variant == 1:
+        _needs_variants()
     _lib.set_option("attn_variant", variant)
     try:
         B, H, S = 1, 3, 1000
@@ -563,6 +573,8 @@ def test_attention_variants_rescale_paths(variant):
     the defer threshold, and a steady ramp whose cumulated growth crosses the threshold many times."""
     from easyanimate_amd import _lib
     ops = _ops()
+    if variant == 1:
+        _needs_variants()
     _lib.set_option("attn_variant", variant)
     try:
         B, H, S = 1, 3, 1000   # 15 full tiles + a 40-key tail
@@ -593,6 +605,7 @@ def test_attention_v2_matches_v1_large():
     tests; here 130 tiles, ragged tail, 16 heads so every XCD slot is used)."""
     from easyanimate_amd import _lib
     ops = _ops()
+    _needs_variants()
     B, H, S = 1, 16, 8300
     q, k, vt, v = _attn_inputs(B, H, S, 29, scale_q=1.5)
     _lib.set_option("attn_variant", 1)
@@ -917,6 +930,7 @@ def test_gemm_w4_equals_the_eight_wave_kernel(B, M, N, K, epi):
     repeated launches bit-identical (race screen for the one-barrier-per-tile schedule)."""
     from easyanimate_amd import _lib
     ops = _ops()
+    _needs_variants()
     w4_default = _lib.get_option("gemm_w4")
     _lib.set_option("gemm_tile", 256)
     try:

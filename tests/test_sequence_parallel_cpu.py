@@ -69,10 +69,10 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
         lay = sp.layout(T, n)
         nl = sp.n_loc
         vo = lay.t_pad
-        assert vo % 64 == 0 and 0 <= vo - T < 64 and lay.q_end == vo + n and lay.rows == vo + nl and lay.v_off == vo
+        assert vo % 64 == 0 and 0 <= vo - T < 64 and lay.q_end == vo + n and lay.rows >= vo + nl and lay.rows % 256 == 0 and lay.v_off == vo
         assert lay.own_ranges == ([(0, T + n)] if vo == T else [(0, T), (vo, vo + n)])
         assert all(lo % 64 == 0 for lo, _ in lay.own_ranges)
-        assert lay.q_pad % 256 == 0 and lay.q_pad >= lay.rows
+        assert lay.q_pad == lay.rows
         assert lay.remote_valid == n_video - n     # every other token, exactly once
         assert sp.exchanges(lay) == (sp.size > 1)
 
@@ -112,7 +112,7 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
             kr, vtr = sp.slot_views(buf, r)
             assert torch.allclose(kr[:, :, vo:vo + rhi - rlo], k_full[:, :, rlo:rhi], atol=1e-5)
             assert torch.allclose(vtr[:, :, :, vo:vo + rhi - rlo], v_full[:, :, rlo:rhi].transpose(2, 3), atol=1e-5)
-            assert kr[:, :, vo + rhi - rlo:].abs().max().item() == 0 if rhi - rlo < nl else True   # tail of a short shard: zero
+            assert not kr[:, :, vo + rhi - rlo:].any()    # tail of a short shard and the pad to 256 rows: zero
 
         # ---- queries = text rows + own rows; keys = the own slot's ranges, then the shard rows of every other slot
         Ks = [k_own[:, :, lo_:hi_] for lo_, hi_ in lay.own_ranges]

@@ -211,8 +211,8 @@ def test_emulated_rank_runs_the_rank_local_work():
             assert out.shape == ref.shape and torch.isfinite(out.float()).all()
             sp = m.sequence_parallel
             assert sp.axis.cfg_degree == 2 and sp.size == P // 2
-            L = g["cfg"]["num_layers"]   # per block: one pass over the own slot (+ one over the other ranks' slots), all by segment addressing
-            assert cnt.get("attention_v3", 0) == 0 and cnt.get("attention_v3_segments", 0) == (L if sp.size == 1 else 2 * L), (P, r, cnt)
+            L = g["cfg"]["num_layers"]   # per block: one pass over the own slot (+ one over the other ranks' slots by segment addressing)
+            assert cnt.get("attention_v3", 0) == L and cnt.get("attention_v3_segments", 0) == (0 if sp.size == 1 else L), (P, r, cnt)
     m.sequence_parallel = None
 
 

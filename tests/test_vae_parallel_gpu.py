@@ -87,10 +87,16 @@ def _worker_grid(rank, world, port, frames, spatial, ret):
             d = vae.decode(z, postprocess=True)[0]
             vae.disable_temporal_parallel()
         assert m.shape == m_ref.shape and d.shape == d_ref.shape == (1, 3, frames, 64, 96)
-        mse = lambda a, b: ((a.double() - b.double()) ** 2).mean().item()
+        mse = lambda a, b: ((a.double().cpu() - b.double().cpu()) ** 2).mean().item()
+        vs_oracle = (0.0, 0.0)
+        if rank == 0:   # both against the fp32 oracle (CPU restatement of the reference): the split must not be further away
+            from oracle import restatement_vae as RV
+            sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+            o = (RV.vae_decode(sd, z.float().cpu(), 16).clamp(-1, 1) / 2 + 0.5).clamp(0, 1)
+            vs_oracle = (mse(d, o), mse(d_ref, o))
         ret[rank] = ((m.float() - m_ref.float()).abs().max().item(), (d.float() - d_ref.float()).abs().max().item(),
                      m_ref.float().abs().max().item(), tp.active_ranks, tp.messages, tp.row_messages, (tp.rank_t, tp.rank_s),
-                     mse(m, m_ref), mse(d, d_ref), (d != d_ref).float().mean().item())
+                     mse(m, m_ref), mse(d, d_ref), (d != d_ref).float().mean().item(), vs_oracle)
     finally:
         dist.destroy_process_group()
 
@@ -107,15 +113,23 @@ def test_space_time_parallel_vae_equals_single_rank(world, frames, spatial):
     print(f"[parity] space-time parallel VAE world {world} = {world // spatial} (time) x {spatial} (rows), {frames} frames vs single rank "
           f"(max |d| moments, frames in [0,1]; active temporal ranks, frame / row halo messages, (rank_t, rank_s)):",
           {r: tuple(ret[r][i] for i in (0, 1, 3, 4, 5, 6)) for r in range(world)},
-          f"| MSE moments {ret[0][7]:.3e}, frames {ret[0][8]:.3e}; {ret[0][9] * 100:.2f} % of the decoded values differ")
+          f"| MSE moments {ret[0][7]:.3e}, frames {ret[0][8]:.3e}; {ret[0][9] * 100:.2f} % of the decoded values differ | decoded frames vs "
+          f"the fp32 oracle: split {ret[0][10][0]:.3e}, single rank {ret[0][10][1]:.3e}")
     for r in range(world):
-        err_m, err_d, mx, active, msgs, row_msgs, (rt, rs), mse_m, mse_d, frac = ret[r]
+        err_m, err_d, mx, active, msgs, row_msgs, (rt, rs), mse_m, mse_d, frac, vs_oracle = ret[r]
         assert active == min(world // spatial, ((frames - 1) // 4 + 1) // 2)
-        # identical arithmetic per retained voxel, but the GroupNorm statistics are summed in another order (per-rank fp32
-        # partial blocks, fp64 across ranks; the single-rank run takes them from the convolution epilogues): a last-bit
-        # difference of (mean, rstd) flips a few activations by one bf16 ulp, which later layers spread thinly.  A wrong or
-        # missing halo row would instead show as O(0.1) errors along the seams: the MSE bound is what separates the two
-        assert mse_m < 1e-6 * max(1.0, mx) ** 2 and mse_d < 1e-6, (mse_m, mse_d)
+        if spatial == 1:
+            assert err_m == 0 and err_d == 0           # the temporal split alone is bit-identical
+            continue
+        # identical arithmetic per retained voxel, but the GroupNorm statistics are summed in another order (fp32 partial sums
+        # over each rank's rows, fp64 across ranks, against one fp32 chain over the whole frame): (mean, rstd) move in their
+        # last digits, which re-rounds activations by one bf16 ulp here and there in every layer -- about 40 % of the decoded
+        # values end up one ulp away (rms 0.003 on [0, 1]).  A wrong or missing halo row would instead show as O(0.1) errors
+        # along the seams (MSE 1e-3): the bounds below separate the two, and the oracle comparison shows the split result
+        # is as close to the reference arithmetic as the single-rank one
+        assert mse_m < 3e-5 * max(1.0, mx) ** 2 and mse_d < 3e-5, (mse_m, mse_d)
         assert err_m <= 0.06 * max(1.0, mx) and err_d <= 0.06
+        if r == 0:
+            assert vs_oracle[0] < 1e-4 and vs_oracle[0] <= 1.25 * vs_oracle[1] + 2e-6, vs_oracle
         if spatial > 1 and rt < active:
             assert row_msgs > 20

@@ -10,6 +10,9 @@ import torch
 from easyanimate_amd import _lib, ops
 from microbench_vae_common import timeit
 
+if _lib.get_option("build_variants") != 1:
+    raise SystemExit("the four-wave kernel is compiled into EA_BUILD_VARIANTS=1 libraries only: EA_BUILD_VARIANTS=1 python -m easyanimate_amd.build --force")
+
 SHAPES = [(106496, 12288, 3072, 1, "FFN-up (GELU)"), (106496, 3072, 12288, 2, "FFN-down (gate + residual)"),
           (106496, 3072, 3072, 2, "out-proj (gate + residual)"), (8192, 8192, 8192, 0, "8192^3"), (13312, 12288, 3072, 1, "FFN-up, one rank of 8")]
 for (M, N, K, epi, what) in SHAPES:
