@@ -213,6 +213,16 @@ def test_emulated_rank_runs_the_rank_local_work():
             assert sp.axis.cfg_degree == 2 and sp.size == P // 2
             L = g["cfg"]["num_layers"]   # per block: one pass over the own slot (+ one over the other ranks' slots by segment addressing)
             assert cnt.get("attention_v3", 0) == L and cnt.get("attention_v3_segments", 0) == (0 if sp.size == 1 else L), (P, r, cnt)
+            if sp.size > 1:   # K | V first, then Q: two launches of the fused kernel per block when the shard allows the fused path
+                assert cnt.get("gemm_qkv_fused_kv_part", 0) == cnt.get("gemm_qkv_fused_q_part", 0)
+        # --emulate-exchange: the all-gather's bytes are moved on a side stream under the own-slot pass; results stay finite
+        # and repeatable (the remote slots are overwritten with the same scratch every block)
+        m.sequence_parallel = EmulatedRank(4, 1)
+        m.sequence_parallel.emulate_exchange = True
+        a = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+        b = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
+        torch.cuda.synchronize()
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
     m.sequence_parallel = None
 
 
