@@ -245,6 +245,7 @@ class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
         super().__init__()
         self.cross_attention_size = cross_attention_size
         self._perm = {}
+        self._maps = None
 
     def _scan_orders(self, F_: int, Hh: int, Ww: int, heads: int, dev):
         key = (F_, Hh, Ww, heads, str(dev))
@@ -263,38 +264,52 @@ class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
         if F_ is None or F_ * Hh * Ww != N:
             raise ValueError("EasyAnimateSWAttnProcessor2_0 needs num_frames / height / width of the token grid")
         S = T + N
-        # ---- cross pass
+        # ---- cross pass: the text keys + every interval-th video key, gathered into ONE small segment ([2, B, Hl, rows * 64]:
+        # K rows, then V^T columns) that ea_attention_fwd_segments_bf16 reads with its own geometry -- no full-size zero-filled
+        # copies of k / v^T (1.3 GB of fills and 0.2 GB of gathers per block at config-3 size in the first version)
         interval = max(N // (self.cross_attention_size - T), 1)
         idx = torch.cat([torch.arange(T, device=dev), T + torch.arange(0, N, interval, device=dev)])
-        kc, vtc = torch.zeros_like(k), torch.zeros_like(vt)
-        kc[:, :, :idx.numel()] = k[:, :, idx]
-        vtc[:, :, :, :idx.numel()] = vt[:, :, :, idx]
+        nc = idx.numel()
+        rows_c = ops.round_up(nc, 64)
+        seg = torch.zeros(2, B, Hl, rows_c * 64, dtype=torch.bfloat16, device=dev)
+        seg[0].view(B, Hl, rows_c, 64)[:, :, :nc] = k[:, :, idx]
+        seg[1].view(B, Hl, 64, rows_c)[:, :, :, :nc] = vt[:, :, :, idx]
         cross = torch.empty(B, S, Hl * 64, dtype=torch.bfloat16, device=dev)
-        ops.attention_range(q, kc, vtc, ops.FOLDED_ATTN_SCALE, 0, S, 0, idx.numel(), out=cross)
-        # ---- window pass over the re-ordered video tokens
+        ops.attention_segments(q, seg, 1, -1, rows_c, nc, 0, S, out=cross)
+        # ---- window pass over the re-ordered video tokens: ONE gather per operand with a per-head row map (the six scan
+        # orders side by side), not one per head group
         n_pad = ops.round_up(N, 256)
-        qp = torch.zeros(B, Hl, n_pad, 64, dtype=torch.bfloat16, device=dev)
-        kp = torch.zeros_like(qp)
-        vtp = torch.zeros(B, Hl, 64, n_pad, dtype=torch.bfloat16, device=dev)
-        orders = []
-        for hs, src in self._scan_orders(F_, Hh, Ww, H_total, dev):   # head groups are defined over ALL heads (:400-417)
-            hs = hs[(hs >= head0) & (hs < head0 + Hl)] - head0
-            if hs.numel():
-                orders.append((hs, src))
-        for hs, src in orders:
-            rows = T + src
-            qp[:, hs, :N] = q[:, hs][:, :, rows]
-            kp[:, hs, :N] = k[:, hs][:, :, rows]
-            vtp[:, hs, :, :N] = vt[:, hs][:, :, :, rows]
+        hmap, inv = self._head_maps(F_, Hh, Ww, H_total, head0, Hl, dev)          # [Hl, N]: scan position -> token, token -> scan position
+        hh = torch.arange(Hl, device=dev)[:, None]
+        qp = torch.empty(B, Hl, n_pad, 64, dtype=torch.bfloat16, device=dev)
+        kp = torch.empty_like(qp)
+        vtp = torch.empty(B, Hl, 64, n_pad, dtype=torch.bfloat16, device=dev)
+        qp[:, :, :N] = q[:, hh, T + hmap]
+        kp[:, :, :N] = k[:, hh, T + hmap]
+        vtp[:, :, :, :N] = vt[:, :, :, T:T + N].gather(3, hmap[None, :, None, :].expand(B, Hl, 64, N))
+        if n_pad != N:      # rows behind the sequence: masked as keys, but V^T must be finite there
+            qp[:, :, N:].zero_(); kp[:, :, N:].zero_(); vtp[:, :, :, N:].zero_()
         win = ops.attention_window(qp, kp, vtp, N, Hh * Ww, ops.FOLDED_ATTN_SCALE).view(B, N, Hl, 64)
-        back = torch.empty_like(win)
-        for hs, src in orders:
-            back[:, src[:, None], hs[None, :]] = win[:, :, hs]
+        back = win.transpose(1, 2)[:, hh, inv].transpose(1, 2)        # [B, N, Hl, 64] in (f h w) order again
         # ---- text rows: cross + cross; video rows: window + cross
         o = torch.empty(B, S, Hl * 64, dtype=torch.bfloat16, device=dev)
         o[:, :T] = ops.bf16_add_(cross[:, :T].contiguous(), cross[:, :T].contiguous())
-        o[:, T:] = ops.bf16_add_(back.view(B, N, Hl * 64), cross[:, T:].contiguous())
+        o[:, T:] = ops.bf16_add_(back.reshape(B, N, Hl * 64).contiguous(), cross[:, T:].contiguous())
         return o
+
+    def _head_maps(self, F_, Hh, Ww, H_total, head0, Hl, dev):
+        key = (F_, Hh, Ww, H_total, head0, Hl, str(dev))
+        if self._maps is None or self._maps[0] != key:
+            N = F_ * Hh * Ww
+            hmap = torch.empty(Hl, N, dtype=torch.long, device=dev)
+            for hs, src in self._scan_orders(F_, Hh, Ww, H_total, dev):   # head groups are defined over ALL heads (:400-417)
+                loc = hs[(hs >= head0) & (hs < head0 + Hl)] - head0
+                if loc.numel():
+                    hmap[loc] = src
+            inv = torch.empty_like(hmap)
+            inv.scatter_(1, hmap, torch.arange(N, device=dev)[None].expand(Hl, N))
+            self._maps = (key, hmap, inv)
+        return self._maps[1], self._maps[2]
 
     def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid, pending=None):
         if sp is None:
