@@ -221,3 +221,35 @@ def test_inpaint_pipeline_branches():
 def pipe_resize(mask, latent):
     from easyanimate_amd.pipeline import resize_mask
     return resize_mask(mask, latent, True)
+
+
+def test_t2v_pipeline_with_fp8_stored_transformer():
+    """predict_t2v.py's default GPU_memory_mode hands the pipeline a transformer whose every parameter is
+    float8_e4m3fn.  `transformer.dtype` is then a storage type: the pipeline must embed / sample / step in the VAE's (text
+    encoder's) bf16 -- `compute_dtype` -- and its result must equal the run of a transformer that holds the same
+    fp8-representable values in bf16, bit for bit (the W8 kernels widen exactly); a `torch.Generator` sampling the latents
+    must work (randn has no fp8 kernel)."""
+    import copy
+    from easyanimate_amd import EasyAnimatePipeline, FlowMatchEulerDiscreteScheduler
+    m, vae, sd_t, sd_v, cfg_t, cfg_v = _models(16)
+    m8, mq = copy.deepcopy(m), copy.deepcopy(m)
+    for p8, pq in zip(m8.parameters(), mq.parameters()):
+        q = p8.data.to(torch.float8_e4m3fn)
+        p8.data = q                                  # convert_model_weight_to_float8 (predict_t2v.py:266)
+        pq.data = q.to(torch.bfloat16)
+    assert m8.dtype == torch.float8_e4m3fn
+    g = torch.Generator().manual_seed(11)
+    F_, H, W, T, steps, guidance = 5, 64, 64, 7, 3, 6.0
+    pos = torch.randn(1, T, cfg_t["text_embed_dim"], generator=g)
+    neg = torch.randn(1, T, cfg_t["text_embed_dim"], generator=g)
+    outs = []
+    for model in (m8, mq):
+        pipe = EasyAnimatePipeline(vae=vae, transformer=model, scheduler=FlowMatchEulerDiscreteScheduler(shift=1.0))
+        assert pipe.compute_dtype == torch.bfloat16
+        pipe.enable_model_cpu_offload()              # what the script calls in this mode: everything stays resident
+        out = pipe(video_length=F_, height=H, width=W, num_inference_steps=steps, guidance_scale=guidance,
+                   generator=torch.Generator(device="cuda").manual_seed(43), prompt_embeds=pos, negative_prompt_embeds=neg,
+                   output_type="latent")
+        outs.append(out.frames)
+    assert outs[0].shape == (1, 3, F_, H, W) and torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
