@@ -229,6 +229,12 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         self.temporal_parallel = TemporalParallel(group, spatial=spatial)
         return self.temporal_parallel
 
+    def enable_temporal_self_loop(self, group=None, virtual: int = 2):
+        """One-GPU bring-up of the split decode: see vae_parallel.SelfLoopTemporal."""
+        from .vae_parallel import SelfLoopTemporal
+        self.temporal_parallel = SelfLoopTemporal(group, virtual=virtual)
+        return self.temporal_parallel
+
     def disable_temporal_parallel(self):
         self.temporal_parallel = None
 
@@ -311,6 +317,15 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         for _ in range(n_temporal):
             out_ranges = [tp.finer(r) for r in out_ranges]
         y = None
+        if isinstance(tp, vae_parallel.SelfLoopTemporal):
+            # bring-up: this one rank plays the temporal ranks in turn, halos through the group's send / recv to itself
+            parts = []
+            for v in range(tp.active_ranks):
+                tp.enter(v)
+                a, b = ranges[v]
+                with vae_parallel.activate(tp):
+                    parts.append(self._decode_local(z[:, a:b], out_dtype, post))
+            return torch.cat(parts, dim=1)
         r0, r1 = tp.rows(z.shape[2])
         if tp.is_active:
             a, b = ranges[tp.rank]

@@ -216,6 +216,52 @@ class TemporalParallel:
         return out.to(like.device) if staged else out
 
 
+class SelfLoopTemporal(TemporalParallel):
+    """Hardware bring-up on a ONE-GPU box: a world of one rank plays `virtual` temporal ranks one after the other, and every
+    frame halo travels through the process group's point-to-point path as a send + receive TO ITSELF (one batched
+    isend / irecv pair per causal convolution -- with backend "nccl" that is RCCL's ncclSend / ncclRecv on device tensors,
+    no host staging), exactly the call sequence a real neighbour pair issues.  The convolutions of virtual rank v run after
+    those of rank v - 1, which left the tails they would have sent in a queue (same convolution order in both).
+    tests/test_vae_parallel_gpu.py::test_rccl_point_to_point_world_of_one."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, virtual: int = 2):
+        super().__init__(group, spatial=1)
+        if self.world != 1:
+            raise ValueError("SelfLoopTemporal is a world-of-one bring-up mode")
+        self.pt = virtual
+        self.virtual_rank = 0
+        self._tails = []        # tails left by the previous virtual rank, in convolution order
+        self._next = []         # tails this virtual rank leaves for the next one
+        self._cursor = 0
+
+    def plan(self, latent_frames: int) -> List[Tuple[int, int]]:
+        return [r for r in super().plan(latent_frames)]
+
+    def enter(self, v: int) -> None:
+        """Start the pass of virtual rank v (0, 1, ... in order)."""
+        self.virtual_rank = self.rank_t = v
+        self._tails, self._next, self._cursor = self._next, [], 0
+
+    def exchange(self, x: torch.Tensor, n: int) -> Optional[torch.Tensor]:
+        if self.virtual_rank + 1 < self.active_ranks:
+            if x.shape[0] < n:
+                raise ValueError(f"temporal parallel VAE: virtual rank {self.virtual_rank} owns {x.shape[0]} frames, fewer than the halo of {n}")
+            self._next.append(x[-n:].contiguous().clone())
+        if self.virtual_rank == 0:
+            return None
+        tail = self._tails[self._cursor]
+        self._cursor += 1
+        assert tail.shape[0] == n and tuple(tail.shape[1:]) == tuple(x.shape[1:]), "convolution order differs between the virtual ranks"
+        self.messages += 1
+        if dist.get_backend(self.group) == "gloo":
+            return tail.clone()       # gloo has no send-to-self: the CPU test covers the queue bookkeeping only
+        recv = torch.empty_like(tail)
+        me = self._global(0)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, tail, me, self.group), dist.P2POp(dist.irecv, recv, me, self.group)]):
+            w.wait()
+        return recv
+
+
 class activate:
     """Context manager: the convolutions of vae_modules consult `current()` while a split encode / decode runs."""
 

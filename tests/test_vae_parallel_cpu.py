@@ -256,3 +256,39 @@ def test_space_time_split_equals_whole_clip(world, frames, spatial):
         assert err_e < 1e-10 and err_d < 1e-10, (r, ret[r])
         if r // spatial < active:
             assert row_msgs > 0
+
+
+def _worker_self_loop(rank, world, port, frames, virtual, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easyanimate_amd.vae_parallel import SelfLoopTemporal
+        w = _weights()
+        g = torch.Generator().manual_seed(7)
+        t_lat = (frames - 1) // 4 + 1
+        z = torch.randn(t_lat, 4, 6, 5, generator=g, dtype=torch.float64)
+        full = lambda x, ww, s=1, d=False: (_tdup(_conv(x, ww, s)) if d else _conv(x, ww, s))
+        ref_d = _decode(full, z, w)
+        tp = SelfLoopTemporal(virtual=virtual)
+        ranges = tp.plan(t_lat)
+        split = lambda x, ww, s=1, d=False: _split_conv(tp, x, ww, s, d)
+        parts = []
+        for v in range(tp.active_ranks):
+            tp.enter(v)
+            parts.append(_decode(split, z[ranges[v][0]:ranges[v][1]], w))
+        d = torch.cat(parts)
+        ret[rank] = ((d - ref_d).abs().max().item(), tp.messages, tp.active_ranks)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("frames,virtual", [(25, 3), (49, 2), (17, 2)])
+def test_self_loop_bring_up_mode_equals_whole_clip(frames, virtual):
+    """SelfLoopTemporal: one rank plays the temporal ranks in turn; the tails a virtual rank leaves are consumed by the next in
+    convolution order.  (gloo cannot send to itself: here the halo is handed over directly; over RCCL it is a real
+    ncclSend / ncclRecv pair, tests/test_vae_parallel_gpu.py::test_rccl_point_to_point_world_of_one.)"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_self_loop, args=(1, _free_port(), frames, virtual, ret), nprocs=1, join=True)
+    err, msgs, active = ret[0]
+    assert err < 1e-12 and active == virtual and msgs == 4 * (virtual - 1)     # 4 causal convolutions in _decode

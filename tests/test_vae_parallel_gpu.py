@@ -133,3 +133,41 @@ def test_space_time_parallel_vae_equals_single_rank(world, frames, spatial):
             assert vs_oracle[0] < 1e-4 and vs_oracle[0] <= 1.25 * vs_oracle[1] + 2e-6, vs_oracle
         if spatial > 1 and rt < active:
             assert row_msgs > 20
+
+
+def _nccl_p2p_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from easyanimate_amd import AutoencoderKLMagvit
+        from easyanimate_amd.synthetic import synth_state_dict
+        g = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
+        vae = AutoencoderKLMagvit.from_config(g["cfg"])
+        vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+        vae = vae.to(torch.bfloat16).to("cuda:0").eval()
+        z = torch.randn(1, 16, 7, 8, 8, generator=torch.Generator().manual_seed(5)).to("cuda:0").bfloat16()
+        with torch.no_grad():
+            d_ref = vae.decode(z, postprocess=True)[0]
+            tp = vae.enable_temporal_self_loop(virtual=3)
+            assert dist.get_backend() == "nccl"
+            d = vae.decode(z, postprocess=True)[0]
+            vae.disable_temporal_parallel()
+        torch.cuda.synchronize()
+        ret[0] = (torch.equal(d, d_ref), tuple(d.shape), tp.messages, tp.active_ranks)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_point_to_point_world_of_one():
+    """The split decode's frame halos over RCCL's point-to-point path on the MI355X: one rank plays three
+    temporal ranks in turn and every halo is a batched ncclSend + ncclRecv of device tensors to itself -- the call sequence
+    a real neighbour pair issues.  The result must be bit-identical to the whole-clip decode (as the gloo / shared-GPU
+    temporal split is)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_p2p_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    same, shape, msgs, active = ret[0]
+    print(f"[parity] RCCL send / recv to self, 3 virtual temporal ranks, 7 latent frames: bit-identical to the whole-clip decode: {same}; "
+          f"{msgs} halo messages over RCCL")
+    assert same and shape == (1, 3, 25, 64, 64) and active == 3 and msgs >= 40
