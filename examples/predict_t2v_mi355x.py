@@ -152,7 +152,9 @@ def build_pipeline(config_path: str, model_name: str, device: str = "cuda", weig
         pipeline = EasyAnimateInpaintPipeline(**slots)
     else:
         pipeline = EasyAnimatePipeline(**slots)
-    pipeline.to(device)   # instead of enable_model_cpu_offload(): nothing needs to leave HBM
+    # predict_t2v.py:256-273 -- every GPU_memory_mode branch ends in one of these; here they make the models resident
+    # (288 GB of HBM: nothing is offloaded, no hooks)
+    pipeline.enable_model_cpu_offload(device=device)
     coefficients = get_teacache_coefficients(model_name)
     if coefficients is not None and teacache_threshold is not None:
         print(f"Enable TeaCache with threshold: {teacache_threshold}.")

@@ -101,7 +101,7 @@ def _worker_grid(rank, world, port, frames, spatial, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,frames,spatial", [(2, 9, 2), (4, 17, 2), (4, 5, 4), (3, 9, 1)])
+@pytest.mark.parametrize("world,frames,spatial", [(4, 17, 2), (4, 5, 4)])
 def test_space_time_parallel_vae_equals_single_rank(world, frames, spatial):
     """The temporal split composed with a spatial (row) split -- 8 GPUs on 13 latent frames run 4 x 2 with every rank busy:
     one-row halos per 3x3x3 convolution, GroupNorm statistics all-reduced over the ranks of a frame, mid-block attention
