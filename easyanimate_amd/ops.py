@@ -308,6 +308,24 @@ def attention_window(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: in
     return out
 
 
+def attention_d512(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, n_keys: int, scale: float,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Single-head, head_dim 512 flash attention per frame (VAE mid block): q bf16 [T, n_q, 512], k bf16 [T, n_kpad, 512],
+    vt bf16 [T, 512, n_kpad] (V^T) -> bf16 [T, n_q, 512]; keys [0, n_keys) of every frame are attended."""
+    _dev(q, k, vt, out)
+    _chk(q, _BF16, "q"); _chk(k, _BF16, "k"); _chk(vt, _BF16, "vt")
+    T, n_q, D = q.shape
+    n_kpad = k.shape[1]
+    assert D == 512 and k.shape == (T, n_kpad, 512) and vt.shape == (T, 512, n_kpad) and n_kpad % 32 == 0 and 0 < n_keys <= n_kpad
+    assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    if out is None:
+        out = torch.empty_like(q)
+    assert out.shape == q.shape and out.is_contiguous()
+    _timed("attention", lambda: _lib.call("ea_attention_d512_fwd_bf16", _p(q), _p(k), _p(vt), _p(out), T, n_q, n_keys, n_kpad,
+                                          q.stride(0), k.stride(0), vt.stride(0), out.stride(0), float(scale), _stream()))
+    return out
+
+
 def attention_state(B: int, H: int, q_begin: int, q_end: int, device) -> torch.Tensor:
     """fp32 scratch for the resumable attention (ea_attention_state_bytes)."""
     n = _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)

@@ -38,6 +38,7 @@ def _pad_bias(b: Optional[torch.Tensor], n_pad: int) -> Optional[torch.Tensor]:
     return b.contiguous()
 
 
+FLASH_MID_BLOCK = True   # False: mid-block attention as Q K^T GEMM -> fp32 logits -> row softmax -> P V GEMM per frame (A/B, tests)
 VIRTUAL_TDUP = True   # False: SpatialTemporalUpsampler3D materialises its duplicated frames (A/B, tests)
 
 
@@ -428,6 +429,14 @@ class SpatialAttention(nn.Module):
             b_eff = ops.linear_small_m(f32(self.to_v.bias).view(1, -1), wo, b_eff).view(-1)
         ones = derived(self.to_out.bias, "ones", lambda t: torch.ones(1, t.shape[0], dtype=torch.float32, device=t.device))
         out = torch.empty_like(xr)
+        if self.inner_dim == 512 and C == 512 and FLASH_MID_BLOCK:
+            # one flash launch for all frames (ea_attention_d512_fwd_bf16): no [n, n] logits buffer, no softmax pass
+            vt = torch.empty((T, C, n_pad), dtype=xn.dtype, device=xn.device)
+            for f in range(T):
+                ops.gemm(wv, xk[f], None, ops.EPI_BIAS, out=vt[f])                # V^T [C, n_pad] of the frame
+            o = ops.attention_d512(q, k, vt, n_keys, self.scale)
+            ops.gemm(o, wo, b_eff, ops.EPI_BIAS_GATE_RES, out=out, res=xr, gate=ones.expand(T, C))
+            return out.view(T, H, W, C)
         logits = torch.empty((n, n_pad), dtype=torch.float32, device=x.device)
         for f in range(T):  # one frame at a time: [n, n] fp32 logits (1 GiB at 1024^2) stay a reusable buffer
             vt = ops.gemm(wv, xk[f], None, ops.EPI_BIAS)                      # V^T [C, n_pad]

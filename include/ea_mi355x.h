@@ -201,6 +201,19 @@ int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, cons
                                    int seg_rows, int n_seg, int skip_seg, int64_t seg_stride, int seg_first_row,
                                    int seg_used_rows, int kv_valid, float scale, float* state, int flags, void* stream);
 
+/* Single-head, head_dim 512 flash attention of the VAE mid block (vaemodules/attention.py:391-423 SpatialAttention with
+ * attention_processors.py:76-139: per latent frame softmax(Q K^T * scale) V over all H x W tokens of the frame, one head of
+ * 512 channels).  One launch for all frames; no logits buffer.
+ *   q  : bf16 [frames, n_q, 512]      (frame stride q_frame_stride elements; rows are queries)
+ *   k  : bf16 [frames, n_kpad, 512]   (rows >= n_keys are never used as keys: masked)
+ *   vt : bf16 [frames, 512, n_kpad]   (V transposed; columns >= n_keys must be finite)
+ *   out: bf16 [frames, n_q, 512]
+ * n_kpad % 32 == 0, n_keys <= n_kpad.  n_q may differ from n_keys (a spatially split VAE attends its rows' queries over
+ * the whole frame's keys). */
+int ea_attention_d512_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out, int frames, int n_q,
+                               int n_keys, int n_kpad, int64_t q_frame_stride, int64_t k_frame_stride,
+                               int64_t vt_frame_stride, int64_t out_frame_stride, float scale, void* stream);
+
 /* Sliding-window (band) attention of EasyAnimateSWAttnProcessor2_0 (processor.py:420: flash_attn_func(q, k, v,
  * window_size=(w, w)) on the six re-ordered head groups): query row i attends key rows j with |i - j| <= window, rows
  * [0, seq) of q / k / vt (same layouts as ea_attention_fwd_bf16), softmax(QK^T * scale) V.  Only key tiles intersecting

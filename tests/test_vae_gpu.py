@@ -653,3 +653,60 @@ def test_conv3d_narrow_n_chunked_equals_whole_clip():
     finally:
         ops.NARROW_SCRATCH_BYTES = lim
     assert torch.equal(chunked, whole)
+
+
+@pytest.mark.parametrize("T,n_q,n_keys,amp", [(2, 300, 300, 1.0), (1, 1024, 1024, 1.0), (3, 512, 1024, 1.0), (1, 200, 5400, 1.0),
+                                                (2, 640, 640, 6.0)])
+def test_attention_head_dim_512_flash(T, n_q, n_keys, amp):
+    """ea_attention_d512_fwd_bf16 (the VAE mid block's single 512-channel head, vaemodules/attention.py:391-423) against an
+    fp64 softmax(Q K^T / sqrt(512)) V: query / key tails, queries != keys (the spatially split VAE), and -- amp = 6 -- score
+    ranges that move the lazy softmax shift many times (scores spread over +-100 in log2 units)."""
+    from easyanimate_amd import _lib, ops
+    g = torch.Generator().manual_seed(17 + n_q)
+    n_pad = ops.round_up(n_keys, 64)
+    q = _bf(torch.randn(T, n_q, 512, generator=g) * amp)
+    k = torch.zeros(T, n_pad, 512, dtype=torch.bfloat16)
+    k[:, :n_keys] = _bf(torch.randn(T, n_keys, 512, generator=g) * amp)
+    k[:, n_keys:] = 50.0                                   # padded key rows hold garbage: they must be masked, not attended
+    v = _bf(torch.randn(T, n_keys, 512, generator=g))
+    vt = torch.zeros(T, 512, n_pad, dtype=torch.bfloat16)
+    vt[:, :, :n_keys] = v.transpose(1, 2)
+    ref = torch.softmax(q.double() @ k[:, :n_keys].double().transpose(1, 2) * 512 ** -0.5, -1) @ v.double()
+    _lib.reset_counters()
+    out = ops.attention_d512(q.to(DEV), k.to(DEV), vt.to(DEV), n_keys, 512 ** -0.5)
+    out2 = ops.attention_d512(q.to(DEV), k.to(DEV), vt.to(DEV), n_keys, 512 ** -0.5)
+    torch.cuda.synchronize()
+    assert _lib.counters() == {"attention_d512": 2} and torch.equal(out, out2)
+    err, rel = _rep(f"attention head_dim 512 T{T} q{n_q} k{n_keys} amp{amp:g}", out, ref)
+    assert rel < 8e-3
+
+
+def test_mid_block_attention_flash_equals_three_gemm_route():
+    """SpatialAttention at full width (512 channels) through the flash kernel against the Q K^T GEMM -> fp32 logits -> row
+    softmax -> P V GEMM route it replaces (both against fp64 elsewhere): same projections, same residual; the two differ
+    only in where the probabilities are rounded (normalised bf16 P vs bf16 exp with one division at the end)."""
+    from easyanimate_amd import _lib, vae_modules
+    from easyanimate_amd.vae_modules import SpatialAttention
+    torch.manual_seed(3)
+    att = SpatialAttention(512, nheads=1, head_dim=512).to(torch.bfloat16).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in att.parameters():
+            if p_.dim() == 2:
+                p_.copy_(torch.randn_like(p_.float()) * (1.5 / p_.shape[1] ** 0.5))
+    x = torch.randn(2, 20, 24, 512, device=DEV).to(torch.bfloat16)     # n = 480 tokens: padded keys
+    with torch.no_grad():
+        _lib.reset_counters()
+        a = att(x)
+        ca = _lib.counters()
+        vae_modules.FLASH_MID_BLOCK = False
+        try:
+            _lib.reset_counters()
+            b = att(x)
+            cb = _lib.counters()
+        finally:
+            vae_modules.FLASH_MID_BLOCK = True
+    assert ca.get("attention_d512", 0) == 1 and "attention_d512" not in cb
+    d = (a.float() - b.float()).abs()
+    rel = (d.norm() / b.float().norm()).item()
+    print(f"[parity] mid-block attention flash vs three-GEMM route: rel_l2 {rel:.3e}, max {d.max().item():.3e}")
+    assert rel < 4e-3
