@@ -228,6 +228,7 @@ def test_vae_full_width_vs_golden():
     assert c_dec.get("conv_row16_256_ups", 0) >= 1      # the 256-channel up-sampler with folded x2 addressing
     assert c_dec.get("conv_pp_256x256", 0) >= 1         # 256 x 256 ping-pong implicit GEMM
     assert c_enc.get("conv_row16_128", 0) >= 4 and c_enc.get("conv_pp_256x256", 0) >= 1
+    assert c_dec.get("attention_d512", 0) == 1 and c_enc.get("attention_d512", 0) == 1     # mid block: head_dim-512 flash kernel
 
 
 def test_vae_decoder_512_rows_vs_golden():
