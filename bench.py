@@ -188,7 +188,6 @@ def self_launch(n: int) -> int:
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("NCCL_MAX_NCHANNELS", "16")          # see main(): bounds the CUs RCCL's kernels take beside the attention kernel
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
@@ -232,9 +231,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL's all-gather runs beside an attention kernel that keeps two workgroups on every CU: one channel = one
-        # workgroup, so the channel count bounds the CUs taken away from it.  16 (6 % of the chip) is a starting point for a
-        # 4-rank sub-communicator over three xGMI links, NOT a measured optimum (no multi-GPU node was available); override by env
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+        # workgroup, so NCCL_MAX_NCHANNELS bounds the CUs taken away from it.  It is deliberately NOT set here: too few channels
+        # stretch the exchange beyond the own-slot pass that hides it (every exposed ms is paid 48 times per step), too many
+        # cost the attention kernel a few percent for ~2 ms per block -- the asymmetric risk favours RCCL's own default until
+        # a multi-GPU node has measured the knee
         if shared:
             dist.init_process_group("gloo")
         else:
