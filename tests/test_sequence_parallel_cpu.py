@@ -187,3 +187,26 @@ def test_partition_arithmetic():
     sp = Fake(8, 0)
     sp.plan(53248)
     assert sp.n_loc == 6656  # config 3: 6656 tokens / rank
+
+
+def test_exchange_layout_at_config3_size():
+    """The slot layout of the per-block K / V^T exchange at the benchmark's size (N = 53 248 video tokens, T = 256, P = 8 =
+    CFG 2 x sequence 4): 13 312 tokens per rank, slots of 13 568 rows (= the q workspace: the own slot is a plain operand),
+    one own key range, 39 936 remote keys; and with unaligned text / a short last shard."""
+    from easyanimate_amd.sequence_parallel import EmulatedRank
+    for r in range(8):
+        sp = EmulatedRank(8, r)
+        assert sp.begin(2) == (r // 4, r // 4 + 1) and sp.size == 4 and sp.rank == r % 4
+        sp.plan(53248)
+        lo, hi = sp.shard_range()
+        assert (lo, hi) == ((r % 4) * 13312, (r % 4 + 1) * 13312)
+        lay = sp.layout(256, hi - lo)
+        assert (lay.t_pad, lay.rows, lay.q_pad, lay.q_end) == (256, 13568, 13568, 13568)
+        assert lay.own_ranges == [(0, 13568)] and lay.remote_valid == 3 * 13312 and sp.exchanges(lay)
+    sp = EmulatedRank(3, 2, cfg_parallel=False)          # flat split, short last shard, text not a multiple of 64
+    sp.begin(2)
+    sp.plan(1000)
+    lo, hi = sp.shard_range()
+    lay = sp.layout(77, hi - lo)
+    assert sp.n_loc == 384 and (lo, hi) == (768, 1000) and lay.t_pad == 128 and lay.rows == 512
+    assert lay.own_ranges == [(0, 77), (128, 128 + 232)] and lay.remote_valid == 768 and lay.q_end == 360

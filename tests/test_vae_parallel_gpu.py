@@ -49,7 +49,7 @@ def _worker(rank, world, port, frames, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,frames", [(2, 17), (3, 13)])
+@pytest.mark.parametrize("world,frames", [(3, 13)])
 def test_temporal_parallel_vae_equals_single_rank(world, frames):
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -101,7 +101,7 @@ def _worker_grid(rank, world, port, frames, spatial, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,frames,spatial", [(4, 17, 2), (4, 5, 4)])
+@pytest.mark.parametrize("world,frames,spatial", [(4, 17, 2)])   # 2 (time) x 2 (rows); rows-only and 4-way row splits: CPU tests
 def test_space_time_parallel_vae_equals_single_rank(world, frames, spatial):
     """The temporal split composed with a spatial (row) split -- 8 GPUs on 13 latent frames run 4 x 2 with every rank busy:
     one-row halos per 3x3x3 convolution, GroupNorm statistics all-reduced over the ranks of a frame, mid-block attention
