@@ -320,3 +320,17 @@ def test_gemm_weight_keeps_fp8_parameters():
     assert _params.gemm_weight(odd).dtype == torch.bfloat16
     b = torch.nn.Parameter(torch.randn(16, 128).bfloat16(), requires_grad=False)
     assert _params.gemm_weight(b).data_ptr() == b.data_ptr()
+
+
+def test_roofline_table_reproduces_the_survey_totals():
+    """tools/roofline.py regenerates SURVEY 8d's algorithmic work from the module graph: DiT 4.540e15 FLOP per denoise step at
+    config 3, VAE decode 7.50e14 / encode 4.77e14 FLOP at 49 x 1024^2 (the figures every roofline fraction is quoted against)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import roofline
+    c3 = roofline.dit_rows()[0]
+    assert c3[1] == 53248 and c3[2] == 53504 and abs(c3[5] / 4.5403e15 - 1) < 1e-4 and abs(c3[6] - 0.744) < 1e-3
+    rows, n_enc = roofline.vae_rows(49, 1024)
+    enc = sum(r[4] for r in rows[:n_enc])
+    dec = sum(r[4] for r in rows[n_enc:])
+    assert abs(enc / 4.7653e14 - 1) < 1e-3 and abs(dec / 7.4998e14 - 1) < 1e-3
