@@ -47,6 +47,7 @@ PROTOTYPES = {
     "ea_gated_residual_bf16": [_P, _P, _P, _P, _I, _L, _I, _L, _P],
     "ea_conv3d_cl_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_conv3d_cl_stats_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
+    "ea_conv3d_cl_subpixel_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
     "ea_groupnorm_finalize_bf16": [_P, _P, _I, _L, _I, _I, _I, _F, _P],
     "ea_conv3d_tap_gather_f32": [_P, _P, _P, _I, _I, _I, _L, _I, _I, _P],
     "ea_im2col3d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

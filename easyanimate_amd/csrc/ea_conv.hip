@@ -790,10 +790,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
 #ifndef EA_CONV_WIDE_PHASE
 #define EA_CONV_WIDE_PHASE 1   // build-time A/B switch (EA_HIPCC_EXTRA=-DEA_CONV_WIDE_PHASE=0)
 #endif
-template <int BN, bool UPS>
+// SUB (1 / 2): the SUB-PIXEL form of "nearest x2 up-sampling, then 3x3x3 convolution" (upsamplers.py:21-37,123-153).  Output
+// pixel (2i + a, 2j + b) sees only 2 x 2 distinct source pixels -- rows {i-1, i} for a = 0 / {i, i+1} for a = 1, the same for
+// columns -- so each of the four parity classes (a, b) is a 3 x 2 x 2 convolution ON THE SOURCE GRID whose weights are sums of
+// the original taps (vae_modules._pack_subpixel_weight): 12 taps instead of 27, 44 % of the MFMA work.  A workgroup computes
+// 256 source voxels of one source row for ONE class: a = blockIdx.y, b = SUB - 1 (compile time: it selects the two shifted
+// fragment-row sets dw = b, b + 1 of the 258-row slab); the slabs are the (dt, dh') pairs with source row h + a - 1 + dh';
+// the outputs land at voxel (2h + a, 2w + b) of the up-sampled clip.  p.w holds the four classes' packed weights
+// [4][C_out, 12 * C_in] (taps ordered dt, dh', dw'), p.H_out / p.W_out are the up-sampled sizes.
+template <int BN, bool UPS, int SUB = 0>
 __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     // UPS: nearest x2 up-sampling folded into the addressing -- output voxel u reads input voxel u >> 1, so the slab holds
     // the 130 input voxels under the 258 up-sampled ones and two neighbouring lanes share a fragment row
+    static_assert(!(UPS && SUB), "the sub-pixel form works on the source grid");
+    constexpr int NDH = SUB ? 2 : 3, NDW = SUB ? 2 : 3, DW0 = SUB == 2 ? 1 : 0, DWL = DW0 + NDW - 1;   // taps per axis, first / last dw
     constexpr int NPIECE = UPS ? 17 : 33, PPW = UPS ? 3 : 5, NROW = UPS ? 130 : 258, ISTEP = UPS ? 1024 : 2048;
     constexpr int WN = BN / 64, WM = 8 / WN;
     constexpr int MT = 256 / WM / 16, MH = MT / 2;   // 16-voxel MFMA tiles per wave, per phase
@@ -819,11 +829,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         tm = m_lo + idx / p.tiles_n;
         tn = idx % p.tiles_n;
     }
-    const int tiles_w = p.W_out / 256;
+    const int grid_h = SUB ? p.H_in : p.H_out;     // rows / row width of the grid the tiles walk (SUB: the source grid)
+    const int tiles_w = (SUB ? p.W_in : p.W_out) / 256;
     const int w0 = (tm % tiles_w) * 256;
-    const int orow = tm / tiles_w;                 // t_out * H_out + h_out
-    const int h_out = orow % p.H_out, t_out = orow / p.H_out;
+    const int orow = tm / tiles_w;                 // t_out * grid_h + h_out
+    const int h_out = orow % grid_h, t_out = orow / grid_h;
     const int col0 = tn * BN;
+    const int sub_a = SUB ? (int)blockIdx.y : 0;   // row parity class
 
     // ---- this lane's slab rows: piece q = wave*5 + i (q < 33), LDS row r = 8q + lane/8  <->  input voxel w0 - 1 + r.
     // The DMA is buffer-addressed (see the 512-voxel kernel below): descriptor = the slab's input row, a_voff = byte offset
@@ -836,14 +848,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         const int w = (UPS ? (w0 >> 1) : w0) - 1 + r;
         a_voff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ (r & 7)) * 8) * 2 : 0x40000000;
     }
-    const int wk = 27 * p.C_in;
+    const int wk = (SUB ? 12 : 27) * p.C_in;
     int w_voff[WP];       // byte offset of (weight row, source chunk) in this N tile's rows of the packed weights
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
         const int r = (wave * WP + i) * 8 + (lane >> 3), c = lane & 7;
         w_voff[i] = (r * wk + (c ^ (r & 7)) * 8) * 2;
     }
-    const unsigned short* const w_tile = p.w + (int64_t)col0 * wk;
+    // SUB: class (a, b)'s packed weights [C_out, 12 * C_in] are block 2 * a + b of p.w
+    const unsigned short* const w_tile = p.w + (SUB ? (int64_t)(2 * sub_a + (SUB - 1)) * p.C_out * wk : 0) + (int64_t)col0 * wk;
     const int w_bytes = BN * wk * 2, row_bytes = p.W_in * p.C_in * 2;
     char* const dma_a = smem + wave * PPW * 1024;
     char* const dma_w = smem + W_BASE + wave * (WP * 1024);
@@ -877,12 +890,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     const unsigned short* slab_row = p.x;       // input row (ti, hh) of the staged (dt, dh)
     bool slab_ok = false;
     auto set_slab = [&](int dtdh) {
-        const int dt = dtdh / 3, dh = dtdh - dt * 3;
+        const int dt = dtdh / NDH, dh = dtdh - dt * NDH;
         int ti = t_out + dt - 2;
         ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
         ti = p.vin ? (ti + 1) >> 1 : ti;                       // virtual temporal x2
-        const int hu = h_out + dh - 1;                         // row in the (up-sampled) padded input
-        slab_ok = hu >= 0 && hu < p.H_out;                     // wave-uniform (stride 1, pad 1: H_out rows)
+        const int hu = SUB ? h_out + sub_a - 1 + dh : h_out + dh - 1;   // row in the (up-sampled) padded input / SUB: source row
+        slab_ok = hu >= 0 && hu < grid_h;                      // wave-uniform (stride 1, pad 1)
         const int hh = UPS ? hu >> 1 : hu;
         slab_row = p.x + ((int64_t)ti * p.H_in + (slab_ok ? hh : 0)) * p.W_in * p.C_in;
     };
@@ -895,7 +908,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
                 bdma16(slab_row, extent, a_voff[i], cb * (BK * 2), dma_a + sa * A_STAGE + i * 1024);
     };
     auto stage_w = [&](int sw, int dtdh, int cb, int dw) {
-        const int koff = (dtdh * 3 + dw) * p.C_in + cb * BK;
+        const int koff = (dtdh * NDW + (dw - DW0)) * p.C_in + cb * BK;
 #pragma unroll
         for (int i = 0; i < WP; ++i) bdma16(w_tile, w_bytes, w_voff[i], koff * 2, dma_w + sw * W_BYTES + i * 1024);
     };
@@ -916,11 +929,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         }                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                      \
             af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[DW][(KS) >> 1] + (((KS) & 1) * MH + i) * ISTEP)); \
-        if ((KS) == 0 && (DW) == 2 && (HAS_NEXT)) {                                                         \
+        if ((KS) == 0 && (DW) == DWL && (HAS_NEXT)) {                                                       \
             next_slab();                                                                                    \
             stage_a(a_dst, n_cb);                                                                           \
         }                                                                                                   \
-        if ((KS) == 1 && (HAS_NEXT)) stage_w(w_dst, n_dtdh, n_cb, ((DW) + 1) % 3);                          \
+        if ((KS) == 1 && (HAS_NEXT)) stage_w(w_dst, n_dtdh, n_cb, (DW) == DWL ? DW0 : (DW) + 1);            \
         if ((KS) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         __builtin_amdgcn_s_barrier();                                                                       \
@@ -948,11 +961,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
             wf[j] = *reinterpret_cast<const bf16x8*>(smem + (w_k[KS] + j * 2048));                          \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
             af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[DW][KS] + i * ISTEP));                     \
-        if ((KS) == 0 && (DW) == 2 && (HAS_NEXT)) {                                                         \
+        if ((KS) == 0 && (DW) == DWL && (HAS_NEXT)) {                                                       \
             next_slab();                                                                                    \
             stage_a(a_dst, n_cb);                                                                           \
         }                                                                                                   \
-        if ((KS) == 0 && (HAS_NEXT)) stage_w(w_dst, n_dtdh, n_cb, ((DW) + 1) % 3);                          \
+        if ((KS) == 0 && (HAS_NEXT)) stage_w(w_dst, n_dtdh, n_cb, (DW) == DWL ? DW0 : (DW) + 1);            \
         if ((KS) == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         __builtin_amdgcn_s_barrier();                                                                       \
@@ -986,7 +999,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     // ---- prologue: slab (dt,dh) = 0, channel block 0 -> A stage 0; its dw = 0 weights -> W stage 0
     set_slab(0);
     stage_a(0, 0);
-    stage_w(0, 0, 0, 0);
+    stage_w(0, 0, 0, DW0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -994,14 +1007,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);
 
     // one trip = one slab = three tiles (dw = 0, 1, 2); the A stage toggles per slab, the W stage per tile
-    const int nslabs = 9 * cblocks;
+    const int nslabs = 3 * NDH * cblocks;
     int a_step = A_STAGE, w_step = W_BYTES;
     a_dst = 1;
     w_dst = 1;
     for (int sl = 0; sl < nslabs; ++sl) {
-        EA_C3_TILE(0, true)
-        EA_C3_TILE(1, true)
-        EA_C3_TILE(2, sl + 1 < nslabs)
+        if (SUB) {      // two dw' taps: fragment-row sets dw = b, b + 1
+            EA_C3_TILE(DW0, true)
+            EA_C3_TILE(DWL, sl + 1 < nslabs)
+        } else {
+            EA_C3_TILE(0, true)
+            EA_C3_TILE(1, true)
+            EA_C3_TILE(2, sl + 1 < nslabs)
+        }
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw)
 #pragma unroll
@@ -1027,10 +1045,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         if (p.bias) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + col0 + wc * 64 + j * 16 + lq * 4);
         else b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int64_t m_base = (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + lr;
+    // SUB: source voxel (h, w) of class (a, b) is output voxel (2h + a, 2w + b): consecutive M tiles are 32 output voxels apart
+    const int64_t m_base = SUB ? ((int64_t)t_out * p.H_out + 2 * h_out + sub_a) * p.W_out + 2 * (w0 + wr * (MT * 16) + lr) + (SUB - 1)
+                               : (int64_t)orow * p.W_out + w0 + wr * (MT * 16) + lr;
     const int ch0 = col0 + wc * 64 + lq * 4;
     const int64_t e_res = m_base * p.C_out + ch0;              // + i * e_step + j * 16
-    const int64_t e_step = (int64_t)16 * p.C_out;
+    const int64_t e_step = (int64_t)(SUB ? 32 : 16) * p.C_out;
     // virtual residual: logical frame t_out lives in physical frame (t_out + 1) >> 1 of p.res
     const unsigned short* const resp = p.res ? p.res - (p.vres ? (int64_t)(t_out - ((t_out + 1) >> 1)) * frame * p.C_out : 0) : nullptr;
     // with tdup the frame t_out >= 1 is stored twice: frames 2t - 1 and 2t of y
@@ -1077,7 +1097,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         // with tdup the frame t_out >= 1 is stored twice (frames 2t-1 and 2t of y): both get the same partial sums
         const bool dup = p.tdup && t_out >= 1;
         const int64_t f0 = dup ? 2 * (int64_t)t_out - 1 : t_out;
-        const int64_t in_frame = ((int64_t)h_out * tiles_w + (tm % tiles_w)) * WM + wr;
+        // SUB: the four classes of a source row tile write four consecutive blocks (p.gn_nblk counts all of them)
+        const int64_t in_frame = SUB ? ((((int64_t)h_out * tiles_w + (tm % tiles_w)) * 4 + 2 * sub_a + (SUB - 1)) * WM + wr)
+                                     : ((int64_t)h_out * tiles_w + (tm % tiles_w)) * WM + wr;
         const int64_t blk = f0 * p.gn_nblk + in_frame;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1682,6 +1704,52 @@ extern "C" int ea_conv3d_cl_stats_bf16(const ea_bf16* x, const ea_bf16* w, const
                                        int64_t gn_capacity_floats, int* gn_nblk_out, void* stream) {
     return conv3d_cl_impl(x, w, bias, res, y, zeros, T_in, H_in, W_in, C_in, C_out, kt, kh, kw, st, ss, pad, ups, tdup, gn_partial,
                           gn_capacity_floats, gn_nblk_out, stream);
+}
+
+extern "C" int ea_conv3d_cl_subpixel_bf16(const ea_bf16* x, const ea_bf16* w4, const float* bias, ea_bf16* y, int T_in, int H_in,
+                                          int W_in, int C_in, int C_out, int tdup, float* gn_partial, int64_t gn_capacity_floats,
+                                          int* gn_nblk_out, void* stream) {
+    if (gn_nblk_out) *gn_nblk_out = 0;
+    EA_REQUIRE(x && w4 && y, "ea_conv3d_cl_subpixel_bf16: null tensor");
+    EA_REQUIRE(T_in > 0 && H_in > 0 && W_in > 0 && W_in % 256 == 0 && C_in > 0 && C_in % BK == 0 && C_out > 0 && C_out % 256 == 0,
+               "ea_conv3d_cl_subpixel_bf16: needs source rows a multiple of 256 voxels wide, C_in % 64 == 0, C_out % 256 == 0 "
+               "(other shapes: ea_conv3d_cl_bf16 with ups = 1)");
+    EA_REQUIRE((tdup & ~1) == 0, "ea_conv3d_cl_subpixel_bf16: tdup is 0 or 1 (duplicate store)");
+    EA_REQUIRE((((uintptr_t)x | (uintptr_t)w4 | (uintptr_t)y | (uintptr_t)bias) & 15) == 0, "ea_conv3d_cl_subpixel_bf16: pointers must be 16-byte aligned");
+    ConvArgs p;
+    p.x = x; p.w = w4; p.bias = bias; p.res = nullptr; p.y = y; p.zeros = nullptr;
+    p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.C_in = C_in; p.C_out = C_out;
+    p.T_out = T_in; p.H_out = 2 * H_in; p.W_out = 2 * W_in;
+    p.kt = p.kh = p.kw = 3; p.st = p.ss = 1; p.pad = 1; p.ups = 0; p.tdup = tdup; p.vin = 0; p.vres = 0;
+    p.M = (int64_t)p.T_out * H_in * W_in;          // source voxels: the M axis of ONE parity class
+    EA_REQUIRE(p.M < (1ll << 31) && (int64_t)p.T_out * p.H_out * p.W_out < (1ll << 40), "ea_conv3d_cl_subpixel_bf16: clip too large");
+    p.tiles_m = (int)(p.M / 256);
+    p.tiles_n = C_out / 256;
+    const int64_t grid = (int64_t)8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    EA_REQUIRE(grid < (1ll << 31), "ea_conv3d_cl_subpixel_bf16: grid too large");
+    p.gn_partial = nullptr; p.gn_nblk = 0;
+    if (gn_partial) {   // one (sum, sumsq) pair per (frame, source row tile, class, wave row, 4-channel bundle)
+        const int64_t nblk = (int64_t)H_in * (W_in / 256) * 4 * 2;
+        const int64_t frames_y = (tdup && p.T_out > 1) ? 2 * (int64_t)p.T_out - 1 : p.T_out;
+        const int64_t need = frames_y * nblk * (C_out / 4) * 2;
+        if (need <= gn_capacity_floats && nblk < (1 << 30) && ((uintptr_t)gn_partial & 7) == 0) {
+            p.gn_partial = gn_partial;
+            p.gn_nblk = (int)nblk;
+            if (gn_nblk_out) *gn_nblk_out = (int)nblk;
+        }
+    }
+    const int lds = 2 * 34 * 1024 + 2 * 256 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_kernel<256, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_kernel<256, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    ea_count("conv_row16_256_subpixel");
+    const dim3 g((unsigned)grid, 2), b(512);       // blockIdx.y = row parity a; the column parity b is the template instance
+    hipLaunchKernelGGL((conv3d_cl_row16_kernel<256, false, 1>), g, b, lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv3d_cl_row16_kernel<256, false, 2>), g, b, lds, (hipStream_t)stream, p);
+    return ea_check_launch("ea_conv3d_cl_subpixel_bf16");
 }
 
 extern "C" int ea_im2col3d_bf16(const ea_bf16* x, ea_bf16* cols, int T_in, int H_in, int W_in, int C_in, int kt, int kh,

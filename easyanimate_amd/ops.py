@@ -511,6 +511,29 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def conv3d_subpixel(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor], tdup: bool = False) -> torch.Tensor:
+    """Nearest x2 up-sampling + 3x3x3 causal convolution in sub-pixel form (ea_conv3d_cl_subpixel_bf16): x bf16 [T,H,W,Cin]
+    (W % 256 == 0), w4 bf16 [4, Cout, 12*Cin] (vae_modules._pack_subpixel_weight) -> bf16 [T', 2H, 2W, Cout]; leaves the
+    GroupNorm partial sums of its output on the result like conv3d_cl."""
+    _dev(x, w4, bias)
+    _chk(x, _BF16, "x"); _chk(w4, _BF16, "w4")
+    assert x.is_contiguous() and w4.is_contiguous() and x.dim() == 4
+    T, H, W, Cin = x.shape
+    Cout = w4.shape[1]
+    assert w4.shape == (4, Cout, 12 * Cin) and W % 256 == 0 and Cin % 64 == 0 and Cout % 256 == 0
+    dup = int(tdup and T > 1)
+    Ty = 2 * T - 1 if dup else T
+    y = torch.empty((Ty, 2 * H, 2 * W, Cout), dtype=_BF16, device=x.device)
+    cap = Ty * H * (W // 256) * 8 * (Cout // 4) * 2
+    partial = torch.empty(cap, dtype=_F32, device=x.device)
+    nblk = ctypes.c_int(0)
+    _timed("conv3d", lambda: _lib.call("ea_conv3d_cl_subpixel_bf16", _p(x), _p(w4), _p(bias), _p(y), T, H, W, Cin, Cout, dup,
+                                       _p(partial), cap, ctypes.byref(nblk), _stream()))
+    if nblk.value:
+        y.gn_partial = (partial, nblk.value)
+    return y
+
+
 def conv3d_narrow(x: torch.Tensor, wz: torch.Tensor, bias: Optional[torch.Tensor], c_out: int, c_pad: int) -> torch.Tensor:
     """3x3x3 / stride 1 / pad 1 causal convolution with C_out <= 4 as one GEMM (weight rows x voxels, fp32, voxel-minor) + a
     tap-gather pass (ea_conv3d_tap_gather_f32).  x bf16 [T,H,W,Cin]; wz bf16 [27*c_out, Cin] -> bf16 [T,H,W,c_pad]."""

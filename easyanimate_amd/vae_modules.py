@@ -29,6 +29,30 @@ def _pack_conv_weight(w: torch.Tensor, k_pad: Optional[int] = None, n_pad: Optio
     return p.contiguous()
 
 
+def _pack_subpixel_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3, 3] -> bf16 [4, Cout, 12 * Cin]: the four parity classes (a, b) of "nearest x2, then 3x3x3" as 3 x 2 x 2
+    convolutions on the source grid (ea_conv3d_cl_subpixel_bf16).  Output pixel (2i + a, 2j + b) reads up-sampled rows
+    2i + a + {-1, 0, 1} = source rows {i-1, i, i} for a = 0 and {i, i, i+1} for a = 1: row tap 0 / 1 of class a = 0 is the sum of
+    kh {0} / {1, 2}, of a = 1 of kh {0, 1} / {2}; columns likewise.  Summed in fp32, rounded to bf16 once; taps ordered
+    (dt, row tap, column tap), channel-minor."""
+    groups = (((0,), (1, 2)), ((0, 1), (2,)))          # [a][tap] -> original kernel indices
+    wf = w.float()
+    out = []
+    for a in range(2):
+        for b in range(2):
+            taps = []
+            for r in range(2):
+                wr = sum(wf[:, :, :, kh] for kh in groups[a][r])            # [Co, Ci, 3, 3(kw)]
+                for c in range(2):
+                    taps.append(sum(wr[:, :, :, kw] for kw in groups[b][c]))   # [Co, Ci, 3(dt)]
+            m = torch.stack(taps, -1).view(w.shape[0], w.shape[1], 3, 2, 2)      # [Co, Ci, dt, r, c]
+            out.append(m.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1))
+    return torch.stack(out).to(torch.bfloat16).contiguous()
+
+
+SUBPIXEL_UPSAMPLE = True   # False: the up-samplers run as 27-tap convolutions with the x2 folded into the addressing (A/B, tests)
+
+
 def _pad_bias(b: Optional[torch.Tensor], n_pad: int) -> Optional[torch.Tensor]:
     if b is None:
         return None
@@ -134,6 +158,12 @@ def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor]
         wz = derived(conv.weight, "narrow", lambda t: t.permute(2, 3, 4, 0, 1).reshape(27 * co, ci).to(torch.bfloat16).contiguous())
         b = derived(conv.bias, "f32c", lambda t: t.float().contiguous()) if conv.bias is not None else None
         return ops.conv3d_narrow(x, wz, b, co, n_pad)
+    if (SUBPIXEL_UPSAMPLE and ups and kt == 3 and (st, sh, pad) == (1, 1, 1) and res is None and ci % 64 == 0 and co % 256 == 0
+            and x.shape[2] % 256 == 0 and not is_virtual(x)):
+        # nearest x2 + 3x3x3 as four 12-tap parity classes on the source grid: 44 % of the MFMA work
+        w4 = derived(conv.weight, "subpixel", _pack_subpixel_weight)
+        b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None
+        return ops.conv3d_subpixel(x, w4, b, tdup=tdup)
     if ci % 64 == 0:
         w = derived(conv.weight, f"cl{n_pad}", lambda t: _pack_conv_weight(t, None, n_pad))
         b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None

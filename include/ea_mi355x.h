@@ -315,6 +315,21 @@ int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, con
                       const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
                       int kw, int st, int ss, int pad, int ups, int tdup, void* stream);
 
+/* "Nearest x2 spatial up-sampling, then 3x3x3 causal convolution" (SpatialUpsampler3D / SpatialTemporalUpsampler3D,
+ * upsamplers.py:21-37,123-153) in SUB-PIXEL form: output pixel (2i + a, 2j + b) sees only 2 x 2 distinct source pixels, so each
+ * of the four parity classes (a, b) is a 3 x 2 x 2 convolution on the SOURCE grid whose weights are sums of the original
+ * taps -- 12 taps instead of 27 (44 % of the MFMA work of ea_conv3d_cl_bf16 with ups = 1).  The sums are formed in fp32 and
+ * rounded to bf16 once (a rounding point the reference does not have: results agree to bf16 weight-rounding noise, not
+ * bit for bit).
+ *   x  : bf16 [T, H, W, C_in]            W % 256 == 0, C_in % 64 == 0
+ *   w4 : bf16 [4, C_out, 12 * C_in]      class 2a + b; taps ordered (dt, row tap, column tap), channel-minor; row tap 0 / 1 of
+ *                                        class a = 0 is kh {0} / {1,2}, of a = 1 is kh {0,1} / {2}; columns likewise with b
+ *   y  : bf16 [T (or 2T-1 with tdup = 1), 2H, 2W, C_out]   C_out % 256 == 0
+ * gn_partial / gn_capacity_floats / gn_nblk_out: as ea_conv3d_cl_stats_bf16 (NULL / 0 / NULL: no statistics). */
+int ea_conv3d_cl_subpixel_bf16(const ea_bf16* x, const ea_bf16* w4, const float* bias, ea_bf16* y, int T_in, int H_in, int W_in,
+                               int C_in, int C_out, int tdup, float* gn_partial, int64_t gn_capacity_floats, int* gn_nblk_out,
+                               void* stream);
+
 /* ea_conv3d_cl_bf16 that also emits the per-frame GroupNorm statistics of ITS OUTPUT -- what the next layer's
  * GroupNorm (common.py:301-305,318) needs -- from the convolution epilogue, instead of a separate pass over the
  * activation (3.5 % of a 49 x 1024^2 decode).  Deterministic two-level form: the epilogue writes one (sum, sumsq) pair per

@@ -710,3 +710,49 @@ def test_mid_block_attention_flash_equals_three_gemm_route():
     rel = (d.norm() / b.float().norm()).item()
     print(f"[parity] mid-block attention flash vs three-GEMM route: rel_l2 {rel:.3e}, max {d.max().item():.3e}")
     assert rel < 4e-3
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,tdup", [(3, 4, 256, 64, 256, False), (2, 3, 512, 128, 256, True), (1, 2, 256, 256, 512, True),
+                                               (2, 5, 256, 512, 512, False)])
+def test_conv3d_subpixel_upsample(T, H, W, Ci, Co, tdup):
+    """ea_conv3d_cl_subpixel_bf16: "nearest x2, then 3x3x3 causal convolution" as four 12-tap parity classes on the source grid,
+    against the fp64 convolution of the up-sampled clip (borders: the zero padding of the UP-SAMPLED image; frame 0: causal
+    replicate; tdup: duplicate store) and against the 27-tap kernel with the x2 folded into its addressing (they differ by
+    the bf16 rounding of the summed weights only).  The GroupNorm partial sums of the epilogue must give the statistics of
+    the output."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight, _pack_subpixel_weight
+    g = torch.Generator().manual_seed(5 + W + Ci)
+    x = _bf(torch.randn(1, Ci, T, H, W, generator=g))
+    w = _bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    xr = F.interpolate(x.double(), scale_factor=(1, 2, 2), mode="nearest")
+    xr = F.pad(xr, (0, 0, 0, 0, 2, 0), mode="replicate")
+    ref = F.conv3d(xr, w.double(), b.double(), padding=(0, 1, 1))
+    if tdup and T > 1:
+        ref = torch.cat([ref[:, :, :1], F.interpolate(ref[:, :, 1:], scale_factor=(2, 1, 1), mode="nearest")], 2)
+    xcl = x[0].permute(1, 2, 3, 0).contiguous().to(DEV)
+    _lib.reset_counters()
+    y = ops.conv3d_subpixel(xcl, _pack_subpixel_weight(w).to(DEV), b.to(DEV), tdup=tdup)
+    assert _lib.counters() == {"conv_row16_256_subpixel": 1}
+    y2 = ops.conv3d_subpixel(xcl, _pack_subpixel_weight(w).to(DEV), b.to(DEV), tdup=tdup)
+    assert torch.equal(y, y2)
+    got = y.permute(3, 0, 1, 2)[None]
+    assert got.shape == ref.shape
+    err, rel = _rep(f"sub-pixel up-sampling conv T{T} {H}x{W} {Ci}->{Co} tdup{int(tdup)}", got, ref)
+    assert rel < 5e-3
+    y27 = ops.conv3d_cl(xcl, _pack_conv_weight(w).to(DEV), b.to(DEV), 3, 1, 1, 1, ups=True, tdup=tdup)
+    d = (y.float() - y27.float())
+    rel27 = (d.norm() / y27.float().norm()).item()
+    print(f"[parity] sub-pixel vs 27-tap folded kernel: rel_l2 {rel27:.3e}")
+    assert y27.shape == y.shape and rel27 < 5e-3
+    # fused GroupNorm statistics == statistics of the tensor
+    gam, bet = torch.ones(Co, device=DEV), torch.zeros(Co, device=DEV)
+    assert getattr(y, "gn_partial", None) is not None
+    n1 = ops.groupnorm_silu(y, gam, bet, 32, 1e-6, act=False)
+    ops.FUSED_GN_STATS = False
+    try:
+        n2 = ops.groupnorm_silu(y, gam, bet, 32, 1e-6, act=False)
+    finally:
+        ops.FUSED_GN_STATS = True
+    assert (n1.float() - n2.float()).abs().max().item() <= 2 ** -6
