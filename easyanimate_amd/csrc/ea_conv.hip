@@ -37,6 +37,11 @@ struct ConvArgs {
     // frames the up-sampler computed, the LOGICAL input has 2T-1, logical frame f lives in physical frame (f + 1) >> 1;
     // vres -- the same for the residual operand (the block's shortcut, computed on the physical frames)
     int vin, vres;
+    // tmerge (with vin): the three temporal taps of a layer whose input is a virtually duplicated clip collapse to TWO physical
+    // frames -- logical frames (t-2, t-1, t) are physical (p-1, p-1, p) for odd t and (p-1, p, p) for even t, p = (t+1)>>1 -- so
+    // p.w holds two merged-weight classes [2][C_out, 18 * C_in] (even t: {W0, W1+W2}; odd t: {W0+W1, W2}) and the K loop runs
+    // over 2 x 3 x 3 taps: 2/3 of the MFMA work (row-slab kernels only)
+    int tmerge;
     int tiles_m, tiles_n;
     int64_t M;
     float* gn_partial;   // optional (row-slab 16x16x32 kernel): per-(frame, row tile, wave row, 4-channel bundle) (sum, sumsq)
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         const int w = (UPS ? (w0 >> 1) : w0) - 1 + r;
         a_voff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ (r & 7)) * 8) * 2 : 0x40000000;
     }
-    const int wk = (SUB ? 12 : 27) * p.C_in;
+    const int wk = (SUB ? 12 : (p.tmerge ? 18 : 27)) * p.C_in;
     int w_voff[WP];       // byte offset of (weight row, source chunk) in this N tile's rows of the packed weights
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
@@ -856,7 +861,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         w_voff[i] = (r * wk + (c ^ (r & 7)) * 8) * 2;
     }
     // SUB: class (a, b)'s packed weights [C_out, 12 * C_in] are block 2 * a + b of p.w
-    const unsigned short* const w_tile = p.w + (SUB ? (int64_t)(2 * sub_a + (SUB - 1)) * p.C_out * wk : 0) + (int64_t)col0 * wk;
+    const unsigned short* const w_tile = p.w + (SUB ? (int64_t)(2 * sub_a + (SUB - 1)) * p.C_out * wk : 0) +
+                                         (p.tmerge ? (int64_t)(t_out & 1) * p.C_out * wk : 0) + (int64_t)col0 * wk;
     const int w_bytes = BN * wk * 2, row_bytes = p.W_in * p.C_in * 2;
     char* const dma_a = smem + wave * PPW * 1024;
     char* const dma_w = smem + W_BASE + wave * (WP * 1024);
@@ -894,6 +900,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
         int ti = t_out + dt - 2;
         ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
         ti = p.vin ? (ti + 1) >> 1 : ti;                       // virtual temporal x2
+        if (p.tmerge) {                                        // two physical frames (p - 1, p), p = (t_out + 1) >> 1
+            ti = ((t_out + 1) >> 1) - 1 + dt;
+            ti = ti < 0 ? 0 : ti;
+        }
         const int hu = SUB ? h_out + sub_a - 1 + dh : h_out + dh - 1;   // row in the (up-sampled) padded input / SUB: source row
         slab_ok = hu >= 0 && hu < grid_h;                      // wave-uniform (stride 1, pad 1)
         const int hh = UPS ? hu >> 1 : hu;
@@ -1007,7 +1017,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);
 
     // one trip = one slab = three tiles (dw = 0, 1, 2); the A stage toggles per slab, the W stage per tile
-    const int nslabs = 3 * NDH * cblocks;
+    const int nslabs = (p.tmerge ? 2 : 3) * NDH * cblocks;
     int a_step = A_STAGE, w_step = W_BYTES;
     a_dst = 1;
     w_dst = 1;
@@ -1199,14 +1209,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
         const int w = S2 ? (r <= TM ? 2 * (w0 + r) : 2 * (w0 + r - TM - 1) + 1) : w0 - 1 + r;
         a_voff[i] = (q < NPIECE && r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ ((r >> 1) & 3)) * 8) * 2 : 0x40000000;
     }
-    const int wk = 27 * p.C_in;
+    const int wk = (p.tmerge ? 18 : 27) * p.C_in;
     int w_voff[WP];                  // 1 KiB pieces of 16 weight rows, WP per wave
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
         const int r = (wave * WP + i) * 16 + (lane >> 2), c = lane & 3;
         w_voff[i] = (r * wk + (c ^ ((r >> 1) & 3)) * 8) * 2;
     }
-    const unsigned short* const w_tile = p.w + (int64_t)col0 * wk;
+    const unsigned short* const w_tile = p.w + ((!S2 && p.tmerge) ? (int64_t)(t_out & 1) * p.C_out * wk : 0) + (int64_t)col0 * wk;
     const int w_bytes = BN * wk * 2, row_bytes = p.W_in * p.C_in * 2;
     char* const dma_a = smem + wave * PPW * 1024;
     char* const dma_w = smem + W_BASE + wave * (WP * 1024);
@@ -1238,6 +1248,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
         int ti = (S2 ? t_out * p.st : t_out) + dt - 2;
         ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
         ti = p.vin ? (ti + 1) >> 1 : ti;                       // virtual temporal x2
+        if (!S2 && p.tmerge) {                                 // two physical frames (p - 1, p), p = (t_out + 1) >> 1
+            ti = ((t_out + 1) >> 1) - 1 + dt;
+            ti = ti < 0 ? 0 : ti;
+        }
         const int hu = S2 ? 2 * h_out + dh : h_out + dh - 1;   // S2: pad 0, one zero row below the last one
         slab_ok = hu >= 0 && hu < p.H_in;
         slab_row = p.x + ((int64_t)ti * p.H_in + (slab_ok ? hu : 0)) * p.W_in * p.C_in;
@@ -1304,7 +1318,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
     __builtin_amdgcn_sched_barrier(0);
 
     // one trip = one slab = three tiles (dw = 0, 1, 2); the A stage toggles per slab
-    const int nslabs = 9 * cblocks;
+    const int nslabs = (p.tmerge ? 6 : 9) * cblocks;
     int a_step = A_STAGE;
     a_dst = 1;
     for (int sl = 0; sl < nslabs; ++sl) {
@@ -1470,11 +1484,12 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.ss = ss; p.pad = pad; p.ups = ups;
     // tdup flags: 1 = store every output frame but the first twice; 2 = the input's frames are virtually duplicated (x holds
     // T_in physical frames, the convolution sees 2 T_in - 1); 4 = the residual's frames are virtually duplicated
-    EA_REQUIRE((tdup & ~7) == 0, "ea_conv3d_cl_bf16: tdup is a bit set of 1 (duplicate store), 2 (virtual input), 4 (virtual residual)");
-    p.tdup = tdup & 1; p.vin = (tdup >> 1) & 1; p.vres = (tdup >> 2) & 1;
+    EA_REQUIRE((tdup & ~15) == 0, "ea_conv3d_cl_bf16: tdup is a bit set of 1 (duplicate store), 2 (virtual input), 4 (virtual residual), 8 (merged temporal taps)");
+    p.tdup = tdup & 1; p.vin = (tdup >> 1) & 1; p.vres = (tdup >> 2) & 1; p.tmerge = (tdup >> 3) & 1;
     tdup = p.tdup;   // from here on `tdup` is the duplicate-store flag alone (the kernel choice below tests it)
     EA_REQUIRE(!(p.vin && (kt != 3 || st != 1 || C_in == 8)), "ea_conv3d_cl_bf16: virtual input frames need a 3x3x3 temporal-stride-1 layer");
     EA_REQUIRE(!(p.vres && !res), "ea_conv3d_cl_bf16: virtual residual without a residual");
+    EA_REQUIRE(!(p.tmerge && !p.vin), "ea_conv3d_cl_bf16: merged temporal taps are the taps of a virtually duplicated input (bit 2)");
     if (p.vin) T_in = T_in > 1 ? 2 * T_in - 1 : T_in;      // logical frames from here on
     p.T_in = T_in;
     const int He = ups ? 2 * H_in : H_in, We = ups ? 2 * W_in : W_in;
@@ -1549,6 +1564,8 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     // voxels wide
     const bool row_ok = bn != 0 && kt == 3 && st == 1 && ss == 1 && pad == 1 && p.W_out % 256 == 0 && C_in % 64 == 0;
     const bool row_use = row_ok && (g_conv_tile == 1024 || (g_conv_tile == 0 && tiles256 * (C_out / bn) >= 512));
+    EA_REQUIRE(!p.tmerge || (row_use && !ups && g_conv_mfma == 16),
+               "ea_conv3d_cl_bf16: merged temporal taps are served by the 16x16x32 row-slab kernels only (ea_conv3d_cl_tmerge_ok)");
     if (row_use) {
         p.tiles_m = (int)(p.M / 256);
         p.tiles_n = C_out / bn;
@@ -1706,6 +1723,15 @@ extern "C" int ea_conv3d_cl_stats_bf16(const ea_bf16* x, const ea_bf16* w, const
                           gn_capacity_floats, gn_nblk_out, stream);
 }
 
+// Would ea_conv3d_cl_bf16 serve a 3x3x3 / stride 1 / pad 1 layer of this shape with a kernel that supports tdup bit 3 (merged
+// temporal taps)?  Mirrors the kernel choice of conv3d_cl_impl: T_logical = the layer's logical (= output) frame count.
+extern "C" int ea_conv3d_cl_tmerge_ok(int T_logical, int H, int W, int C_in, int C_out) {
+    const int bn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 0);
+    if (bn == 0 || C_in % 64 != 0 || W % 256 != 0 || g_conv_mfma != 16 || T_logical < 2) return 0;
+    const int64_t tiles256 = ((int64_t)T_logical * H * W + 255) / 256;
+    return (g_conv_tile == 1024 || (g_conv_tile == 0 && tiles256 * (C_out / bn) >= 512)) ? 1 : 0;
+}
+
 extern "C" int ea_conv3d_cl_subpixel_bf16(const ea_bf16* x, const ea_bf16* w4, const float* bias, ea_bf16* y, int T_in, int H_in,
                                           int W_in, int C_in, int C_out, int tdup, float* gn_partial, int64_t gn_capacity_floats,
                                           int* gn_nblk_out, void* stream) {
@@ -1720,7 +1746,7 @@ extern "C" int ea_conv3d_cl_subpixel_bf16(const ea_bf16* x, const ea_bf16* w4, c
     p.x = x; p.w = w4; p.bias = bias; p.res = nullptr; p.y = y; p.zeros = nullptr;
     p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.C_in = C_in; p.C_out = C_out;
     p.T_out = T_in; p.H_out = 2 * H_in; p.W_out = 2 * W_in;
-    p.kt = p.kh = p.kw = 3; p.st = p.ss = 1; p.pad = 1; p.ups = 0; p.tdup = tdup; p.vin = 0; p.vres = 0;
+    p.kt = p.kh = p.kw = 3; p.st = p.ss = 1; p.pad = 1; p.ups = 0; p.tdup = tdup; p.vin = 0; p.vres = 0; p.tmerge = 0;
     p.M = (int64_t)p.T_out * H_in * W_in;          // source voxels: the M axis of ONE parity class
     EA_REQUIRE(p.M < (1ll << 31) && (int64_t)p.T_out * p.H_out * p.W_out < (1ll << 40), "ea_conv3d_cl_subpixel_bf16: clip too large");
     p.tiles_m = (int)(p.M / 256);

@@ -474,7 +474,7 @@ def conv_out_shape(T, H, W, k: int, st: int, ss: int, pad: int, ups: bool = Fals
 
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], k: int, st: int = 1, ss: int = 1,
               pad: int = 1, ups: bool = False, tdup: bool = False, res: Optional[torch.Tensor] = None,
-              want_stats: bool = True, vin: bool = False, vres: bool = False) -> torch.Tensor:
+              want_stats: bool = True, vin: bool = False, vres: bool = False, tmerge: bool = False) -> torch.Tensor:
     """x bf16 [T,H,W,Cin] (Cin % 64 == 0), w_packed bf16 [Cout, k^3*Cin] -> bf16 [T',H',W',Cout].
     Cin == 8 (RGB padded to one 16-byte chunk per voxel; k = 3): w_packed [Cout, 256] = 32 tap slots x 8 channels, zero beyond
     tap 26 / the real channels (pack_conv_weight_c8).
@@ -486,15 +486,19 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     _chk(x, _BF16, "x"); _chk(w_packed, _BF16, "w")
     assert x.is_contiguous() and w_packed.is_contiguous() and x.dim() == 4
     T, H, W, Cin = x.shape
-    Cout = w_packed.shape[0]
-    assert w_packed.shape[1] == (256 if Cin == 8 else k * k * k * Cin)
+    if tmerge:      # merged temporal taps (tdup bit 8): w_packed [2, Cout, 18*Cin], see vae_modules._pack_tmerge_weight
+        assert vin and k == 3 and w_packed.dim() == 3 and w_packed.shape[0] == 2 and w_packed.shape[2] == 18 * Cin
+        Cout = w_packed.shape[1]
+    else:
+        Cout = w_packed.shape[0]
+        assert w_packed.shape[1] == (256 if Cin == 8 else k * k * k * Cin)
     Tl = (2 * T - 1 if T > 1 else T) if vin else T          # logical input frames
     To, Ho, Wo = conv_out_shape(Tl, H, W, k, st, ss, pad, ups)
     Ty = 2 * To - 1 if (tdup and To > 1) else To
     y = torch.empty((Ty, Ho, Wo, Cout), dtype=_BF16, device=x.device)
     if res is not None:
         assert res.is_contiguous() and res.shape == ((To + 1) // 2 if vres else To, Ho, Wo, Cout) and res.dtype == _BF16
-    dup = int(tdup and To > 1) | (2 if vin else 0) | (4 if (vres and res is not None) else 0)
+    dup = int(tdup and To > 1) | (2 if vin else 0) | (4 if (vres and res is not None) else 0) | (8 if tmerge else 0)
     if want_stats and k == 3 and ((st, ss, pad) == (1, 1, 1) or (ss == 2 and pad == 0 and not ups)) and Wo % 256 == 0 and Cout % 128 == 0:
         cap = Ty * Ho * (Wo // 256) * 4 * (Cout // 4) * 2       # the largest layout the kernel may choose
         partial = torch.empty(cap, dtype=_F32, device=x.device)
@@ -509,6 +513,11 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                                        _p(_zeros_page(x.device)), T, H, W, Cin, Cout, k, k, k, st, ss, pad, int(ups),
                                        dup, _stream()))
     return y
+
+
+def conv3d_tmerge_ok(T_logical: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    """Does the kernel that will serve this 3x3x3 layer accept merged temporal taps (ea_conv3d_cl_tmerge_ok)?"""
+    return bool(_lib.load().ea_conv3d_cl_tmerge_ok(int(T_logical), int(H), int(W), int(Cin), int(Cout)))
 
 
 def conv3d_subpixel(x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor], tdup: bool = False) -> torch.Tensor:

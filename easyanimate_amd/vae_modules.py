@@ -50,6 +50,21 @@ def _pack_subpixel_weight(w: torch.Tensor) -> torch.Tensor:
     return torch.stack(out).to(torch.bfloat16).contiguous()
 
 
+def _pack_tmerge_weight(w: torch.Tensor, n_pad: int) -> torch.Tensor:
+    """[Cout, Cin, 3, 3, 3] -> bf16 [2, Cout(_pad), 18 * Cin]: the temporal taps of a layer that reads a VIRTUALLY duplicated clip
+    (logical frame f = physical (f + 1) >> 1) merged onto the two physical frames it touches (ea_conv3d_cl_bf16, tdup bit 8):
+    even output frames see physical (p-1, p, p) -> {W_dt0, W_dt1 + W_dt2}, odd ones (p-1, p-1, p) -> {W_dt0 + W_dt1, W_dt2}; frame
+    0 (all three taps on physical frame 0) comes out of the even class with the clamped p - 1.  Summed in fp32, rounded once."""
+    wf = w.float()
+    even = torch.stack([wf[:, :, 0], wf[:, :, 1] + wf[:, :, 2]], 2)      # [Co, Ci, 2, 3, 3]
+    odd = torch.stack([wf[:, :, 0] + wf[:, :, 1], wf[:, :, 2]], 2)
+    out = torch.stack([m.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1) for m in (even, odd)])
+    if n_pad != w.shape[0]:
+        out = torch.nn.functional.pad(out, (0, 0, 0, n_pad - w.shape[0]))
+    return out.to(torch.bfloat16).contiguous()
+
+
+TEMPORAL_TAP_MERGE = True  # False: a layer behind a virtual temporal x2 runs its 27 taps with the frame map in the addressing (A/B, tests)
 SUBPIXEL_UPSAMPLE = True   # False: the up-samplers run as 27-tap convolutions with the x2 folded into the addressing (A/B, tests)
 
 
@@ -167,8 +182,13 @@ def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor]
     if ci % 64 == 0:
         w = derived(conv.weight, f"cl{n_pad}", lambda t: _pack_conv_weight(t, None, n_pad))
         b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None
-        return ops.conv3d_cl(x, w, b, kt, st, sh, pad, ups=ups, tdup=tdup, res=res, vin=is_virtual(x) and kt == 3,
-                             vres=is_virtual(res))
+        vin = is_virtual(x) and kt == 3
+        if (vin and TEMPORAL_TAP_MERGE and (st, sh, pad) == (1, 1, 1) and not ups and not tdup and x.shape[0] > 1
+                and ops.conv3d_tmerge_ok(2 * x.shape[0] - 1, x.shape[1], x.shape[2], ci, n_pad)):
+            # the duplicated frames make two of the three temporal taps coincide: 18 merged taps instead of 27
+            wm = derived(conv.weight, f"tmerge{n_pad}", lambda t: _pack_tmerge_weight(t, n_pad))
+            return ops.conv3d_cl(x, wm, b, kt, st, sh, pad, res=res, vin=True, vres=is_virtual(res), tmerge=True)
+        return ops.conv3d_cl(x, w, b, kt, st, sh, pad, ups=ups, tdup=tdup, res=res, vin=vin, vres=is_virtual(res))
     assert not is_virtual(x) and not is_virtual(res)
     # small C_in: explicit im2col + GEMM
     assert res is None and not ups and not tdup

@@ -308,12 +308,21 @@ int ea_gated_residual_bf16(const ea_bf16* x, const ea_bf16* res, const float* ga
  *   2: the same duplication kept VIRTUAL on the input side: x holds the T_in frames an up-sampler computed, the layer
  *      convolves the 2*T_in-1 logical frames (logical frame f = physical frame (f+1)>>1) -- the duplicated frames are
  *      never written, normalised or read twice from HBM (3x3x3, temporal stride 1 layers);
- *   4: the residual operand is such a virtual clip ((T_out+1)/2 physical frames).
+ *   4: the residual operand is such a virtual clip ((T_out+1)/2 physical frames);
+ *   8: (with 2) MERGED temporal taps: the three temporal taps of a layer that reads a virtually duplicated clip touch only two
+ *      physical frames -- logical (t-2, t-1, t) = physical (p-1, p-1, p) for odd t, (p-1, p, p) for even t, p = (t+1)>>1 -- so
+ *      w is [2, C_out, 18 * C_in]: class 0 (even t) = {W_dt0, W_dt1 + W_dt2}, class 1 (odd t) = {W_dt0 + W_dt1, W_dt2}, summed in
+ *      fp32 and rounded to bf16 once, taps ordered (dt', kh, kw); 2/3 of the MFMA work.  Row-slab shapes only
+ *      (ea_conv3d_cl_tmerge_ok).
  * res (optional, same shape as the un-duplicated output -- or its physical frames with tdup & 4): y = conv + bias + res.
  * zeros: any device buffer holding >= 128 zero bytes (source of the spatial zero padding). */
 int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
                       const ea_bf16* zeros, int T_in, int H_in, int W_in, int C_in, int C_out, int kt, int kh,
                       int kw, int st, int ss, int pad, int ups, int tdup, void* stream);
+
+/* 1 if ea_conv3d_cl_bf16 serves a 3x3x3 / stride 1 / pad 1 layer of this shape (T_logical output frames) with a kernel that
+ * accepts tdup bit 8 (merged temporal taps), else 0. */
+int ea_conv3d_cl_tmerge_ok(int T_logical, int H, int W, int C_in, int C_out);
 
 /* "Nearest x2 spatial up-sampling, then 3x3x3 causal convolution" (SpatialUpsampler3D / SpatialTemporalUpsampler3D,
  * upsamplers.py:21-37,123-153) in SUB-PIXEL form: output pixel (2i + a, 2j + b) sees only 2 x 2 distinct source pixels, so each

@@ -756,3 +756,41 @@ def test_conv3d_subpixel_upsample(T, H, W, Ci, Co, tdup):
     finally:
         ops.FUSED_GN_STATS = True
     assert (n1.float() - n2.float()).abs().max().item() <= 2 ** -6
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,kern", [(4, 4, 256, 128, 256, "conv_row16_256"), (3, 3, 512, 256, 128, "conv_row16_m512"),
+                                               (2, 2, 512, 64, 128, "conv_row16_m512"), (3, 2, 256, 64, 128, "conv_row16_128")])
+def test_conv3d_merged_temporal_taps(T, H, W, Ci, Co, kern):
+    """tdup bit 8: a 3x3x3 layer behind a virtual temporal x2 with its temporal taps merged onto the two physical frames it
+    touches (18 taps), against the fp64 convolution of the materialised clip and against the 27-tap kernel with the frame map
+    in its addressing (they differ by the bf16 rounding of the summed weights only); with a virtual residual; frame 0 (all
+    three taps on one frame) included."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight, _pack_tmerge_weight
+    g = torch.Generator().manual_seed(41 + W + Ci)
+    u = _bf(torch.randn(T, H, W, Ci, generator=g))
+    w = _bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    r = _bf(torch.randn(T, H, W, Co, generator=g))
+    idx = (torch.arange(2 * T - 1) + 1) >> 1
+    xm = u[idx].permute(3, 0, 1, 2)[None].double()
+    ref = F.conv3d(F.pad(xm, (0, 0, 0, 0, 2, 0), mode="replicate"), w.double(), b.double(), padding=(0, 1, 1))
+    ref = ref + r[idx].permute(3, 0, 1, 2)[None].double()
+    _lib.set_option("conv_tile", 1024)
+    try:
+        assert ops.conv3d_tmerge_ok(2 * T - 1, H, W, Ci, Co)
+        _lib.reset_counters()
+        y = ops.conv3d_cl(u.to(DEV), _pack_tmerge_weight(w, Co).to(DEV), b.to(DEV), 3, 1, 1, 1, res=r.to(DEV), vin=True, vres=True, tmerge=True)
+        c = _lib.counters()
+        y2 = ops.conv3d_cl(u.to(DEV), _pack_tmerge_weight(w, Co).to(DEV), b.to(DEV), 3, 1, 1, 1, res=r.to(DEV), vin=True, vres=True, tmerge=True)
+        y27 = ops.conv3d_cl(u.to(DEV), _pack_conv_weight(w).to(DEV), b.to(DEV), 3, 1, 1, 1, res=r.to(DEV), vin=True, vres=True)
+    finally:
+        _lib.set_option("conv_tile", 0)
+    torch.cuda.synchronize()
+    assert list(c) == [kern] and torch.equal(y, y2), c
+    got = y.permute(3, 0, 1, 2)[None]
+    assert got.shape == ref.shape
+    err, rel = _rep(f"merged temporal taps T{T} {H}x{W} {Ci}->{Co}", got, ref)
+    rel27 = ((y.float() - y27.float()).norm() / y27.float().norm()).item()
+    print(f"[parity] merged-tap vs 27-tap kernel: rel_l2 {rel27:.3e}")
+    assert rel < 5e-3 and rel27 < 5e-3
