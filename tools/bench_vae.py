@@ -22,7 +22,10 @@ def conv_flops(vae, frames, size):
     import torch.nn as nn
     from easyanimate_amd import ops
     from easyanimate_amd.vae_modules import SpatialAttention
+    from easyanimate_amd import vae_modules as VM
     total = {"enc": 0.0, "dec": 0.0}
+    executed = {"enc": 0.0, "dec": 0.0}   # MFMA work actually issued: the sub-pixel up-samplers run 12 of 27 taps, a layer behind a
+    virt = [False]                        # virtual temporal x2 18 of 27 (vae_modules.SUBPIXEL_UPSAMPLE / TEMPORAL_TAP_MERGE)
     traffic = {"enc": 0.0, "dec": 0.0}   # minimal bf16 activation traffic: every conv / GroupNorm reads its input once and
     side = ["enc"]                        # writes its output once, no fusion credit
     # walk the graph symbolically with shapes only
@@ -32,6 +35,14 @@ def conv_flops(vae, frames, size):
         pad = c.padding[1] if k == 3 else 0
         To, Ho, Wo = ops.conv_out_shape(T, H, W, k, st, ss, pad, ups)
         fl = 2.0 * k ** 3 * ci * co * To * Ho * Wo
+        ex = fl
+        if ups and k == 3 and VM.SUBPIXEL_UPSAMPLE and W % 256 == 0 and ci % 64 == 0 and co % 256 == 0:
+            ex = fl * 12.0 / 27.0
+        elif virt[0] and k == 3 and VM.TEMPORAL_TAP_MERGE and To > 1 and ops.conv3d_tmerge_ok(To, H, W, ci, ops.round_up(co, 8)):
+            ex = fl * 18.0 / 27.0
+        if k == 3:
+            virt[0] = bool(tdup and To > 1 and VM.VIRTUAL_TDUP)     # a temporal up-sampler leaves a virtual clip for the next 3x3x3
+        executed[side[0]] += ex
         if tdup and To > 1:
             To = 2 * To - 1
         traffic[side[0]] += 2.0 * (T * H * W * ci + To * Ho * Wo * co)
@@ -54,6 +65,7 @@ def conv_flops(vae, frames, size):
                 T, H, W = s
                 n, C = H * W, a.inner_dim
                 fl += T * (8.0 * n * C * C + 4.0 * n * n * C)
+                executed[side[0]] += T * (8.0 * n * C * C + 4.0 * n * n * C)
             f, s = res(r, s); fl += f
         return fl, s
     T, H, W = frames, size, size
@@ -80,6 +92,7 @@ def conv_flops(vae, frames, size):
     gn(s, vae.decoder.conv_out.weight.shape[1])
     f, s = conv(vae.decoder.conv_out, *s); total["dec"] += f
     total["traffic"] = traffic
+    total["executed"] = executed
     return total, lat, s
 
 
@@ -134,6 +147,7 @@ def run(vae, frames: int = 49, size: int = 1024, iters: int = 2, kernel_breakdow
             key = "dec" if name == "decode" else "enc"
             res[name] = {"seconds": dt, "MPix_per_s": mpix / dt, "algorithmic_flop": fl[key],
                          "TFLOPs": fl[key] / dt / 1e12, "mfma_frac": fl[key] / dt / 1e12 / PEAK,
+                         "executed_flop": fl["executed"][key], "executed_mfma_frac": fl["executed"][key] / dt / 1e12 / PEAK,
                          "min_activation_bytes": fl["traffic"][key], "hbm_frac": fl["traffic"][key] / dt / 8e12,
                          "finite": bool(torch.isfinite(y.float()).all().item()), "out_shape": list(y.shape)}
             del y
