@@ -1,4 +1,4 @@
-"""world_size-2/3/4 gloo tests (CPU) of the multi-GPU layer (easyanimate_amd/sequence_parallel.py).
+"""world_size-2/3/4/8 gloo tests (CPU) of the multi-GPU layer (easyanimate_amd/sequence_parallel.py).
 
 The layer is communication + indexing only, so it runs on CPU tensors.  The per-token arithmetic in these tests is
 the ORACLE's (tests may use it); the product plugs its HIP kernels into the same layout.  Checked, for the flat
@@ -153,6 +153,7 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
     (2, 256, 64, False), (2, 200, 7, False), (3, 330, 16, True),    # flat sequence split (3: odd world)
     (2, 200, 64, True),                                              # CFG split only: no per-block exchange
     (4, 330, 64, True), (4, 256, 7, True),                           # 2 (CFG) x 2 (sequence), ragged / unaligned text
+    (8, 900, 16, True),                                              # 2 x 4: the shape of `bench.py --gpus 8`
 ])
 def test_sequence_parallel_block_equals_unsharded(world, n_video, T, cfg_parallel):
     mgr = mp.Manager()
