@@ -211,3 +211,39 @@ def test_exchange_layout_at_config3_size():
     lay = sp.layout(77, hi - lo)
     assert sp.n_loc == 384 and (lo, hi) == (768, 1000) and lay.t_pad == 128 and lay.rows == 512
     assert lay.own_ranges == [(0, 77), (128, 128 + 232)] and lay.remote_valid == 768 and lay.q_end == 360
+
+
+def test_layout_invariants_over_random_shapes():
+    """Property test of the partition + slot layout over random (world, N, T): shards tile [0, N) in rank order, every
+    alignment the kernels rely on holds (shard stride and first shard row multiples of 64, slot rows a multiple of 256),
+    own + remote keys add up to every key of the sequence, and the queries fit the workspace."""
+    from hypothesis import given, settings, strategies as st
+    from easyanimate_amd.sequence_parallel import EmulatedRank
+
+    @settings(max_examples=300, deadline=None)
+    @given(world=st.sampled_from([2, 3, 4, 6, 8]), cfg=st.booleans(), n=st.integers(4000, 60000), T=st.integers(1, 300))
+    def check(world, cfg, n, T):
+        seen, keys_total = [], None
+        for r in range(world):
+            sp = EmulatedRank(world, r, cfg_parallel=cfg)
+            b0, b1 = sp.begin(2)
+            P = sp.size
+            assert P == (world // 2 if cfg and world % 2 == 0 else world) and 0 <= b0 < b1 <= 2
+            sp.plan(n)
+            lo, hi = sp.shard_range()
+            if sp.rank == 0:
+                seen.append([])
+            seen[-1].append((lo, hi))
+            lay = sp.layout(T, hi - lo)
+            assert sp.n_loc % 64 == 0 and lay.t_pad % 64 == 0 and lay.t_pad - T < 64 and lay.rows % 256 == 0
+            assert lay.rows >= lay.t_pad + sp.n_loc and lay.q_pad == lay.rows and lay.q_end == lay.t_pad + (hi - lo) <= lay.q_pad
+            assert all(a % 64 == 0 and a < b for a, b in lay.own_ranges)
+            own_keys = sum(b - a for a, b in lay.own_ranges)
+            assert own_keys == T + (hi - lo)
+            assert own_keys + lay.remote_valid == T + n          # every key of the sequence exactly once
+            assert sp.exchanges(lay) == (P > 1)
+        for shards in seen:                                      # one list per sequence-parallel group
+            assert shards[0][0] == 0 and shards[-1][1] == n
+            assert all(shards[i][1] == shards[i + 1][0] for i in range(len(shards) - 1))
+            assert all(hi - lo == shards[0][1] - shards[0][0] for lo, hi in shards[:-1]) and 0 < shards[-1][1] - shards[-1][0]
+    check()
