@@ -435,6 +435,29 @@ def gen_transformer_full(ns, shim):
         torch.save(rec, os.path.join(OUT, f"{name}.pt"))
 
 
+@section("transformer_full_ragged")
+def gen_transformer_full_ragged(ns, shim):
+    # ---- round 3: full width at the patch grid of the reference's own published shapes (README.md:143: 384 x 672 -> latents
+    # 48 x 84 -> 24 x 42 patches), two latent frames: N = 2016 video tokens = 31.5 x 64 -- not a multiple of the 64-key tile, the
+    # 256-row query block or the GEMM tiles -- with T = 256 text tokens.  Inputs regenerated from seeds (dit_full_inputs).
+    import time
+    cfg = dict(FULL_DIT)
+    m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg).eval()
+    shapes = _load_sd(m, 5, "stress")
+    dims = (2, 2, 48, 84, 256)
+    B, Fr, H, W, T = dims
+    lat, extra, enc = dit_full_inputs(cfg, 29, *dims)
+    t = torch.tensor([433.0] * B).to(torch.bfloat16).float()
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+    cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+    t0 = time.time()
+    out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), inpaint_latents=extra, return_dict=False)[0]
+    print(f"  transformer_full_ragged: fp32 forward {time.time() - t0:.1f} s, out std {out.std().item():.3f}", flush=True)
+    torch.save(dict(cfg=cfg, shapes=shapes, seed=5, style="stress", input_seed=29, dims=dims, t=t, crops=cc,
+                    lat_sum=lat.double().sum().item(), enc_sum=enc.double().sum().item(), out=out),
+               os.path.join(OUT, "transformer_full_ragged.pt"))
+
+
 DIT_7B = dict(FULL_DIT, num_layers=28)     # "7B-class" declared dims, SURVEY Appendix B
 
 

@@ -176,11 +176,13 @@ def test_restatement_transformer_branches_vs_golden(name):
     _close(out, g["out"], 5e-6, name)
 
 
-def test_restatement_transformer_full_width_vs_golden():
-    """d = 3072, two layers, 33 input channels, unaligned text length (the small full-width fixture; the 5 x 64 x 64 one
-    takes 10 s of CPU per forward and is left to the GPU test)."""
+@pytest.mark.parametrize("name", ["transformer_full_inp", "transformer_full_ragged"])
+def test_restatement_transformer_full_width_vs_golden(name):
+    """d = 3072, two layers: 33 input channels with an unaligned text length, and the 24 x 42 patch grid of the reference's
+    published 384 x 672 shape (N = 2016 = 31.5 x 64 tokens).  (The 5 x 64 x 64 fixture takes 10 s of CPU per forward and is left
+    to the GPU test.)"""
     from oracle.gen_golden import dit_full_inputs
-    g = _load("transformer_full_inp.pt")
+    g = _load(name + ".pt")
     sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
     B, Fr, H, W, T = g["dims"]
     lat, extra, enc = dit_full_inputs(g["cfg"], g["input_seed"], *g["dims"])

@@ -161,7 +161,7 @@ def test_transformer_swa_vs_golden(name):
 # ---------------------------------------------------------------------------------------------------------
 # (c) full-width two-layer forwards
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["transformer_full_t2v", "transformer_full_inp"])
+@pytest.mark.parametrize("name", ["transformer_full_t2v", "transformer_full_inp", "transformer_full_ragged"])
 def test_transformer_full_width_vs_golden(name):
     from easyanimate_amd import _lib
     from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
