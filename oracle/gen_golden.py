@@ -322,6 +322,36 @@ def gen_vae_dec_512(ns, shim):
     print("  dec std", out["dec_std"], "shape", out["dec_shape"])
 
 
+def vae_ragged_inputs(seed=12, frames=5, height=96, width=168):
+    g = _g(seed)
+    video = torch.rand(1, 3, frames, height, width, generator=g) * 2 - 1
+    z = torch.randn(1, 16, (frames - 1) // 4 + 1, height // 8, width // 8, generator=g)
+    return video, z
+
+
+@section("vae_ragged")
+def gen_vae_ragged(ns, shim):
+    # ---- round 3: full-width VAE at a quarter of the reference's published 384 x 672 shape: 5 x 96 x 168, latents 12 x 21 --
+    # an odd latent width, rows that are no multiple of any tile (21 / 42 / 84 / 168 voxels), 252 mid-block keys (padded to
+    # 256 by the product).  The reference in its chunked / cached mode, encode and decode, plus its own bf16 floor.
+    vkw = dict(FULL_VAE)
+    vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()
+    shapes = _load_sd(vae, 2, "default")
+    video, zlat = vae_ragged_inputs()
+    moments = vae.encode(video)[0].parameters
+    dec = vae.decode(zlat)[0]
+    out = dict(cfg=vkw, shapes=shapes, seed=2, style="default", input_seed=12, frames=5, height=96, width=168,
+               video_sum=video.double().sum().item(), z_sum=zlat.double().sum().item(),
+               moments=moments, dec_f16=dec.to(torch.float16), dec_std=dec.std().item(), moments_std=moments.std().item())
+    vb = vae.to(torch.bfloat16)
+    mb = vb.encode(video.bfloat16())[0].parameters.float()
+    db = vb.decode(zlat.bfloat16())[0].float()
+    out.update(moments_floor_mse=_mse(mb, moments), dec_floor_mse=_mse(db, dec))
+    torch.save(out, os.path.join(OUT, "vae_full_ragged_5x96x168.pt"))
+    print("  moments", tuple(moments.shape), "std", out["moments_std"], "dec", tuple(dec.shape), "std", out["dec_std"],
+          {k: v for k, v in out.items() if k.endswith("floor_mse")})
+
+
 def _ref_loop(ns, shim, m, latents, enc, rope, steps, guidance, dt, keep=None):
     """The reference's sampling loop (pipeline_easyanimate.py:1069-1111) over the shim-hosted reference transformer."""
     mm = copy.deepcopy(m).to(dt)

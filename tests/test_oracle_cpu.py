@@ -270,3 +270,19 @@ def test_where_the_50_step_loop_error_comes_from():
     print(f"[parity] 50-step loop: bf16 model + fp32 latents {bf16_model_fp32_latents:.3e}; fp32 model + bf16 latents "
           f"{fp32_model_bf16_latents:.3e}; reference bf16 run {floor:.3e}")
     assert bf16_model_fp32_latents < 1e-4 < fp32_model_bf16_latents and fp32_model_bf16_latents > 0.5 * floor
+
+
+def test_restatement_vae_ragged_shape_vs_golden_chunked_reference():
+    """Full-width VAE at 5 x 96 x 168 (a quarter of the reference's published 384 x 672 shape: odd latent width 21, no row a
+    multiple of any tile, 252 mid-block keys): the monolithic restatement against the reference's chunked / cached run."""
+    from oracle import restatement_vae as RV
+    from oracle.gen_golden import vae_ragged_inputs
+    g = _load("vae_full_ragged_5x96x168.pt")
+    sd = synth_state_dict(g["shapes"], g["seed"], g["style"])
+    video, z = vae_ragged_inputs(g["input_seed"], g["frames"], g["height"], g["width"])
+    assert abs(video.double().sum().item() - g["video_sum"]) < 1e-3 and abs(z.double().sum().item() - g["z_sum"]) < 1e-4
+    with torch.no_grad():
+        m = RV.vae_encode_moments(sd, video, 32)
+        d = RV.vae_decode(sd, z, 32)
+    _close(m, g["moments"], 2e-5, "ragged full-width vae moments")
+    _close(d, g["dec_f16"].float(), 1.5e-3, "ragged full-width vae decode (fixture stored fp16)")

@@ -192,6 +192,33 @@ def test_transformer_full_width_vs_golden(name):
         assert cnt.get("gemm_256_mi16", 0) > 0                          # M = 2 x 5120 rows: the large-tile GEMM path
 
 
+def test_vae_full_width_ragged_shape_vs_golden():
+    """Full-width VAE at 5 x 96 x 168 = a quarter of the reference's published 384 x 672 shape: latents 12 x 21 (odd width), rows
+    of 21 / 42 / 84 / 168 voxels (no multiple of any tile: every convolution runs on the general implicit-GEMM kernels with
+    ragged last tiles), 252 mid-block keys (padded to 256 for the head_dim-512 kernel)."""
+    from easyanimate_amd import AutoencoderKLMagvit, _lib
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle.gen_golden import vae_ragged_inputs
+    g = _load("vae_full_ragged_5x96x168.pt")
+    video, z = vae_ragged_inputs(g["input_seed"], g["frames"], g["height"], g["width"])
+    assert abs(video.double().sum().item() - g["video_sum"]) < 1e-3 and abs(z.double().sum().item() - g["z_sum"]) < 1e-4
+    vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    _lib.reset_counters()
+    with torch.no_grad():
+        mom = vae.encode(video.to(DEV).bfloat16())[0].parameters
+        dec = vae.decode(z.to(DEV).bfloat16())[0]
+    torch.cuda.synchronize()
+    cnt = _lib.counters()
+    assert mom.shape == g["moments"].shape and dec.shape == g["dec_f16"].shape == (1, 3, 5, 96, 168)
+    mse_e, mse_d = _mse(mom.float(), g["moments"]), _mse(dec.float(), g["dec_f16"].float())
+    print(f"[parity] full-width VAE 5x96x168 (ragged): encode moments MSE={mse_e:.3e} (ref-bf16 floor {g['moments_floor_mse']:.3e}); "
+          f"decode MSE={mse_d:.3e} (ref-bf16 floor {g['dec_floor_mse']:.3e}) | kernels {cnt}")
+    assert mse_e < BAR and mse_d < BAR
+    assert cnt.get("attention_d512", 0) == 2       # the mid-block flash kernel served both passes with padded keys
+
+
 # ---------------------------------------------------------------------------------------------------------
 # (b) full-width VAE at 9 x 256^2 (SURVEY 8d-(iv))
 # ---------------------------------------------------------------------------------------------------------
