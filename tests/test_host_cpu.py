@@ -284,6 +284,43 @@ def test_encode_prompt_matches_the_reference_glue(tmp_path):
     assert a[0].shape == (1, 77, 16)
 
 
+def tiny_qwen2vl(hidden: int, seed: int = 0):
+    """The class the reference puts into the text_encoder slot (predict_t2v.py: Qwen2VLForConditionalGeneration.from_pretrained),
+    at a tiny random-init configuration -- no checkpoint is reachable from here."""
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    cfg = Qwen2VLConfig(vocab_size=128, hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=3, num_attention_heads=4,
+                        num_key_value_heads=2, max_position_embeddings=512, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                        rope_scaling={"type": "mrope", "mrope_section": [hidden // 8 - 2 * (hidden * 3 // 64), hidden * 3 // 64, hidden * 3 // 64]},
+                        vision_config=dict(depth=1, embed_dim=32, hidden_size=hidden, num_heads=2, mlp_ratio=2, in_channels=3,
+                                           patch_size=14, spatial_merge_size=2, temporal_patch_size=2))
+    torch.manual_seed(seed)
+    return Qwen2VLForConditionalGeneration(cfg).eval()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/easyanimate"), reason="/root/reference not present (GPU box)")
+def test_encode_prompt_with_the_transformers_qwen2vl_class():
+    """The text-encoder step (pipeline_easyanimate.py:421-460) with the real `transformers` class in the slot: chat template ->
+    256 padded tokens -> Qwen2VLForConditionalGeneration(..., output_hidden_states=True).hidden_states[-2], positive and
+    negative prompt; the product's method and the reference's own (called unbound) return identical tensors."""
+    import types
+    from oracle import ref_loader
+    from easyanimate_amd.pipeline import EasyAnimatePipeline
+    ns = ref_loader.load()
+    ref_cls = ns.pipeline_easyanimate.EasyAnimatePipeline
+    cfg = types.SimpleNamespace(enable_text_attention_mask=True, get=lambda k, d=None: {"enable_text_attention_mask": True}.get(k, d))
+    tr = types.SimpleNamespace(config=cfg)
+    enc = tiny_qwen2vl(64)
+    mine = EasyAnimatePipeline(vae=None, text_encoder=enc, tokenizer=_StubLLMTokenizer(), transformer=tr, scheduler=None)
+    fake = types.SimpleNamespace(tokenizer=mine.tokenizer, tokenizer_2=None, text_encoder=enc, text_encoder_2=None, transformer=tr)
+    with torch.no_grad():
+        a = mine.encode_prompt("a dog shakes its head", "cpu", torch.float32, 1, True, "blurry, static")
+        b = ref_cls.encode_prompt(fake, "a dog shakes its head", "cpu", torch.float32, 1, True, "blurry, static")
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)
+    assert a[0].shape == (1, 256, 64) and a[1].shape == (1, 256, 64) and not torch.equal(a[0], a[1])
+    assert int(a[2].sum()) < 256                       # padded: the mask the reference computes and then never uses (transformer3d.py:1502)
+
+
 def test_conv_weight_packing_for_8_channel_inputs():
     """vae_modules._pack_conv_weight_c8: [Cout, Cin <= 8, 3, 3, 3] -> [n_pad, 32 tap slots x 8 channels]; column 8 * tap + c
     holds w[:, c, dt, dh, dw] with tap = (dt * 3 + dh) * 3 + dw, everything else is zero (what conv3d_cl_kernel<C8> reads)."""

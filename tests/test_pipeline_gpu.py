@@ -66,6 +66,70 @@ def test_t2v_pipeline_end_to_end():
     assert mse < 2e-4   # pixel scale [0,1]; the loop's bf16 noise (CFG x11) passed through the decoder
 
 
+class _DeviceTokenizer:
+    """Stand-in for the Qwen2 tokenizer files (unreachable offline): chat template + byte-level ids, padded to max_length, with a
+    BatchEncoding-like `.to(device)`."""
+    model_max_length = 512
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+        return "".join(f"<|im_start|>{m['role']}\n{m['content'][0]['text']}<|im_end|>\n" for m in messages) + "<|im_start|>assistant\n"
+
+    def __call__(self, text=None, padding=None, max_length=None, truncation=None, return_attention_mask=None, padding_side=None,
+                 return_tensors=None):
+        assert padding == "max_length" and padding_side == "right" and return_tensors == "pt"
+        rows, masks = [], []
+        for t in text:
+            ids = [3 + b % 97 for b in t.encode()][:max_length]
+            masks.append([1] * len(ids) + [0] * (max_length - len(ids)))
+            rows.append(ids + [0] * (max_length - len(ids)))
+
+        class _Enc:
+            def __init__(self, ids, mask):
+                self.input_ids, self.attention_mask = ids, mask
+
+            def to(self, device):
+                return _Enc(self.input_ids.to(device), self.attention_mask.to(device))
+        return _Enc(torch.tensor(rows), torch.tensor(masks))
+
+
+def test_t2v_pipeline_from_prompt_strings():
+    """The text-encoder step in front of the loop (pipeline_easyanimate.py:421-460): the text_encoder slot holds
+    the `transformers` class the reference loads (Qwen2VLForConditionalGeneration, tiny random-init configuration, on the GPU in
+    bf16), prompts go in as STRINGS.  The embeddings the pipeline derives equal the fp32 CPU run of the same encoder to bf16
+    noise, and the frames equal the oracle chain fed with those embeddings."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_host_cpu import tiny_qwen2vl
+    from easyanimate_amd import EasyAnimatePipeline, FlowMatchEulerDiscreteScheduler
+    m, vae, sd_t, sd_v, cfg_t, cfg_v = _models(16)
+    enc_cpu = tiny_qwen2vl(cfg_t["text_embed_dim"])
+    enc = tiny_qwen2vl(cfg_t["text_embed_dim"]).to(torch.bfloat16).to(DEV)
+    tok = _DeviceTokenizer()
+    pipe = EasyAnimatePipeline(vae=vae, text_encoder=enc, tokenizer=tok, transformer=m, scheduler=FlowMatchEulerDiscreteScheduler(shift=1.0))
+    F_, H, W, steps, guidance = 9, 64, 64, 4, 6.0
+    g = torch.Generator().manual_seed(21)
+    latents = torch.randn(pipe.latent_shape(1, 16, F_, H, W), generator=g)
+    prompt, negative = "a dog shakes its head", "blurry, static, low quality"
+    with torch.no_grad():
+        pe, ne, pm, nm = pipe.encode_prompt(prompt, DEV, torch.bfloat16, 1, True, negative)
+        ref_pipe = EasyAnimatePipeline(vae=None, text_encoder=enc_cpu, tokenizer=tok, transformer=m, scheduler=None)
+        pe32, ne32, _, _ = ref_pipe.encode_prompt(prompt, "cpu", torch.float32, 1, True, negative)
+    assert pe.shape == (1, 256, cfg_t["text_embed_dim"]) and pe.device.type == "cuda" and int(pm.sum()) < 256
+    for a, b in ((pe, pe32), (ne, ne32)):
+        err = ((a.float().cpu() - b) ** 2).mean().item() / (b ** 2).mean().item()
+        assert err < 1e-3, err          # the encoder forward itself is transformers' code (bf16 on the GPU vs fp32 on the host)
+    out = pipe(prompt=prompt, negative_prompt=negative, video_length=F_, height=H, width=W, num_inference_steps=steps,
+               guidance_scale=guidance, latents=latents.to(torch.bfloat16), output_type="np")
+    out2 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, video_length=F_, height=H, width=W, num_inference_steps=steps,
+                guidance_scale=guidance, latents=latents.to(torch.bfloat16), output_type="np")
+    assert out.frames.shape == (1, 3, F_, H, W) and (out.frames == out2.frames).all()     # strings and their embeddings: the same call
+    rope = tuple(t.cpu() for t in pipe.rotary_embedding(H, W, 3))
+    vcfg = dict(cfg_v, scaling_factor=vae.config.scaling_factor)
+    ref = _oracle_frames(sd_t, cfg_t, sd_v, vcfg, latents.bfloat16().float(), torch.cat([ne, pe]).float().cpu(), rope, steps, guidance)
+    mse, mx = _report("t2v pipeline from prompt strings (Qwen2VL class in the text_encoder slot)", out.frames, ref)
+    assert mse < 2e-4
+
+
 def test_i2v_pipeline_end_to_end():
     """predict_i2v.py path: start image -> get_image_to_video_latent -> mask / masked video -> VAE encode ->
     inpaint_latents [2, 17, f, h, w] -> InP transformer (in_channels 33) loop -> decode."""
