@@ -1046,7 +1046,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
         const int cs = c ^ (r & 7);
-        asrc[i] = Ab + (int64_t)(row0 + r) * q.lda + cs * 8;      // M % 256 == 0: no row clamp
+        const int ra = row0 + r < q.M ? row0 + r : q.M - 1;       // ragged last M tile: rows past M re-read row M - 1
+        asrc[i] = Ab + (int64_t)ra * q.lda + cs * 8;
         wsrc[i] = Wb + (int64_t)(col0 + r) * q.K + cs * 8;
     }
     char* const dma_a = smem + wave * 4096;
@@ -1083,6 +1084,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
 
     if (which == 2) {
         EA_G3_MAINLOOP(1, W8)
+        int Mv = q.M;                       // laundered: nothing of the ragged-tile bookkeeping is hoisted above the main loop
+        asm volatile("" : "+s"(Mv));
+        int lane_e;                         // the lane id again, so that no lane-derived value stays live across the main loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int lr = lane_e & 15, lq = lane_e >> 4, lane = lane_e;
         // ---- v: lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1100,23 +1106,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
         // wave-private image: the LDS writes above are ordered before the reads below by the waitcnt the compiler inserts
         const int r4 = lane >> 4, c16 = lane & 15;
         unsigned short* dst = q.vt_out + (bh * 64) * (int64_t)q.kv_rows + q.kv_off + tok0 + c16 * 8;
+        const int nv = Mv - (tok0 + c16 * 8);       // valid tokens among this lane's eight (ragged last M tile: < 8)
+        if (nv >= 8) {
 #pragma unroll
-        for (int qq = 0; qq < 16; ++qq) {
-            const int n = qq * 4 + r4;
-            const u16x8 o = *reinterpret_cast<const u16x8*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
-            *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.kv_rows) = o;
+            for (int qq = 0; qq < 16; ++qq) {
+                const int n = qq * 4 + r4;
+                const u16x8 o = *reinterpret_cast<const u16x8*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
+                *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.kv_rows) = o;
+            }
+        } else if (nv > 0) {   // the one straddling group of a row: element stores, nothing past column kv_off + M is written
+            for (int qq = 0; qq < 16; ++qq) {
+                const int n = qq * 4 + r4;
+                const unsigned short* src = reinterpret_cast<const unsigned short*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
+                for (int e = 0; e < nv; ++e) dst[(int64_t)n * q.kv_rows + e] = src[e];
+            }
         }
         return;
     }
 
     EA_G3_MAINLOOP(0, W8)
-    // ---- q / k: lane holds features j*16 + lq*4 + 0..3 of token i*16 + lr
+    int Mv = q.M;
+    asm volatile("" : "+s"(Mv));
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int lr_e = lane_e & 15, lq_e = lane_e >> 4;
+    // ---- q / k: lane_e holds features j*16 + lq_e*4 + 0..3 of token i*16 + lr_e
     const float* gw = q.nw[which];
     const float* gb = q.nb[which];
     f32x4_t bias4[4], gw4[4], gb4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = j * 16 + lq * 4;
+        const int n = j * 16 + lq_e * 4;
         f32x4_t z = {0.f, 0.f, 0.f, 0.f};
         bias4[j] = biasb ? *reinterpret_cast<const f32x4_t*>(biasb + col0 + wc * 64 + n) : z;
         gw4[j] = *reinterpret_cast<const f32x4_t*>(gw + n);
@@ -1125,13 +1145,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     const float osc = which == 0 ? q.q_scale : 1.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int r = i * 16 + lr;
+        const int r = i * 16 + lr_e;
         // the token's cos / sin rows first: their latency is covered by the LayerNorm arithmetic below
         f32x4_t c4[4], s4[4];
         if (q.cosT) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t tr = (int64_t)(tok0 + r) * 64 + j * 16 + lq * 4;
+                const int64_t tr = (int64_t)(tok0 + r < Mv ? tok0 + r : Mv - 1) * 64 + j * 16 + lq_e * 4;
                 c4[j] = *reinterpret_cast<const f32x4_t*>(q.cosT + tr);
                 s4[j] = *reinterpret_cast<const f32x4_t*>(q.sinT + tr);
             }
@@ -1176,18 +1196,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[j][e] * osc);
             }
-            const int ch = j * 2 + (lq >> 1);
-            *reinterpret_cast<u16x4*>(img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq & 1) * 8) = o;
+            const int ch = j * 2 + (lq_e >> 1);
+            *reinterpret_cast<u16x4*>(img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq_e & 1) * 8) = o;
         }
     }
-    const int r8 = lane >> 3, c8 = lane & 7;
+    const int r8 = lane_e >> 3, c8 = lane_e & 7;
     unsigned short* dst = (which ? q.k_out + (bh * q.kv_rows + q.kv_off + tok0) * 64
                                  : q.q_out + (bh * q.s_pad + q.seq_off + tok0) * 64) + c8 * 8;
 #pragma unroll
     for (int qq = 0; qq < 16; ++qq) {
         const int r = qq * 8 + r8;
         const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
-        *reinterpret_cast<u16x8*>(dst + (int64_t)r * 64) = o;
+        if (tok0 + r < Mv) *reinterpret_cast<u16x8*>(dst + (int64_t)r * 64) = o;
     }
 }
 
@@ -1320,7 +1340,6 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
                "ea_qkv_gemm_norm_rope_bf16: kv_off / kv_rows must be multiples of 8 with kv_off + M <= kv_rows");
     EA_REQUIRE((cos == nullptr) == (sin == nullptr), "ea_qkv_gemm_norm_rope_bf16: cos and sin go together");
     EA_REQUIRE(batch > 0 && batch <= 65535 && heads > 0 && M > 0 && K > 0, "ea_qkv_gemm_norm_rope_bf16: bad sizes");
-    EA_REQUIRE(M % 256 == 0, "ea_qkv_gemm_norm_rope_bf16: M=%d must be a multiple of 256 (use ea_gemm_bf16 + ea_qknorm_rope_bf16)", M);
     EA_REQUIRE((heads * 64) % 256 == 0, "ea_qkv_gemm_norm_rope_bf16: heads*64 must be a multiple of 256");
     EA_REQUIRE(K % BK == 0 && lda % 8 == 0, "ea_qkv_gemm_norm_rope_bf16: K must be a multiple of 64, lda of 8");
     EA_REQUIRE(seq_off >= 0 && seq_off % 8 == 0 && s_pad % 8 == 0 && seq_off + M <= s_pad,
@@ -1339,7 +1358,7 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
     q.M = M; q.K = K; q.inner = heads * 64; q.heads = heads; q.seq_off = seq_off; q.s_pad = s_pad;
     q.kv_off = kv_off; q.kv_rows = kv_rows; q.first_part = parts == 6 ? 1 : 0;
     q.lda = lda; q.abs_ = a_batch_stride; q.eps = ln_eps; q.q_scale = q_scale;
-    q.tiles_m = M / 256;
+    q.tiles_m = (M + 255) / 256;      // a ragged last tile re-reads row M - 1 and stores rows < M only
     q.tiles_n = (parts == 7 ? 3 : (parts == 6 ? 2 : 1)) * q.inner / 256;
     q.rows_per_xcd = q.tiles_m >= 64 ? (q.tiles_m + 7) / 8 : 0;
     dim3 grid(q.rows_per_xcd ? 8 * q.rows_per_xcd * q.tiles_n : q.tiles_m * q.tiles_n, batch);

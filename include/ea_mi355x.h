@@ -160,8 +160,9 @@ int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride, ea_bf16* q
  *   kv_off, kv_rows: as in ea_qknorm_rope_bf16 (k_out / vt_out may have their own rows-per-head and first row).
  *   parts: which thirds of the q | k | v output axis this launch computes: 7 (or 0) = all, 6 = k | v, 1 = q.  The
  *          sequence-parallel step projects K | V first, starts the K / V^T exchange, and projects Q under it.
- * Requirements: M % 256 == 0, (heads*64) % 256 == 0, K % 64 == 0, seq_off % 8 == 0, kv_off % 8 == 0; other shapes
- * (test-size models) use ea_gemm_bf16 + ea_qknorm_rope_bf16. */
+ * Requirements: (heads*64) % 256 == 0, K % 64 == 0, seq_off % 8 == 0, kv_off % 8 == 0; other shapes (test-size models)
+ * use ea_gemm_bf16 + ea_qknorm_rope_bf16.  M is arbitrary: a ragged last 256-row tile re-reads row M - 1 and stores rows
+ * < M only (exactly rows / columns [off, off + M) are written). */
 int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
                                const float* bq, const float* bk, const float* bv, ea_bf16* q_out, ea_bf16* k_out,
                                ea_bf16* vt_out, const float* nq_w, const float* nq_b, const float* nk_w,

@@ -269,7 +269,11 @@ def test_qknorm_rope(B, H, n_tok, seq_off, use_rope):
 
 
 @pytest.mark.parametrize("B,H,M,K,seq_off,use_rope", [(2, 4, 512, 128, 8, True), (1, 4, 256, 64, 0, False), (2, 48, 768, 3072, 256, True),
-                                                     (1, 8, 1024, 192, 320, True)])
+                                                     (1, 8, 1024, 192, 320, True),
+                                                     # ragged last M tile: whole 8-token groups, a straddling group (M % 8 != 0),
+                                                     # a last tile of one row, wave tiles entirely past M
+                                                     (2, 4, 1032, 128, 8, True), (1, 8, 1283, 192, 256, True), (2, 4, 1025, 64, 0, False),
+                                                     (1, 48, 2016, 3072, 256, True)])
 def test_qkv_fused_matches_unfused(B, H, M, K, seq_off, use_rope):
     """ea_qkv_gemm_norm_rope_bf16 (one launch: three projections + qk-LayerNorm + RoPE + scatter in the GEMM epilogue,
     V^T through the operand-swapped main loop) against ea_gemm_bf16 x 3 (same 256^2 16x16x32 main loop) followed by
