@@ -39,6 +39,12 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Buffer-addressed LDS-DMA (see ea_attention.hip): 16 bytes per lane from base + voff (per lane, fixed) + soff (scalar).
+__device__ __forceinline__ void bdma16g(const void* base, int extent, int voff, int soff, void* lds_wave_base) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, extent, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 // ---- fp8 weight storage (the reference's `model_cpu_offload_and_qfloat8` mode, utils/fp8_optimization.py:17-35: every
 // Linear weight is kept as torch.float8_e4m3fn = OCP E4M3 and up-cast to bf16 for each call).  The W8 kernel variants read
 // the fp8 bytes themselves: a weight tile row comes in through registers (16 bytes = 16 elements per load), is widened to
@@ -784,7 +790,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
 // passed by a wave only after its reads of tile t's stage have returned (they feed step 1), so behind it that stage is free
 // for tile t + 2, and every wave waited for its own pieces of tile t + 1 (vmcnt) before arriving, so tile t + 1 is complete.
 // Same LDS layout / swizzle / DMA source addressing / C^T orientation / epilogue image as gemm256_mi16_kernel.
-template <int EPI>
+// SCHED = 1 (ea_set_option("gemm_w4", 2)): the second main-loop schedule of this kernel, see the comment in front of it.
+#ifndef EA_W4B_BAR0
+#define EA_W4B_BAR0 32        // MFMA slot of step 0 in front of which "this tile's stage is consumed" is synchronised
+#endif
+#ifndef EA_W4B_DMA_EVERY
+#define EA_W4B_DMA_EVERY 4    // one DMA piece pair of tile t + 2 every this many MFMA slots behind that point
+#endif
+template <int EPI, int SCHED = 0>
 __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -870,6 +883,7 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
     }                                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+  if (SCHED == 0) {
     // ---- prologue: tile 0 -> stage 0, its first fragments -> buffer 0, tile 1 -> stage 1
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -903,6 +917,78 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
         EA_W4_STEP(1, 0, so ^ OPER2, 0, issue, so)
         so ^= OPER2;
     }
+  } else {
+    // ---- second schedule (round 3, after reading how a one-wave-per-SIMD main loop has to be fed):
+    //  * every non-MFMA instruction sits alone between two MFMAs (one fragment read per slot, one DMA piece pair every
+    //    EA_W4B_DMA_EVERY slots), never in blocks in front of a group;
+    //  * the DMA is buffer-addressed: per-lane byte offsets fixed for the kernel (16 registers instead of 32 for 64-bit
+    //    pointers), the K tile is the scalar offset -- no vector address arithmetic in the loop;
+    //  * the prefetch distance is two tiles: a stage is consumed (all four k-step fragments of its tile in registers) half
+    //    way through step 0 of its tile -- one barrier -- and tile t + 2 is requested right behind that point, a step and a
+    //    half earlier than in the first schedule; at the step-1 barrier a wave waits with vmcnt(16): its pieces of tile t + 1
+    //    (requested two and a half steps ago) have landed, those of tile t + 2 stay in flight.
+    int aoff[8], woff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ (r & 7);
+        const int ra = (row0 + r < p.M ? row0 + r : p.M - 1) - row0;
+        const int rw = (col0 + r < p.N ? col0 + r : p.N - 1) - col0;
+        aoff[i] = (int)((int64_t)ra * p.lda * 2) + cs * 16;
+        woff[i] = rw * p.K * 2 + cs * 16;
+    }
+    const unsigned short* Abase = Ab + (int64_t)row0 * p.lda;
+    const unsigned short* Wbase = p.W + (int64_t)col0 * p.K;
+    const int a_rows = p.M - row0 < 256 ? p.M - row0 : 256, w_rows = p.N - col0 < 256 ? p.N - col0 : 256;
+    const int a_ext = (int)((((int64_t)a_rows - 1) * p.lda + p.K) * 2);      // bytes reachable from Abase / Wbase
+    const int w_ext = ((w_rows - 1) * p.K + p.K) * 2;
+#define EA_W4B_ISSUE1(SOFF, X, KB)                                                                                \
+    {                                                                                                             \
+        bdma16g(Abase, a_ext, aoff[X], KB, dma_a + (SOFF) + (X) * 1024);                                         \
+        bdma16g(Wbase, w_ext, woff[X], KB, dma_w + (SOFF) + (X) * 1024);                                         \
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) EA_W4B_ISSUE1(0, x, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk > 1) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) EA_W4B_ISSUE1(OPER2, x, BK * 2)
+    }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) { EA_W4_READ1(0, 0, 0, x) }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int BAR0 = EA_W4B_BAR0, DEV = EA_W4B_DMA_EVERY;
+    static_assert(BAR0 >= 16 && BAR0 + 1 + 7 * DEV < 128, "EA_W4B_BAR0 / EA_W4B_DMA_EVERY: the eight piece pairs must fit behind the barrier");
+    unsigned so = 0;
+    for (int t = 0; t < nk; ++t) {
+        const bool issue = t + 2 < nk;                       // wave-uniform
+        const int kb2 = (t + 2) * (BK * 2);                  // byte offset of tile t + 2 along K
+        // slots 0 .. 63: step 0 (MFMAs on buffer 0), 64 .. 127: step 1 (buffer 1)
+#pragma unroll
+        for (int n = 0; n < 128; ++n) {
+            if (n < 16) { EA_W4_READ1(1, so, 1, n) }                          // the k-step-1 fragments of tile t
+            if (n == BAR0) {                                                   // every wave holds all of tile t in registers
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (n > BAR0 && (n - BAR0 - 1) % DEV == 0 && (n - BAR0 - 1) / DEV < 8 && issue)
+                EA_W4B_ISSUE1(so, (n - BAR0 - 1) / DEV, kb2)                   // tile t + 2 -> the stage tile t leaves
+            if (n == 64) {                                                     // tile t + 1 complete (own pieces, then everyone's)
+                if (issue && BAR0 + 1 + 7 * DEV < 64) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (n >= 64 && n < 80) { EA_W4_READ1(0, so ^ OPER2, 0, n - 64) }  // the first fragments of tile t + 1
+            if (n < 64) { EA_W4_MFMA1(0, n) } else { EA_W4_MFMA1(1, n - 64) }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        so ^= OPER2;
+    }
+#undef EA_W4B_ISSUE1
+  }
     // the last MFMAs' results must have left the pipe before the epilogue reads the accumulators (inline asm: the hazard
     // recogniser does not see the producer)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -1234,11 +1320,15 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
         if (g_gemm_w4 && g_gemm_mfma == 16 && !W8 && EPI != EA_EPI_F32_OUT) {
             static bool attrw4_done = false;
             if (!attrw4_done) {
-                hipFuncSetAttribute((const void*)gemm256_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)gemm256_w4_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)gemm256_w4_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 attrw4_done = true;
             }
-            ea_count("gemm_256_w4");
-            hipLaunchKernelGGL((gemm256_w4_kernel<EPI>), grid, dim3(256), lds, st, p);
+            // the buffer-addressed schedule needs the tile's operands within 2 GiB of their first row
+            const bool sched1 = g_gemm_w4 == 2 && 256ll * p.lda * 2 + (int64_t)p.K * 2 < (1ll << 31) && 256ll * p.K * 2 < (1ll << 31);
+            ea_count(sched1 ? "gemm_256_w4b" : "gemm_256_w4");
+            if (sched1) hipLaunchKernelGGL((gemm256_w4_kernel<EPI, 1>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((gemm256_w4_kernel<EPI, 0>), grid, dim3(256), lds, st, p);
         } else
 #endif
         if ((g_gemm_mfma == 16 || W8) && EPI != EA_EPI_F32_OUT) {
@@ -1410,7 +1500,7 @@ int ea_gemm_tile_set(int v) {
 }
 int ea_gemm_w4_get() { return g_gemm_w4; }
 int ea_gemm_w4_set(int v) {
-    if (v != 0 && !(v == 1 && EA_BUILD_VARIANTS)) return -1;   // the four-wave kernel exists in EA_BUILD_VARIANTS=1 libraries only
+    if (v != 0 && !((v == 1 || v == 2) && EA_BUILD_VARIANTS)) return -1;   // the four-wave kernel (1: first schedule, 2: second) exists in EA_BUILD_VARIANTS=1 libraries only
     g_gemm_w4 = v;
     return 0;
 }

@@ -928,20 +928,22 @@ def test_attention_segments_slot_rows(P, rank, T, nl, n_last):
 # ---- round 3: the four-wave 256^2 GEMM (128 x 128 wave tiles, accumulators in AGPRs) -----------------------------------------
 @pytest.mark.parametrize("B,M,N,K", GEMM256_SHAPES + [(1, 256, 256, 320), (1, 4096, 3072, 3072)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_gemm_w4_equals_the_eight_wave_kernel(B, M, N, K, epi):
+@pytest.mark.parametrize("sched", [1, 2])
+def test_gemm_w4_equals_the_eight_wave_kernel(B, M, N, K, epi, sched):
     """gemm256_w4_kernel against fp64 (through test_gemm) and against gemm256_mi16_kernel: the same 16x16x32 products summed
     in the same order per output element -> bit-identical, M / N tails, odd and even K-tile counts, strided batches;
-    repeated launches bit-identical (race screen for the one-barrier-per-tile schedule)."""
+    repeated launches bit-identical (race screen for the one-barrier-per-tile schedule and, sched = 2, for the buffer-addressed
+    two-tiles-ahead schedule)."""
     from easyanimate_amd import _lib
     ops = _ops()
     _needs_variants()
     w4_default = _lib.get_option("gemm_w4")
     _lib.set_option("gemm_tile", 256)
     try:
-        _lib.set_option("gemm_w4", 1)
+        _lib.set_option("gemm_w4", sched)
         _lib.reset_counters()
         test_gemm(B, M, N, K, epi)
-        assert _lib.counters().get("gemm_256_w4", 0) == 1, _lib.counters()
+        assert _lib.counters().get("gemm_256_w4" if sched == 1 else "gemm_256_w4b", 0) == 1, _lib.counters()
         g = torch.Generator(device="cpu").manual_seed(8)
         A = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
         W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
