@@ -1,6 +1,9 @@
 """Builds libea_mi355x.so (HIP kernels + C ABI) for gfx950 with hipcc.  No GPU is needed to build.
 
     python -m easyanimate_amd.build [--force]
+    EA_BUILD_VARIANTS=1 EA_LIB_OUT=easyanimate_amd/lib/variants/libea_variants.so python -m easyanimate_amd.build
+        # a second library beside the product one, with the cross-check / experiment kernels compiled in; load it with
+        # EA_LIB_PATH=<that file> (tests: the EA_BUILD_VARIANTS-only cases run; tools/ab_*.py: in-process A/Bs)
 """
 from __future__ import annotations
 
@@ -14,6 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libea_mi355x.so")
+_OUT = os.environ.get("EA_LIB_OUT")     # build another library file (own object directory and stamp); the product library stays
+if _OUT:
+    LIB = os.path.abspath(_OUT)
+    LIBDIR = os.path.dirname(LIB)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file extras: the one-wave-per-SIMD attention kernel keeps its MFMA accumulators in arch VGPRs (they are read by
@@ -54,11 +61,11 @@ def _compile(src: str, objdir: str) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "build.sha256")
+    stamp = os.path.join(LIBDIR, "build.sha256") if not _OUT else LIB + ".sha256"
     dg = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dg:
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if not _OUT else os.path.join(HERE, "build", "out_" + os.path.basename(LIB))
     os.makedirs(objdir, exist_ok=True)
     srcs = _sources()
     if verbose:

@@ -377,12 +377,15 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
 
 #include "ea_attention_v2.inc"
 #include "ea_attention_v3.inc"
+#if EA_BUILD_VARIANTS
+#include "ea_attention_v4.inc"
+#endif
 
 }  // namespace
 
 int ea_attn_variant_get() { return g_attn_variant; }
 int ea_attn_variant_set(int v) {
-    if (v != 2 && v != 3 && !(v == 1 && EA_BUILD_VARIANTS)) return -1;   // v1 over plain keys: EA_BUILD_VARIANTS=1 libraries only
+    if (v != 2 && v != 3 && !((v == 1 || v == 4) && EA_BUILD_VARIANTS)) return -1;   // v1 / the v4 experiment: EA_BUILD_VARIANTS=1 libraries only
     g_attn_variant = v;
     return 0;
 }
@@ -417,7 +420,7 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     EA_REQUIRE((flags & ~3) == 0 && (flags == 0 || state), "ea_attention_fwd: bad flags / missing state buffer");
     if (q_end == q_begin) return EA_OK;
     const bool plain = flags == 0 && kv_begin == 0;
-    const int variant = plain ? g_attn_variant : (g_attn_variant == 3 ? 3 : 2);   // key ranges / resumable state: v2 / v3 only
+    const int variant = plain ? g_attn_variant : (g_attn_variant >= 3 ? 3 : 2);   // key ranges / resumable state: v2 / v3 only
     const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
     const int bh = batch * heads;
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
@@ -437,9 +440,20 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     {
         // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
         const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;
-        ea_count(variant == 3 && folded ? "attention_v3" : "attention_v2");
+#if EA_BUILD_VARIANTS
+        if (variant == 4 && folded) {   // the one-wave-per-SIMD experiment: plain calls with the scale folded into Q only
+            const int nqb4 = (q_end - q_begin + ATT4_QB - 1) / ATT4_QB;
+            const int64_t blocks4 = (int64_t)((bh + 7) / 8) * nqb4 * 8;
+            ea_count("attention_v4");
+            hipLaunchKernelGGL(attention_fwd_v4_kernel, dim3((unsigned)blocks4), blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride,
+                               heads, bh, kv_end, s_pad, q_begin, q_end, nqb4);
+            return ea_check_launch("ea_attention_fwd");
+        }
+#endif
+        const int variant23 = variant == 4 ? 3 : variant;
+        ea_count(variant23 == 3 && folded ? "attention_v3" : "attention_v2");
 #define EA_ATT_LAUNCH(MODE, FOLDED)                                                                                       \
-    if (variant == 3 && FOLDED)                                                                                           \
+    if (variant23 == 3 && FOLDED)                                                                                         \
         hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid, blk, ATT_LDS, st, q, k, vt, o16,                         \
                            out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);  \
     else                                                                                                                  \

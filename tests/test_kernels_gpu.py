@@ -777,6 +777,41 @@ def test_attention_query_range(attn_kernel):
         assert (out[:, :512] == 7.0).all() and (out[:, 1024:] == 7.0).all()
 
 
+@pytest.mark.parametrize("B,H,S", [(1, 2, 512), (1, 3, 1000), (2, 9, 2048 + 77), (1, 1, 5), (1, 8, 4096), (1, 2, 1300)])
+def test_attention_v4_experiment(B, H, S):
+    """The one-wave-per-SIMD attention experiment (ea_attention_v4.inc, EA_BUILD_VARIANTS=1 libraries, attn_variant 4): plain
+    calls with the scale folded into Q against fp64 softmax and against v3 (same MFMA products in the same order; the row sums
+    accumulate inside the sum MFMAs instead of per-block adds -> last-bit differences only); partial last key tile, several
+    query blocks of 512, a query range, untouched rows; repeated launches bit-identical (race screen for the moved hand-over)."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    _needs_variants()
+    q, k, vt, v = _attn_inputs(B, H, S, 7, scale_q=2.0)
+    qs = _fold(q)
+    ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
+    try:
+        _lib.set_option("attn_variant", 4)
+        _lib.reset_counters()
+        out4 = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+        assert _lib.counters().get("attention_v4", 0) == 1, _lib.counters()
+        for _ in range(3):
+            assert torch.equal(ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE), out4)
+        if S >= 1024:
+            part = torch.full((B, S, H * 64), 7.0, dtype=torch.bfloat16, device=DEV)
+            ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE, out=part, q_begin=256, q_end=900)
+            assert torch.equal(part[:, 256:900], out4[:, 256:900]) and (part[:, :256] == 7.0).all() and (part[:, 900:] == 7.0).all()
+        _lib.set_option("attn_variant", 3)
+        out3 = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+    finally:
+        _lib.set_option("attn_variant", 3)
+    err, rel = _report(f"attention v4 B{B}H{H}S{S}", out4, ref)
+    assert rel < 8e-3 and err < 0.05, (err, rel)
+    d = (out4.float() - out3.float()).abs()
+    tol = out3.float().abs().clamp_min(1e-3) * 2.0 ** -7
+    print(f"[parity] attention v4 vs v3: {(d > 0).float().mean().item() * 100:.3f} % of the outputs differ, max {(d / tol).max().item():.2f} bf16 ulp")
+    assert (d <= tol).all()
+
+
 def test_patchify_unpatchify_cfg_euler():
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(17)

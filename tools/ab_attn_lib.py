@@ -4,7 +4,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from easyanimate_amd import ops
+from easyanimate_amd import _lib, ops
 from microbench_vae_common import timeit
 
 lib = os.path.basename(os.environ.get("EA_LIB_PATH", "default"))
@@ -14,6 +14,9 @@ k = torch.randn(B, H, S, 64, device="cuda").to(torch.bfloat16)
 vt = torch.randn(B, H, 64, S, device="cuda").to(torch.bfloat16)
 qq = (q.float() * ops.FOLDED_Q_SCALE).to(torch.bfloat16)
 out = torch.empty(B, S, H * 64, dtype=torch.bfloat16, device="cuda")
+variants = [3] + ([4] if _lib.get_option("build_variants") == 1 else [])    # 4: the one-wave-per-SIMD experiment (EA_BUILD_VARIANTS=1)
 for rep in range(3):
+  for variant in variants:
+    _lib.set_option("attn_variant", variant)
     ms = timeit(lambda: ops.attention(qq, k, vt, S, ops.FOLDED_ATTN_SCALE, out=out), warm=1, iters=5)
-    print(json.dumps({"lib": lib, "kernel": "attention v3", "ms": round(ms, 3), "TFLOPs": round(4.0 * B * H * S * S * 64 / ms / 1e9, 1)}), flush=True)
+    print(json.dumps({"lib": lib, "kernel": f"attention v{variant}", "ms": round(ms, 3), "TFLOPs": round(4.0 * B * H * S * S * 64 / ms / 1e9, 1)}), flush=True)
