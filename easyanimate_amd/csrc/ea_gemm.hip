@@ -795,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
 #define EA_W4B_BAR0 32        // MFMA slot of step 0 in front of which "this tile's stage is consumed" is synchronised
 #endif
 #ifndef EA_W4B_DMA_EVERY
-#define EA_W4B_DMA_EVERY 4    // one DMA piece pair of tile t + 2 every this many MFMA slots behind that point
+#define EA_W4B_DMA_EVERY 2    // one DMA request (1 KiB piece of one operand) of tile t + 2 every this many MFMA slots behind that point
 #endif
 template <int EPI, int SCHED = 0>
 __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
     }
   } else {
     // ---- second schedule (round 3, after reading how a one-wave-per-SIMD main loop has to be fed):
-    //  * every non-MFMA instruction sits alone between two MFMAs (one fragment read per slot, one DMA piece pair every
+    //  * every non-MFMA instruction sits alone between two MFMAs (one fragment read per slot, one DMA request every
     //    EA_W4B_DMA_EVERY slots), never in blocks in front of a group;
     //  * the DMA is buffer-addressed: per-lane byte offsets fixed for the kernel (16 registers instead of 32 for 64-bit
     //    pointers), the K tile is the scalar offset -- no vector address arithmetic in the loop;
@@ -942,10 +942,16 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
     const int a_rows = p.M - row0 < 256 ? p.M - row0 : 256, w_rows = p.N - col0 < 256 ? p.N - col0 : 256;
     const int a_ext = (int)((((int64_t)a_rows - 1) * p.lda + p.K) * 2);      // bytes reachable from Abase / Wbase
     const int w_ext = ((w_rows - 1) * p.K + p.K) * 2;
+    // half-piece Q (0..15): even = activation piece Q / 2, odd = weight piece Q / 2 -- ONE request per MFMA slot in the loop
+#define EA_W4B_ISSUEH(SOFF, Q, KB)                                                                                \
+    {                                                                                                             \
+        if (((Q) & 1) == 0) bdma16g(Abase, a_ext, aoff[(Q) >> 1], KB, dma_a + (SOFF) + ((Q) >> 1) * 1024);      \
+        else bdma16g(Wbase, w_ext, woff[(Q) >> 1], KB, dma_w + (SOFF) + ((Q) >> 1) * 1024);                      \
+    }
 #define EA_W4B_ISSUE1(SOFF, X, KB)                                                                                \
     {                                                                                                             \
-        bdma16g(Abase, a_ext, aoff[X], KB, dma_a + (SOFF) + (X) * 1024);                                         \
-        bdma16g(Wbase, w_ext, woff[X], KB, dma_w + (SOFF) + (X) * 1024);                                         \
+        EA_W4B_ISSUEH(SOFF, 2 * (X), KB)                                                                          \
+        EA_W4B_ISSUEH(SOFF, 2 * (X) + 1, KB)                                                                      \
     }
 #pragma unroll
     for (int x = 0; x < 8; ++x) EA_W4B_ISSUE1(0, x, 0)
@@ -961,33 +967,37 @@ __global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     constexpr int BAR0 = EA_W4B_BAR0, DEV = EA_W4B_DMA_EVERY;
-    static_assert(BAR0 >= 16 && BAR0 + 1 + 7 * DEV < 128, "EA_W4B_BAR0 / EA_W4B_DMA_EVERY: the eight piece pairs must fit behind the barrier");
+    static_assert(BAR0 >= 16 && BAR0 + 1 + 15 * DEV < 64, "EA_W4B_BAR0 / EA_W4B_DMA_EVERY: the sixteen requests must fit between the barrier and the end of step 0");
     unsigned so = 0;
     for (int t = 0; t < nk; ++t) {
         const bool issue = t + 2 < nk;                       // wave-uniform
         const int kb2 = (t + 2) * (BK * 2);                  // byte offset of tile t + 2 along K
-        // slots 0 .. 63: step 0 (MFMAs on buffer 0), 64 .. 127: step 1 (buffer 1)
+        // step 0: MFMAs on buffer 0 (two loops of 64 slots: one of 128 is past hipcc's full-unroll size limit)
 #pragma unroll
-        for (int n = 0; n < 128; ++n) {
+        for (int n = 0; n < 64; ++n) {
             if (n < 16) { EA_W4_READ1(1, so, 1, n) }                          // the k-step-1 fragments of tile t
             if (n == BAR0) {                                                   // every wave holds all of tile t in registers
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if (n > BAR0 && (n - BAR0 - 1) % DEV == 0 && (n - BAR0 - 1) / DEV < 8 && issue)
-                EA_W4B_ISSUE1(so, (n - BAR0 - 1) / DEV, kb2)                   // tile t + 2 -> the stage tile t leaves
-            if (n == 64) {                                                     // tile t + 1 complete (own pieces, then everyone's)
-                if (issue && BAR0 + 1 + 7 * DEV < 64) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            if (n >= 64 && n < 80) { EA_W4_READ1(0, so ^ OPER2, 0, n - 64) }  // the first fragments of tile t + 1
-            if (n < 64) { EA_W4_MFMA1(0, n) } else { EA_W4_MFMA1(1, n - 64) }
+            if (n > BAR0 && (n - BAR0 - 1) % DEV == 0 && (n - BAR0 - 1) / DEV < 16 && issue)
+                EA_W4B_ISSUEH(so, (n - BAR0 - 1) / DEV, kb2)                   // tile t + 2 -> the stage tile t leaves
+            EA_W4_MFMA1(0, n)
+        }
+        // step 1: MFMAs on buffer 1; tile t + 1 complete (own pieces, then everyone's)
+        if (issue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int n = 0; n < 64; ++n) {
+            if (n < 16) { EA_W4_READ1(0, so ^ OPER2, 0, n) }                  // the first fragments of tile t + 1
+            EA_W4_MFMA1(1, n)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         so ^= OPER2;
     }
 #undef EA_W4B_ISSUE1
+#undef EA_W4B_ISSUEH
   }
     // the last MFMAs' results must have left the pipe before the epilogue reads the accumulators (inline asm: the hazard
     // recogniser does not see the producer)
