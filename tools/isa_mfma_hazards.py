@@ -2,7 +2,7 @@
 largest loop, for every MFMA that writes arch VGPRs, the number of instructions / MFMAs up to the first later instruction
 that READS one of those registers (VALU, memory, another MFMA as A / B), and for every VALU write of a register that a
 later MFMA reads, the distance to that MFMA; and the reverse (MFMA reads a register, a later VALU overwrites it).
-    python tools/isa_mfma_hazards.py /tmp/att_v4.s attention_fwd_v4_kernel
+    python tools/isa_mfma_hazards.py /tmp/att_v4.s attention_fwd_v4_kernel [first_label last_label]
 Walks the basic blocks that contain MFMAs in layout order as one cyclic instruction stream (the tile loop)."""
 import re
 import sys
@@ -16,12 +16,18 @@ def regs(tok):
     return {(m.group(1), int(m.group(2)))} if m else set()
 
 
-def main(path, kernel):
+def main(path, kernel, first=None, last=None):
     s = open(path).read()
     m = re.search(r'\n(_Z\S*' + kernel + r'\S*?):[^\n]*\n(.*?)\.Lfunc_end', s, re.S)
     blocks = re.split(r'\n(?=\.LBB\d+_\d+:)', m.group(2))
-    loop = [b for b in blocks if len(re.findall(r'v_mfma', b)) >= 8][1:]     # skip the prologue block
-    loop = [b for b in loop if 'v_exp_f32' in b or 'ds_read' in b]
+    if first:     # explicit range of labels, e.g. .LBB7_11 .LBB7_10 (layout order; the loop may end in front of its head)
+        names = [b.split(':')[0] for b in blocks]
+        a, z = names.index(first), names.index(last)
+        loop = blocks[a:z + 1] if a <= z else blocks[a:] + blocks[:z + 1]
+        loop = [b for b in loop if 'v_mfma' in b or 'ds_read' in b or 'buffer_load' in b]
+    else:
+        loop = [b for b in blocks if len(re.findall(r'v_mfma', b)) >= 8][1:]     # skip the prologue block
+        loop = [b for b in loop if 'v_exp_f32' in b or 'ds_read' in b]
     ins = []
     for b in loop:
         for l in b.split('\n'):
@@ -95,4 +101,4 @@ def main(path, kernel):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:5])
