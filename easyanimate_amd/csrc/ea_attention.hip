@@ -445,7 +445,12 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
             const int nqb4 = (q_end - q_begin + ATT4_QB - 1) / ATT4_QB;
             const int64_t blocks4 = (int64_t)((bh + 7) / 8) * nqb4 * 8;
             ea_count("attention_v4");
-            hipLaunchKernelGGL(attention_fwd_v4_kernel, dim3((unsigned)blocks4), blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride,
+            static bool attr4_done = false;
+            if (!attr4_done) {
+                (void)hipFuncSetAttribute((const void*)attention_fwd_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS);
+                attr4_done = true;
+            }
+            hipLaunchKernelGGL(attention_fwd_v4_kernel, dim3((unsigned)blocks4), blk, ATT4_LDS, st, q, k, vt, o16, out_batch_stride,
                                heads, bh, kv_end, s_pad, q_begin, q_end, nqb4);
             return ea_check_launch("ea_attention_fwd");
         }
