@@ -1,6 +1,10 @@
+"""Instruction mix of the basic block with the most MFMAs of one kernel in a device assembly file (hipcc --cuda-device-only -S;
+tools/build_variants.sh leaves /tmp/<source>_<TAG>.s):
+    python tools/isa_hot_block.py /tmp/ea_attention_V4F2.s V4F2 [kernel-name substring, default attention_fwd_v3_kernelILi0ELb0E]"""
 import sys,re,collections
 s=open(sys.argv[1]).read()
-m=re.search(r'\n(_ZN\S*attention_fwd_v3_kernelILi0ELb0E\S*?):[^\n]*\n(.*?)\.Lfunc_end', s, re.S)
+kern=sys.argv[3] if len(sys.argv) > 3 else 'attention_fwd_v3_kernelILi0ELb0E'
+m=re.search(r'\n(_ZN\S*' + kern + r'\S*?):[^\n]*\n(.*?)\.Lfunc_end', s, re.S)
 body=m.group(2)
 blocks=re.split(r'\n(?=\.LBB\d+_\d+:)', body)
 best=max(blocks,key=lambda b:len(re.findall(r'v_mfma',b)))
