@@ -383,3 +383,33 @@ def test_attention_v4_stage_bookkeeping_model():
     spec.loader.exec_module(mod)
     bad = [e for NS in (2, 4) for nt in range(1, 9) for early in (False, True) for e in mod.run(NS, nt, early)]
     assert not bad, bad[:3]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/easyanimate"), reason="/root/reference not present (GPU box)")
+def test_pipeline_rope_matches_the_reference_call_site_for_random_shapes():
+    """EasyAnimatePipeline.rotary_embedding(height, width, latent_frames) against the reference's own call site
+    (pipeline_easyanimate.py:999-1011: grid = size // 8 // patch, base 720 x 480, get_resize_crop_region_for_grid ->
+    get_3d_rotary_pos_embed) for random sizes -- the published 384 x 672 / 576 x 1008 / 768 x 1344 among them."""
+    import types
+    from hypothesis import given, settings, strategies as st
+    from oracle import ref_loader
+    from easyanimate_amd.pipeline import EasyAnimatePipeline
+    ns = ref_loader.load()
+    cfg = types.SimpleNamespace(patch_size=2, attention_head_dim=64)
+    pipe = EasyAnimatePipeline(vae=None, transformer=types.SimpleNamespace(config=cfg, device=torch.device("cpu")), scheduler=None)
+
+    def check(height, width, frames):
+        gh, gw = height // 8 // 2, width // 8 // 2
+        cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((gh, gw), 720 // 8 // 2, 480 // 8 // 2)
+        cos_r, sin_r = ns.shim.get_3d_rotary_pos_embed(64, cc, grid_size=(gh, gw), temporal_size=frames, use_real=True)
+        cos, sin = pipe.rotary_embedding(height, width, frames)
+        assert cos.shape == (frames * gh * gw, 64) and torch.equal(cos, cos_r) and torch.equal(sin, sin_r)
+
+    for h, w in ((384, 672), (576, 1008), (768, 1344), (1024, 1024), (256, 256)):
+        check(h, w, 13)
+
+    @settings(max_examples=40, deadline=None)
+    @given(h=st.integers(2, 40), w=st.integers(2, 60), f=st.integers(1, 13))
+    def prop(h, w, f):
+        check(16 * h, 16 * w, f)
+    prop()
