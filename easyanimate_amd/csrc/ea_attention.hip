@@ -450,8 +450,20 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
                 (void)hipFuncSetAttribute((const void*)attention_fwd_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS);
                 attr4_done = true;
             }
+            // one flag per 256-query block of v3's grid, cleared on the stream in front of v4, read by the fix-up pass behind it
+            static int* redo = nullptr;
+            static int64_t redo_cap = 0;
+            const int64_t need = (int64_t)bh * nqb;
+            if (need > redo_cap) {
+                if (redo) (void)hipFree(redo);
+                EA_REQUIRE(hipMalloc(&redo, (size_t)need * sizeof(int)) == hipSuccess, "ea_attention_fwd: flag buffer");
+                redo_cap = need;
+            }
+            (void)hipMemsetAsync(redo, 0, (size_t)need * sizeof(int), st);
             hipLaunchKernelGGL(attention_fwd_v4_kernel, dim3((unsigned)blocks4), blk, ATT4_LDS, st, q, k, vt, o16, out_batch_stride,
-                               heads, bh, kv_end, s_pad, q_begin, q_end, nqb4);
+                               heads, bh, kv_end, s_pad, q_begin, q_end, nqb4, redo, nqb);
+            hipLaunchKernelGGL((attention_fwd_v3_kernel<0, false, true>), grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads,
+                               bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4, AttSegments(), (const int*)redo);
             return ea_check_launch("ea_attention_fwd");
         }
 #endif

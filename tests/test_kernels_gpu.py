@@ -812,6 +812,39 @@ def test_attention_v4_experiment(B, H, S):
     assert (d <= tol).all()
 
 
+@pytest.mark.parametrize("amp", [0.02, 1.0, 30.0])
+def test_attention_v4_fixup_pass(amp):
+    """The v4 experiment has no rescale path of its own: a wave whose queries end with a row sum outside [2^-60, 2^100) flags its
+    block of 256 queries and v3 redoes the flagged blocks right behind.  Same inputs as test_attention_folded_leaves_raw_mode:
+    scores scaled to +- a few (nothing flagged), to hundreds (exp2 overflows: head 0 / every key of a query far below zero until
+    a late block: head 1)."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    _needs_variants()
+    B, H, S = 1, 3, 1000
+    q, k, vt, v = _attn_inputs(B, H, S, 37)
+    q = (q.float() * amp).to(torch.bfloat16)
+    for (qq, kk, a) in [(3, 40, 3.0), (3, 70, 2.5), (17, 31, 4.0), (200, 999, 9.0), (777, 960, 5.0), (64, 0, 6.0)]:
+        k[:, 0, kk] = (q[:, 0, qq].float() / max(amp, 1e-3) * a).to(torch.bfloat16)
+    d = torch.ones(64, device=DEV)
+    q[:, 1, :S] = (d * 2.0 * amp).to(torch.bfloat16)
+    k[:, 1, :S] = (-d * 1.5 + 0.05 * torch.randn(S, 64, device=DEV)).to(torch.bfloat16)
+    k[:, 1, 900:905] = (d * 0.5).to(torch.bfloat16)
+    qs = _fold(q)
+    try:
+        _lib.set_option("attn_variant", 4)
+        _lib.reset_counters()
+        out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+        assert _lib.counters().get("attention_v4", 0) == 1
+    finally:
+        _lib.set_option("attn_variant", 3)
+    ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
+    assert torch.isfinite(out.float()).all()
+    for h in range(H):
+        err, rel = _report(f"attention v4 + fix-up amp {amp} head{h}", out[:, :, h * 64:(h + 1) * 64], ref[:, :, h * 64:(h + 1) * 64])
+        assert rel < 8e-3 and err < 0.05, (h, err, rel)
+
+
 def test_patchify_unpatchify_cfg_euler():
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(17)
