@@ -181,7 +181,9 @@ class EasyAnimateAttnProcessor2_0:
             nonlocal pending
             lq, lk, lv = mod.to_q, mod.to_k, mod.to_v
             nq, nk = mod.norm_q, mod.norm_k
-            if self.fuse_qkv and ops.qkv_fused_ok(n_tok, d, inp.shape[2], seq_off):
+            # (under sequence parallelism a ragged shard keeps the three-GEMM route until the fused kernel's ragged tile has been
+            # run together with its kv_off / K | V-first forms on a GPU: tests/test_kernels_gpu.py covers the two separately)
+            if self.fuse_qkv and ops.qkv_fused_ok(n_tok, d, inp.shape[2], seq_off) and (lay is None or n_tok % 256 == 0):
                 # one launch: the [B, n, 3d] QKV buffer never exists (ea_qkv_gemm_norm_rope_bf16) -- or two, K | V first
                 args = (inp, gemm_weight(lq.weight), gemm_weight(lk.weight), gemm_weight(lv.weight),
                         f32(lq.bias), f32(lk.bias), f32(lv.bias), ws["q"], ws["k"], ws["vt"],
