@@ -67,17 +67,16 @@ extern "C" const char* ea_last_dispatch(void) { return g_last; }
 extern "C" void ea_reset_counters(void) {
     for (int i = 0; i < g_ncounters; ++i) g_counters[i].n = 0;
 }
-extern "C" int ea_version(void) { return 110; }   // 110: K / V^T geometry + parts in the QKV entry points, first / used rows in the segment attention
+extern "C" int ea_version(void) { return 111; }   // 111: the default library requires the softmax scale folded into Q (ea_attention_fwd*); 110: K / V^T geometry + parts in the QKV entry points
 
 // Tuning / benchmarking switches.  Each kernel file owns its switch; results never depend on them.
 #define EA_OPTION(n) int ea_##n##_set(int v); int ea_##n##_get();
 EA_OPTION(gemm_tile)      // ea_gemm.hip:      0 (auto) | 128 | 256
 EA_OPTION(gemm_mfma)      // ea_gemm.hip:      16 | 32
-EA_OPTION(gemm_w4)        // ea_gemm.hip:      0 | 1  (four-wave 128x128-wave-tile kernel for the 256^2 tiles)
 EA_OPTION(conv_mfma)      // ea_conv.hip:      16 | 32
 EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
 EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1
-EA_OPTION(attn_variant)   // ea_attention.hip: 1 | 2
+EA_OPTION(attn_variant)   // ea_attention.hip: 3 (EA_BUILD_VARIANTS=1 libraries: also 1 | 2)
 #undef EA_OPTION
 // read-only: was this library built with EA_BUILD_VARIANTS=1 (the cross-check kernel generations are present)?
 int ea_build_variants_get() { return EA_BUILD_VARIANTS; }
@@ -85,7 +84,7 @@ int ea_build_variants_set(int v) { return v == EA_BUILD_VARIANTS ? 0 : -1; }
 namespace {
 struct Option { const char* name; int (*set)(int); int (*get)(); };
 #define EA_OPTION(n) {#n, ea_##n##_set, ea_##n##_get}
-const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(gemm_w4), EA_OPTION(conv_mfma),
+const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(conv_mfma),
                             EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(attn_variant), EA_OPTION(build_variants)};
 #undef EA_OPTION
 const Option* find_option(const char* name) {

@@ -375,17 +375,20 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     }
 }
 
-#include "ea_attention_v2.inc"
-#include "ea_attention_v3.inc"
+// RAW mode (P = exp2 of the raw score, no shift) is exact while a query's block row sums stay inside [2^-60, 2^60)
+constexpr float ATT_BIG = 1.152921504606846976e18f;   // 2^60
+constexpr float ATT_TINY = 8.673617379884035e-19f;    // 2^-60
+int g_attn_variant = 3;  // ea_set_option("attn_variant", 3): v3 (16x16x32 MFMA); EA_BUILD_VARIANTS=1 libraries also carry 2 = v2 (32x32x16) and 1 = the first, un-pipelined kernel
 #if EA_BUILD_VARIANTS
-#include "ea_attention_v4.inc"
+#include "ea_attention_v2.inc"   // the 32x32x16 generation (and the only one that takes an un-folded softmax scale): cross-check builds only
 #endif
+#include "ea_attention_v3.inc"
 
 }  // namespace
 
 int ea_attn_variant_get() { return g_attn_variant; }
 int ea_attn_variant_set(int v) {
-    if (v != 2 && v != 3 && !((v == 1 || v == 4) && EA_BUILD_VARIANTS)) return -1;   // v1 / the v4 experiment: EA_BUILD_VARIANTS=1 libraries only
+    if (v != 3 && !((v == 1 || v == 2) && EA_BUILD_VARIANTS)) return -1;   // v1 / v2 (the cross-check generations): EA_BUILD_VARIANTS=1 libraries only
     g_attn_variant = v;
     return 0;
 }
@@ -419,8 +422,13 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     EA_REQUIRE(kv_begin % ATT_KV == 0, "ea_attention_fwd: kv_begin must be a multiple of 64");
     EA_REQUIRE((flags & ~3) == 0 && (flags == 0 || state), "ea_attention_fwd: bad flags / missing state buffer");
     if (q_end == q_begin) return EA_OK;
+    // scale * log2(e) == 1: the caller folded the softmax scale into Q (q_scale of ea_qkv_gemm_norm_rope_bf16 / ea_qknorm_rope_bf16)
+    const bool folded = fabsf(scale * 1.4426950408889634f - 1.0f) < 1e-6f;
+#if !EA_BUILD_VARIANTS
+    EA_REQUIRE(folded, "ea_attention_fwd: the softmax scale must be folded into Q (q_scale = scale * log2(e) at the projection, scale = "
+                       "1 / log2(e) here); the kernel generation that multiplies every score is built with EA_BUILD_VARIANTS=1 only");
+#endif
     const bool plain = flags == 0 && kv_begin == 0;
-    const int variant = plain ? g_attn_variant : (g_attn_variant >= 3 ? 3 : 2);   // key ranges / resumable state: v2 / v3 only
     const int nqb = (q_end - q_begin + ATT_QB - 1) / ATT_QB;
     const int bh = batch * heads;
     const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
@@ -431,63 +439,44 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     unsigned short* o16 = (unsigned short*)out;
     f32x4* st4 = reinterpret_cast<f32x4*>(state);
 #if EA_BUILD_VARIANTS
+    const int variant = plain ? g_attn_variant : (g_attn_variant >= 3 ? 3 : 2);   // key ranges / resumable state: v2 / v3 only
     if (variant == 1) {
         ea_count("attention_v1");
         hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads, bh, kv_end,
                            s_pad, q_begin, q_end, nqb, scale_log2e, 0);
-    } else
-#endif
-    {
-        // scale * log2(e) == 1: the caller folded the softmax scale into Q (ea_qknorm_rope_bf16 q_scale)
-        const bool folded = fabsf(scale_log2e - 1.0f) < 1e-6f;
-#if EA_BUILD_VARIANTS
-        if (variant == 4 && folded) {   // the one-wave-per-SIMD experiment: plain calls with the scale folded into Q only
-            const int nqb4 = (q_end - q_begin + ATT4_QB - 1) / ATT4_QB;
-            const int64_t blocks4 = (int64_t)((bh + 7) / 8) * nqb4 * 8;
-            ea_count("attention_v4");
-            static bool attr4_done = false;
-            if (!attr4_done) {
-                (void)hipFuncSetAttribute((const void*)attention_fwd_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS);
-                attr4_done = true;
-            }
-            // one flag per 256-query block of v3's grid, cleared on the stream in front of v4, read by the fix-up pass behind it
-            static int* redo = nullptr;
-            static int64_t redo_cap = 0;
-            const int64_t need = (int64_t)bh * nqb;
-            if (need > redo_cap) {
-                if (redo) (void)hipFree(redo);
-                EA_REQUIRE(hipMalloc(&redo, (size_t)need * sizeof(int)) == hipSuccess, "ea_attention_fwd: flag buffer");
-                redo_cap = need;
-            }
-            (void)hipMemsetAsync(redo, 0, (size_t)need * sizeof(int), st);
-            hipLaunchKernelGGL(attention_fwd_v4_kernel, dim3((unsigned)blocks4), blk, ATT4_LDS, st, q, k, vt, o16, out_batch_stride,
-                               heads, bh, kv_end, s_pad, q_begin, q_end, nqb4, redo, nqb);
-            hipLaunchKernelGGL((attention_fwd_v3_kernel<0, false, true>), grid, blk, ATT_LDS, st, q, k, vt, o16, out_batch_stride, heads,
-                               bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4, AttSegments(), (const int*)redo);
-            return ea_check_launch("ea_attention_fwd");
-        }
-#endif
-        const int variant23 = variant == 4 ? 3 : variant;
-        ea_count(variant23 == 3 && folded ? "attention_v3" : "attention_v2");
-#define EA_ATT_LAUNCH(MODE, FOLDED)                                                                                       \
-    if (variant23 == 3 && FOLDED)                                                                                         \
-        hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid, blk, ATT_LDS, st, q, k, vt, o16,                         \
-                           out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4);  \
-    else                                                                                                                  \
+        return ea_check_launch("ea_attention_fwd");
+    }
+    if (variant != 3 || !folded) {
+        ea_count("attention_v2");
+#define EA_ATT_LAUNCH2(MODE, FOLDED)                                                                                      \
         hipLaunchKernelGGL((attention_fwd_v2_kernel<MODE, FOLDED>), grid, blk, ATT_LDS, st, q, k, vt, o16,                 \
                            out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4)
         switch (flags * 2 + (folded ? 1 : 0)) {
-            case 0: EA_ATT_LAUNCH(0, false); break;
-            case 1: EA_ATT_LAUNCH(0, true); break;
-            case 2: EA_ATT_LAUNCH(1, false); break;
-            case 3: EA_ATT_LAUNCH(1, true); break;
-            case 4: EA_ATT_LAUNCH(2, false); break;
-            case 5: EA_ATT_LAUNCH(2, true); break;
-            case 6: EA_ATT_LAUNCH(3, false); break;
-            default: EA_ATT_LAUNCH(3, true); break;
+            case 0: EA_ATT_LAUNCH2(0, false); break;
+            case 1: EA_ATT_LAUNCH2(0, true); break;
+            case 2: EA_ATT_LAUNCH2(1, false); break;
+            case 3: EA_ATT_LAUNCH2(1, true); break;
+            case 4: EA_ATT_LAUNCH2(2, false); break;
+            case 5: EA_ATT_LAUNCH2(2, true); break;
+            case 6: EA_ATT_LAUNCH2(3, false); break;
+            default: EA_ATT_LAUNCH2(3, true); break;
         }
-#undef EA_ATT_LAUNCH
+#undef EA_ATT_LAUNCH2
+        return ea_check_launch("ea_attention_fwd");
     }
+#endif
+    (void)plain;
+    ea_count("attention_v3");
+#define EA_ATT_LAUNCH(MODE)                                                                                               \
+    hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid, blk, ATT_LDS, st, q, k, vt, o16,                             \
+                       out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4)
+    switch (flags) {
+        case 0: EA_ATT_LAUNCH(0); break;
+        case 1: EA_ATT_LAUNCH(1); break;
+        case 2: EA_ATT_LAUNCH(2); break;
+        default: EA_ATT_LAUNCH(3); break;
+    }
+#undef EA_ATT_LAUNCH
     return ea_check_launch("ea_attention_fwd");
 }
 

@@ -300,9 +300,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #ifdef EA_GEMM_TIMESTAMPS
 __device__ unsigned long long* g_gemm_ts = nullptr;   // diagnostic builds: per-workgroup s_memtime stamps
 #endif
-#ifndef EA_GEMM_W4_DEFAULT
-#define EA_GEMM_W4_DEFAULT 0
-#endif
 constexpr int OPER2 = 256 * 128;   // one operand tile, 32 KiB
 constexpr int GEMM2_LDS = 4 * OPER2;
 
@@ -778,302 +775,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
 }
 
 // =================================================================================================
-// 256 x 256 x 64 tiles with FOUR waves, one per SIMD, each owning a 128 x 128 wave tile: 8 x 8 MFMA tiles of 16 x 16 =
-// 256 accumulator registers, which live in the AGPR half of the wave's 512-register file (the MFMA reads and writes them
-// there; nothing else touches them until the epilogue).  Per k32 step a wave reads 8 W + 8 activation fragments for 64
-// MFMAs -- 0.25 ds_read_b128 per MFMA against 0.375 for the eight-wave kernel's 128 x 64 wave tiles -- and each fragment
-// feeds 8 MFMAs instead of 4 / 8: less LDS traffic and less operand-fetch energy per flop, which is what bounds a
-// power-limited GEMM.  There is no second wave on a SIMD to cover LDS latency, so the wave pipelines
-// itself: the fragments of step s + 1 are read (into the other half of a register double buffer) in the shadow of the 64
-// MFMAs of step s, one ds_read per four MFMAs; the K tile after next is requested by LDS-DMA right behind the one barrier
-// per K tile (a whole tile time before it is needed).  Stage hand-over: the barrier at the start of step 1 of tile t is
-// passed by a wave only after its reads of tile t's stage have returned (they feed step 1), so behind it that stage is free
-// for tile t + 2, and every wave waited for its own pieces of tile t + 1 (vmcnt) before arriving, so tile t + 1 is complete.
-// Same LDS layout / swizzle / DMA source addressing / C^T orientation / epilogue image as gemm256_mi16_kernel.
-// SCHED = 1 (ea_set_option("gemm_w4", 2)): the second main-loop schedule of this kernel, see the comment in front of it.
-#ifndef EA_W4B_BAR0
-#define EA_W4B_BAR0 32        // MFMA slot of step 0 in front of which "this tile's stage is consumed" is synchronised
-#endif
-#ifndef EA_W4B_DMA_EVERY
-#define EA_W4B_DMA_EVERY 2    // one DMA request (1 KiB piece of one operand) of tile t + 2 every this many MFMA slots behind that point
-#endif
-template <int EPI, int SCHED = 0>
-__global__ __launch_bounds__(256) void gemm256_w4_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int lr = lane & 15, lq = lane >> 4;
-
-    int tm, tn;
-    if (!tile_of_block(p, tm, tn)) return;
-    const int b = blockIdx.y;
-    const int row0 = tm * 256, col0 = tn * 256;
-    const unsigned short* Ab = p.A + b * p.abs_;
-
-    // DMA pieces: a K tile of an operand is 256 rows x 128 bytes = 32 pieces of 1 KiB; wave w stages pieces 8w .. 8w+7
-    const unsigned short* asrc[8];
-    const unsigned short* wsrc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = (wave * 8 + i) * 8 + (lane >> 3), c = lane & 7;
-        const int cs = c ^ (r & 7);
-        int ra = row0 + r;
-        ra = ra < p.M ? ra : p.M - 1;
-        int rw = col0 + r;
-        rw = rw < p.N ? rw : p.N - 1;
-        asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
-        wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
-    }
-    char* const dma_a = smem + wave * 8192;
-    char* const dma_w = smem + 2 * OPER2 + wave * 8192;
-
-    f32x4_t acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-    unsigned a_k[2], w_k[2];
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-        w_k[ks2] = 2 * OPER2 + (wc * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-    }
-    const int nk = p.K / BK;
-
-    bf16x8 fa[2][8], fw[2][8];
-    // The accumulators are pinned to the AGPR file by the operand constraint ("+a": in-place accumulate): left to itself
-    // hipcc allocates part of them in arch VGPRs and shuffles ~220 v_accvgpr copies per K tile through the loop.  The asm
-    // statements are volatile, i.e. scheduling barriers: the instruction order of the loop is the source order below.
-#define EA_W4_MFMA1(BUF, N)                                                                                       \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                        \
-                 : "+a"(acc[(N) & 7][(N) >> 3]) : "v"(fw[BUF][(N) >> 3]), "v"(fa[BUF][(N) & 7]));
-    // fragment x of K step KS -> buffer BUF from the stage at byte offset SOFF: even x = W fragment x / 2, odd x = activation
-    // fragment x / 2
-#define EA_W4_READ1(BUF, SOFF, KS, X)                                                                             \
-    if (((X) & 1) == 0) fw[BUF][(X) >> 1] = *reinterpret_cast<const bf16x8*>(smem + (w_k[KS] + (SOFF) + ((X) >> 1) * 2048)); \
-    else fa[BUF][(X) >> 1] = *reinterpret_cast<const bf16x8*>(smem + (a_k[KS] + (SOFF) + ((X) >> 1) * 2048));
-    // DMA piece x (0..7) of both operands of the next K tile into the stage at SOFF (the source pointers advance by one tile)
-#define EA_W4_ISSUE1(SOFF, X)                                                                                     \
-    {                                                                                                             \
-        asrc[X] += BK;                                                                                            \
-        wsrc[X] += BK;                                                                                            \
-        glds16(asrc[X], dma_a + (SOFF) + (X) * 1024);                                                             \
-        glds16(wsrc[X], dma_w + (SOFF) + (X) * 1024);                                                             \
-    }
-    // one k32 step: 64 MFMAs on buffer BUFC in 16 groups of four.  Groups 1..8 are each preceded by two fragment reads into
-    // buffer BUFL: all 16 are issued in the first half of the step and have returned when it ends (the closing lgkmcnt(0)
-    // is free, and nothing is in flight when the next step's first MFMAs wait for THEIR fragments); the odd groups by one DMA
-    // piece pair of the K tile after next (ISSUE, wave-uniform)
-#define EA_W4_STEP(BUFC, BUFL, SOFF_L, KS_L, ISSUE, SOFF_I)                                                       \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                              \
-        if (g >= 1 && g <= 8) {                                                                                   \
-            EA_W4_READ1(BUFL, SOFF_L, KS_L, 2 * (g - 1))                                                          \
-            EA_W4_READ1(BUFL, SOFF_L, KS_L, 2 * (g - 1) + 1)                                                      \
-        }                                                                                                         \
-        if ((g & 1) && (ISSUE)) EA_W4_ISSUE1(SOFF_I, g >> 1)                                                      \
-        EA_W4_MFMA1(BUFC, g * 4 + 0)                                                                              \
-        EA_W4_MFMA1(BUFC, g * 4 + 1)                                                                              \
-        EA_W4_MFMA1(BUFC, g * 4 + 2)                                                                              \
-        EA_W4_MFMA1(BUFC, g * 4 + 3)                                                                              \
-    }                                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  if (SCHED == 0) {
-    // ---- prologue: tile 0 -> stage 0, its first fragments -> buffer 0, tile 1 -> stage 1
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        glds16(asrc[i], dma_a + i * 1024);
-        glds16(wsrc[i], dma_w + i * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (nk > 1) {
-#pragma unroll
-        for (int x = 0; x < 8; ++x) EA_W4_ISSUE1(OPER2, x)
-    }
-#pragma unroll
-    for (int x = 0; x < 16; ++x) { EA_W4_READ1(0, 0, 0, x) }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- ONE loop body for every K tile (the MFMA code exists once: no second copy whose register assignment the compiler
-    // would have to reconcile with copies -- it cannot see that an asm statement is an MFMA whose result needs wait states).
-    // Tile t lives in the stage at `so` (0 / OPER2, toggled).  Step 0: MFMAs on buffer 0 while its step-1 fragments -> buffer
-    // 1.  Then "tile t + 1 complete, this tile's stage free" (own pieces by vmcnt, the others' by the barrier).  Step 1: MFMAs
-    // on buffer 1 while the first fragments of tile t + 1 -> buffer 0 (after the last tile: a harmless read of stale LDS)
-    // and tile t + 2 -> this tile's stage.
-    unsigned so = 0;
-    for (int t = 0; t < nk; ++t) {
-        const bool issue = t + 2 < nk;                       // wave-uniform
-        EA_W4_STEP(0, 1, so, 1, false, 0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        EA_W4_STEP(1, 0, so ^ OPER2, 0, issue, so)
-        so ^= OPER2;
-    }
-  } else {
-    // ---- second schedule (round 3, after reading how a one-wave-per-SIMD main loop has to be fed):
-    //  * every non-MFMA instruction sits alone between two MFMAs (one fragment read per slot, one DMA request every
-    //    EA_W4B_DMA_EVERY slots), never in blocks in front of a group;
-    //  * the DMA is buffer-addressed: per-lane byte offsets fixed for the kernel (16 registers instead of 32 for 64-bit
-    //    pointers), the K tile is the scalar offset -- no vector address arithmetic in the loop;
-    //  * the prefetch distance is two tiles: a stage is consumed (all four k-step fragments of its tile in registers) half
-    //    way through step 0 of its tile -- one barrier -- and tile t + 2 is requested right behind that point, a step and a
-    //    half earlier than in the first schedule; at the step-1 barrier a wave waits with vmcnt(16): its pieces of tile t + 1
-    //    (requested two and a half steps ago) have landed, those of tile t + 2 stay in flight.
-    int aoff[8], woff[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = (wave * 8 + i) * 8 + (lane >> 3), c = lane & 7;
-        const int cs = c ^ (r & 7);
-        const int ra = (row0 + r < p.M ? row0 + r : p.M - 1) - row0;
-        const int rw = (col0 + r < p.N ? col0 + r : p.N - 1) - col0;
-        aoff[i] = (int)((int64_t)ra * p.lda * 2) + cs * 16;
-        woff[i] = rw * p.K * 2 + cs * 16;
-    }
-    const unsigned short* Abase = Ab + (int64_t)row0 * p.lda;
-    const unsigned short* Wbase = p.W + (int64_t)col0 * p.K;
-    const int a_rows = p.M - row0 < 256 ? p.M - row0 : 256, w_rows = p.N - col0 < 256 ? p.N - col0 : 256;
-    const int a_ext = (int)((((int64_t)a_rows - 1) * p.lda + p.K) * 2);      // bytes reachable from Abase / Wbase
-    const int w_ext = ((w_rows - 1) * p.K + p.K) * 2;
-    // half-piece Q (0..15): even = activation piece Q / 2, odd = weight piece Q / 2 -- ONE request per MFMA slot in the loop
-#define EA_W4B_ISSUEH(SOFF, Q, KB)                                                                                \
-    {                                                                                                             \
-        if (((Q) & 1) == 0) bdma16g(Abase, a_ext, aoff[(Q) >> 1], KB, dma_a + (SOFF) + ((Q) >> 1) * 1024);      \
-        else bdma16g(Wbase, w_ext, woff[(Q) >> 1], KB, dma_w + (SOFF) + ((Q) >> 1) * 1024);                      \
-    }
-#define EA_W4B_ISSUE1(SOFF, X, KB)                                                                                \
-    {                                                                                                             \
-        EA_W4B_ISSUEH(SOFF, 2 * (X), KB)                                                                          \
-        EA_W4B_ISSUEH(SOFF, 2 * (X) + 1, KB)                                                                      \
-    }
-#pragma unroll
-    for (int x = 0; x < 8; ++x) EA_W4B_ISSUE1(0, x, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (nk > 1) {
-#pragma unroll
-        for (int x = 0; x < 8; ++x) EA_W4B_ISSUE1(OPER2, x, BK * 2)
-    }
-#pragma unroll
-    for (int x = 0; x < 16; ++x) { EA_W4_READ1(0, 0, 0, x) }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int BAR0 = EA_W4B_BAR0, DEV = EA_W4B_DMA_EVERY;
-    static_assert(BAR0 >= 16 && BAR0 + 1 + 15 * DEV < 64, "EA_W4B_BAR0 / EA_W4B_DMA_EVERY: the sixteen requests must fit between the barrier and the end of step 0");
-    unsigned so = 0;
-    for (int t = 0; t < nk; ++t) {
-        const bool issue = t + 2 < nk;                       // wave-uniform
-        const int kb2 = (t + 2) * (BK * 2);                  // byte offset of tile t + 2 along K
-        // step 0: MFMAs on buffer 0 (two loops of 64 slots: one of 128 is past hipcc's full-unroll size limit)
-#pragma unroll
-        for (int n = 0; n < 64; ++n) {
-            if (n < 16) { EA_W4_READ1(1, so, 1, n) }                          // the k-step-1 fragments of tile t
-            if (n == BAR0) {                                                   // every wave holds all of tile t in registers
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            if (n > BAR0 && (n - BAR0 - 1) % DEV == 0 && (n - BAR0 - 1) / DEV < 16 && issue)
-                EA_W4B_ISSUEH(so, (n - BAR0 - 1) / DEV, kb2)                   // tile t + 2 -> the stage tile t leaves
-            EA_W4_MFMA1(0, n)
-        }
-        // step 1: MFMAs on buffer 1; tile t + 1 complete (own pieces, then everyone's)
-        if (issue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int n = 0; n < 64; ++n) {
-            if (n < 16) { EA_W4_READ1(0, so ^ OPER2, 0, n) }                  // the first fragments of tile t + 1
-            EA_W4_MFMA1(1, n)
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        so ^= OPER2;
-    }
-#undef EA_W4B_ISSUE1
-#undef EA_W4B_ISSUEH
-  }
-    // the last MFMAs' results must have left the pipe before the epilogue reads the accumulators (inline asm: the hazard
-    // recogniser does not see the producer)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#undef EA_W4_MFMA1
-#undef EA_W4_READ1
-#undef EA_W4_ISSUE1
-#undef EA_W4_STEP
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the LDS becomes the epilogue images
-
-    // ---- epilogue: the wave's 128 x 128 tile as two 128 x 64 halves through its private 16 KiB image (rows = output rows,
-    // 128 B = 64 columns, 16-byte chunks XOR-swizzled with (row >> 1) & 7), exactly gemm256_mi16_kernel's
-    char* const img = smem + wave * 16384;
-    const int mrow0 = row0 + wr * 128;
-    const int r8 = lane >> 3, c8 = lane & 7;
-    unsigned short* Cb = p.C + b * p.cbs;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int ncol0 = col0 + wc * 128 + h * 64;
-        if (EPI == EA_EPI_BIAS_GATE_RES) {
-            const unsigned short* Rb = p.res + b * p.rbs;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int r = q * 8 + r8;
-                int m = mrow0 + r;
-                m = m < p.M ? m : p.M - 1;
-                int n = ncol0 + ((c8 ^ ((r >> 1) & 7)) << 3);
-                n = n < p.N ? n : 0;
-                glds16(Rb + (int64_t)m * p.ldres + n, img + q * 1024);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float* gb = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs : nullptr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n0 = ncol0 + j * 16 + lq * 4;
-            if (n0 >= p.N) continue;
-            f32x4_t bv = {0.f, 0.f, 0.f, 0.f}, gv = bv;
-            if (p.bias) bv = *reinterpret_cast<const f32x4_t*>(p.bias + n0);
-            if (EPI == EA_EPI_BIAS_GATE_RES) gv = *reinterpret_cast<const f32x4_t*>(gb + n0);
-            const int ch = j * 2 + (lq >> 1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = i * 16 + lr;
-                char* cell = img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq & 1) * 8;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][h * 4 + j][e] + bv[e];
-                if (EPI == EA_EPI_BIAS_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                }
-                if (EPI == EA_EPI_BIAS_GATE_RES) {
-                    const u16x4 rr = *reinterpret_cast<const u16x4*>(cell);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = bf16_bits_to_f32(rr[e]) + gv[e] * v[e];
-                }
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                *reinterpret_cast<u16x4*>(cell) = o;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = q * 8 + r8;
-            const int m = mrow0 + r;
-            const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
-            if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8) = o;
-        }
-    }
-}
-
-// =================================================================================================
 // Fused QKV projection: ONE launch computes q, k, v = Linear_{q,k,v}(x) for a token stream and finishes each
 // (128 tokens x one head) wave tile in its epilogue -- bias, qk-LayerNorm(64), interleaved RoPE, softmax scale on q,
 // head-major scatter of q / k rows, transposed scatter of v -- i.e. processor.py:244-285 without the [B,n,3d] QKV
@@ -1308,7 +1009,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
 }
 
 int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of the 256^2 kernel (32: the first version, kept as cross-check)
-int g_gemm_w4 = EA_GEMM_W4_DEFAULT;   // ea_set_option("gemm_w4", 0 | 1): 1 = the four-wave 128x128-wave-tile kernel serves the bf16-weight 256^2 tiles
 
 template <int EPI, bool W8>
 int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
@@ -1326,21 +1026,6 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done[1] = true;
         }
-#if EA_BUILD_VARIANTS
-        if (g_gemm_w4 && g_gemm_mfma == 16 && !W8 && EPI != EA_EPI_F32_OUT) {
-            static bool attrw4_done = false;
-            if (!attrw4_done) {
-                hipFuncSetAttribute((const void*)gemm256_w4_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)gemm256_w4_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                attrw4_done = true;
-            }
-            // the buffer-addressed schedule needs the tile's operands within 2 GiB of their first row
-            const bool sched1 = g_gemm_w4 == 2 && 256ll * p.lda * 2 + (int64_t)p.K * 2 < (1ll << 31) && 256ll * p.K * 2 < (1ll << 31);
-            ea_count(sched1 ? "gemm_256_w4b" : "gemm_256_w4");
-            if (sched1) hipLaunchKernelGGL((gemm256_w4_kernel<EPI, 1>), grid, dim3(256), lds, st, p);
-            else hipLaunchKernelGGL((gemm256_w4_kernel<EPI, 0>), grid, dim3(256), lds, st, p);
-        } else
-#endif
         if ((g_gemm_mfma == 16 || W8) && EPI != EA_EPI_F32_OUT) {
             static bool attr16_done = false;
             if (!attr16_done) {
@@ -1506,12 +1191,6 @@ int ea_gemm_tile_get() { return g_gemm_tile; }
 int ea_gemm_tile_set(int v) {
     if (v != 0 && v != 128 && v != 256) return -1;
     g_gemm_tile = v;
-    return 0;
-}
-int ea_gemm_w4_get() { return g_gemm_w4; }
-int ea_gemm_w4_set(int v) {
-    if (v != 0 && !((v == 1 || v == 2) && EA_BUILD_VARIANTS)) return -1;   // the four-wave kernel (1: first schedule, 2: second) exists in EA_BUILD_VARIANTS=1 libraries only
-    g_gemm_w4 = v;
     return 0;
 }
 int ea_gemm_mfma_get() { return g_gemm_mfma; }

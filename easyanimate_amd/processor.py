@@ -26,7 +26,7 @@ def _workspace(B: int, H: int, s_pad: int, device) -> dict:
     key = (B, H, s_pad, str(device))
     ws = _ws.get(key)
     if ws is None:
-        for k in [k for k in _ws if k[0] not in ("state", "q")]:  # one live shape at a time keeps the footprint bounded
+        for k in [k for k in _ws if k[0] not in ("state", "q", "heads")]:  # one live shape at a time keeps the footprint bounded
             del _ws[k]
         ws = dict(q=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
                   k=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
@@ -45,6 +45,20 @@ def _workspace_q(B: int, H: int, q_pad: int, device) -> torch.Tensor:
         q = torch.zeros(B, H, q_pad, 64, dtype=torch.bfloat16, device=device)
         _ws[key] = q
     return q
+
+
+def _workspace_heads(B: int, Hl: int, s_pad: int, device):
+    """q / k / v^T of ALL tokens for this rank's heads (head-parallel attention under sequence parallelism), zero-initialised
+    once and reused by every block: rows >= seq are never written."""
+    key = ("heads", B, Hl, s_pad, str(device))
+    w = _ws.get(key)
+    if w is None:
+        for k in [k for k in _ws if k[0] == "heads"]:
+            del _ws[k]
+        w = (torch.zeros(B, Hl, s_pad, 64, dtype=torch.bfloat16, device=device), torch.zeros(B, Hl, s_pad, 64, dtype=torch.bfloat16, device=device),
+             torch.zeros(B, Hl, 64, s_pad, dtype=torch.bfloat16, device=device))
+        _ws[key] = w
+    return w
 
 
 def _attention_state(B: int, H: int, q_end: int, device) -> torch.Tensor:
@@ -87,9 +101,63 @@ class EasyAnimateAttnProcessor2_0:
 
     kv_first = os.environ.get("EA_SP_KV_FIRST", "1") != "0"  # sequence parallel: project K | V first, start the exchange, project Q under it
 
+    def _head_parallel(self, ws, B, H, T, S, d, dev, lay, sp, attend_heads):
+        """Sequence parallelism by HEAD all-to-all (SURVEY 5.7 design C, "Ulysses"): every rank sends the q / k / v^T rows of its
+        token shard for the heads of rank g to rank g, receives the rows of ALL video tokens for its own H / P' heads, runs
+        `attend_heads(qf, kf, vf, Hl, head0, Nt) -> [B, T + Nt, Hl * 64]` on contiguous single-GPU operands (rows = [text 0..T |
+        all Nt video tokens]), and a second all-to-all returns every rank's query rows for all heads.  The replicated text rows
+        are computed by each head's owner and all-gathered, so they are bit-identical on every rank."""
+        P = sp.size
+        if H % P:
+            raise NotImplementedError(f"head-parallel attention under sequence parallelism needs heads ({H}) % sequence ranks ({P}) == 0")
+        Hl, nl, tp, Nt = H // P, lay.n_loc, lay.t_pad, sp.n_total
+        head0 = sp.rank * Hl
+        q, k, vt = ws["q"], ws["k"], ws["vt"]
+        n_own = lay.n_own
+        send = torch.empty(P, 3, B, Hl, nl * 64, dtype=torch.bfloat16, device=dev)
+        sv = send.view(P, 3, B, Hl, nl, 64)
+        sv[:, 0, :, :, :n_own] = q[:, :, tp:tp + n_own].reshape(B, P, Hl, n_own, 64).transpose(0, 1)
+        sv[:, 1, :, :, :n_own] = k[:, :, tp:tp + n_own].reshape(B, P, Hl, n_own, 64).transpose(0, 1)
+        send[:, 2].view(P, B, Hl, 64, nl)[..., :n_own] = vt[:, :, :, tp:tp + n_own].reshape(B, P, Hl, 64, n_own).transpose(0, 1)
+        if n_own != nl:       # a short last shard: the tail of its chunks is never read by the receiver, but must not be garbage on the wire
+            sv[:, :2, :, :, n_own:].zero_()
+            send[:, 2].view(P, B, Hl, 64, nl)[..., n_own:].zero_()
+        recv = sp.all_to_all(send)                                   # [source rank, 3, B, Hl, nl * 64]
+        s_pad = ops.round_up(T + Nt, 256)
+        qf, kf, vf = _workspace_heads(B, Hl, s_pad, dev)             # zero-initialised once; rows >= T + Nt are never written
+        hsl = slice(head0, head0 + Hl)
+        qf[:, :, :T], kf[:, :, :T], vf[:, :, :, :T] = q[:, hsl, :T], k[:, hsl, :T], vt[:, hsl, :, :T]
+        for g in range(P):
+            lo, hi = sp.shard_range(g)
+            qf[:, :, T + lo:T + hi] = recv[g, 0].view(B, Hl, nl, 64)[:, :, :hi - lo]
+            kf[:, :, T + lo:T + hi] = recv[g, 1].view(B, Hl, nl, 64)[:, :, :hi - lo]
+            vf[:, :, :, T + lo:T + hi] = recv[g, 2].view(B, Hl, 64, nl)[:, :, :, :hi - lo]
+        ol = attend_heads(qf, kf, vf, Hl, head0, Nt)                  # [B, T + Nt, Hl * 64]
+        back = torch.empty(P, B, nl, Hl * 64, dtype=torch.bfloat16, device=dev)
+        for g in range(P):
+            lo, hi = sp.shard_range(g)
+            back[g, :, :hi - lo] = ol[:, T + lo:T + hi]
+            if hi - lo != nl:
+                back[g, :, hi - lo:].zero_()
+        mine = sp.all_to_all(back)                                    # [head owner, B, nl, Hl * 64]
+        text = sp.all_gather(ol[:, :T].contiguous())                  # [head owner, B, T, Hl * 64]
+        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        o[:, :T] = text.permute(1, 2, 0, 3).reshape(B, T, d)
+        o[:, tp:tp + n_own] = mine.permute(1, 2, 0, 3).reshape(B, nl, d)[:, :n_own]
+        return o
+
+    def _heads_mode(self, lay, sp, H) -> bool:
+        """EA_SP_MODE=heads (sequence_parallel.SequenceParallel.mode): the full-attention blocks exchange heads, not keys."""
+        return lay is not None and sp.size > 1 and getattr(sp, "mode", "keys") == "heads" and H % sp.size == 0
+
     def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid, pending=None):
         """softmax(QK^T)V over the rows staged in ws -> bf16 [B, S, d]."""
         # ---- joint attention (processor.py:287-291): queries = text rows + this rank's video rows
+        if self._heads_mode(lay, sp, H):
+            # one contiguous launch over all keys for H / P' heads: no second pass, no state round trip, no replicated text queries
+            def full(qf, kf, vf, Hl, head0, Nt):
+                return ops.attention(qf, kf, vf, T + Nt, ops.FOLDED_ATTN_SCALE)
+            return self._head_parallel(ws, B, H, T, S, d, dev, lay, sp, full)
         o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
         if lay is not None and sp.exchanges(lay):
             # sequence-parallel: attend the OWN slot (text + own shard) while the in-place K / V^T all-gather is in flight,
@@ -205,7 +273,8 @@ class EasyAnimateAttnProcessor2_0:
                 pending = sp.exchange_start(ws["kv"])
 
         qkv_stream(e, tattn, T, 0, None, None)      # text rows: no RoPE
-        qkv_stream(x, attn, N, v_off, cos, sin, start_exchange=exchange and self.exchange_in_attend is False)
+        qkv_stream(x, attn, N, v_off, cos, sin,
+                   start_exchange=exchange and self.exchange_in_attend is False and not self._heads_mode(lay, sp, H))
 
         o = self._attend(ws, B, H, T, N, S, v_off, d, dev, lay, sp, (num_frames, height, width), pending)
         o_t, o_v = o[:, :T], o[:, v_off:]
@@ -317,42 +386,7 @@ class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
         if sp is None:
             return self._swa(ws["q"], ws["k"], ws["vt"], B, H, 0, H, T, N, dev, grid)
         # ---- sequence parallelism: the six scan orders scatter a rank's contiguous (f h w) shard over the whole sequence, so
-        # the window pass is not a halo exchange.  The block switches to HEAD parallelism instead (all-to-all): every rank
-        # receives the q / k / v^T rows of ALL tokens for H / P' heads, runs the single-GPU passes on them, and a second
-        # all-to-all returns every rank's query rows for all heads; the replicated text rows are computed by the head's
-        # owner and all-gathered (bit-identical on every rank).
-        P = sp.size
-        if H % P:
-            raise NotImplementedError(f"sliding-window blocks under sequence parallelism need heads ({H}) % sequence ranks ({P}) == 0")
-        Hl, nl, tp, Nt = H // P, lay.n_loc, lay.t_pad, sp.n_total
-        head0 = sp.rank * Hl
-        q, k, vt = ws["q"], ws["k"], ws["vt"]
-        send = torch.zeros(P, 3, B, Hl, nl * 64, dtype=torch.bfloat16, device=dev)
-        sv = send.view(P, 3, B, Hl, nl, 64)
-        sv[:, 0] = q[:, :, tp:tp + nl].reshape(B, P, Hl, nl, 64).transpose(0, 1)
-        sv[:, 1] = k[:, :, tp:tp + nl].reshape(B, P, Hl, nl, 64).transpose(0, 1)
-        send[:, 2] = vt[:, :, :, tp:tp + nl].reshape(B, P, Hl, 64 * nl).transpose(0, 1)
-        recv = sp.all_to_all(send)                                   # [source rank, 3, B, Hl, nl * 64]
-        s_pad = ops.round_up(T + Nt, 256)
-        qf = torch.zeros(B, Hl, s_pad, 64, dtype=torch.bfloat16, device=dev)
-        kf = torch.zeros_like(qf)
-        vf = torch.zeros(B, Hl, 64, s_pad, dtype=torch.bfloat16, device=dev)
-        hsl = slice(head0, head0 + Hl)
-        qf[:, :, :T], kf[:, :, :T], vf[:, :, :, :T] = q[:, hsl, :T], k[:, hsl, :T], vt[:, hsl, :, :T]
-        for g in range(P):
-            lo, hi = sp.shard_range(g)
-            qf[:, :, T + lo:T + hi] = recv[g, 0].view(B, Hl, nl, 64)[:, :, :hi - lo]
-            kf[:, :, T + lo:T + hi] = recv[g, 1].view(B, Hl, nl, 64)[:, :, :hi - lo]
-            vf[:, :, :, T + lo:T + hi] = recv[g, 2].view(B, Hl, 64, nl)[:, :, :, :hi - lo]
-        ol = self._swa(qf, kf, vf, B, Hl, head0, H, T, Nt, dev, grid)   # [B, T + Nt, Hl * 64]
-        back = torch.zeros(P, B, nl, Hl * 64, dtype=torch.bfloat16, device=dev)
-        for g in range(P):
-            lo, hi = sp.shard_range(g)
-            back[g, :, :hi - lo] = ol[:, T + lo:T + hi]
-        mine = sp.all_to_all(back)                                    # [head owner, B, nl, Hl * 64]
-        text = sp.all_gather(ol[:, :T].contiguous())                  # [head owner, B, T, Hl * 64]
-        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
-        n_own = lay.n_own
-        o[:, :T] = text.permute(1, 2, 0, 3).reshape(B, T, d)
-        o[:, tp:tp + n_own] = mine.permute(1, 2, 0, 3).reshape(B, nl, d)[:, :n_own]
-        return o
+        # the window pass is not a halo exchange.  The block switches to HEAD parallelism instead (_head_parallel): the
+        # single-GPU passes run on all tokens of H / P' heads (head groups keep their global scan order).
+        return self._head_parallel(ws, B, H, T, S, d, dev, lay, sp,
+                                   lambda qf, kf, vf, Hl, head0, Nt: self._swa(qf, kf, vf, B, Hl, head0, H, T, Nt, dev, grid))

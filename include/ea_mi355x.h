@@ -52,8 +52,9 @@ int ea_version(void);
  *   "conv_m512":    row-slab layers without folded up-sampling, bit 0 (1): C_out == 128 with rows a multiple of 512 voxels use the
  *                   512-voxel x 128-channel kernel (stride 1, and the spatially strided down-sampler in its de-interleaved form), bit 1 (2): the 256-channel tiles use the 256 x 256 kernel -- both one phase
  *                   per tile over 32-channel stages; 1 = default (bit 1 measured 1.5-3 % slower), 0 = the four-phase kernels over 64-channel stages;
- *   "attn_variant": 3 = the pipelined kernel on 16x16x32 MFMAs (default; serves calls with the scale folded into Q,
- *                   others fall through to 2), 2 = the pipelined kernel on 32x32x16, 1 = the first, un-pipelined kernel. */
+ *   "attn_variant": 3 = the pipelined kernel on 16x16x32 MFMAs (the only generation in the default library: the softmax
+ *                   scale must be folded into Q, see ea_attention_fwd_bf16); EA_BUILD_VARIANTS=1 libraries also carry 2 = the
+ *                   pipelined kernel on 32x32x16 (takes any scale) and 1 = the first, un-pipelined kernel. */
 int ea_set_option(const char* name, int value);
 /* Current value of a switch (tests restore what they found). */
 int ea_get_option(const char* name, int* value);
@@ -183,7 +184,11 @@ int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq_fp8, const
  *         never read as valid keys (they are masked) but must be finite-or-zero in vt.
  *   out : bf16 [batch, seq, heads*64] (out_batch_stride elements between batches)
  * Only query rows [q_begin, q_end) are computed (sequence parallelism: a rank owns a query range but
- * sees all keys).  s_pad % 256 == 0 and s_pad >= seq. */
+ * sees all keys).  s_pad % 256 == 0 and s_pad >= seq.
+ * scale: the softmax scale must live in Q -- project with q_scale = scale * log2(e) (ea_qkv_gemm_norm_rope_bf16 /
+ * ea_qknorm_rope_bf16) and pass scale = ln 2 here, so that scale * log2(e) == 1 and the kernel exponentiates the raw MFMA
+ * scores; any other value is EA_ERR_ARG (same rule for ea_attention_fwd_range_bf16; EA_BUILD_VARIANTS=1 libraries carry the
+ * 32x32x16 generation that multiplies every score and accept any scale). */
 int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
                           int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
                           int q_begin, int q_end, float scale, void* stream);

@@ -688,6 +688,55 @@ def gen_config1_v0(ns, shim):
                os.path.join(OUT, "config1_7b_256_v0.pt"))
 
 
+def config2_inputs():
+    """BASELINE.json configs[1]: 7B-class DiT, 49 frames 512 x 512 -> latents [1,16,13,64,64] (13 * 32 * 32 = 13 312 video tokens
+    + 256 text tokens = S 13 568); text embeddings for the negative / positive prompt.  bf16-representable values, so the fp32
+    reference and the bf16 product start from identical inputs."""
+    enc = (torch.randn(2, 256, 3584, generator=_g(61)) * 3).bfloat16().float()
+    latents = torch.randn(1, 16, 13, 64, 64, generator=_g(62)).bfloat16().float()
+    return latents, enc
+
+
+@section("config2_forward")
+def gen_config2_forward(ns, shim):
+    # ---- VERDICT r3 next #3a: depth x length on a BASELINE config -- ONE forward of the declared 7B-class model (L = 28,
+    # d = 3072) at config 2's full shape (S = 13 568), CFG pair, the first timestep of the 50-step Flow schedule; the unchanged
+    # reference in fp32 on the host cores (~3e14 FLOP).  The two batch elements run one after the other (B = 1 each: the forward
+    # has no cross-batch term, and a B = 2 fp32 pass of this size does not fit beside the 25 GB of fp32 weights in 62 GB of RAM).
+    # Then the reference's own bf16 forward from the same inputs (its per-forward noise floor).  Stored as fp16 (|v| < 10).
+    import time
+    t0 = time.time()
+    m, _ = _meta_build(lambda: ns.transformer3d.EasyAnimateTransformer3DModel(**DIT_7B), 0, "default_bf16")
+    print(f"  7B-class reference transformer built in {time.time() - t0:.0f} s", flush=True)
+    latents, enc = config2_inputs()
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((32, 32), 45, 30)
+    rope = shim.get_3d_rotary_pos_embed(64, cc, (32, 32), 13, use_real=True)
+    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(50, device="cpu", mu=1)
+    t = s.timesteps[0]
+    tt = torch.tensor([t]).to(torch.bfloat16).float()     # the pipeline hands the model a bf16 timestep (pipeline_easyanimate.py:1079-1081)
+    outs = []
+    with torch.no_grad():
+        for b in range(2):
+            t0 = time.time()
+            outs.append(m(latents, tt, encoder_hidden_states=enc[b:b + 1], image_rotary_emb=rope, return_dict=False)[0])
+            print(f"  fp32 forward, batch element {b}: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads; std {outs[-1].std().item():.3f}", flush=True)
+        v = torch.cat(outs)
+        mb = m.to(torch.bfloat16)
+        outs = []
+        for b in range(2):
+            t0 = time.time()
+            outs.append(mb(latents.bfloat16(), tt.bfloat16(), encoder_hidden_states=enc[b:b + 1].bfloat16(), image_rotary_emb=rope,
+                           return_dict=False)[0].float())
+            print(f"  bf16 forward, batch element {b}: {time.time() - t0:.1f} s", flush=True)
+        vb = torch.cat(outs)
+    print(f"  reference bf16-vs-fp32 velocity MSE {_mse(vb, v):.3e}; |v| max {v.abs().max().item():.2f}", flush=True)
+    torch.save(dict(cfg=DIT_7B, seed=0, style="default_bf16", timestep=float(tt), crops=cc, v=v.half(), floor_mse=_mse(vb, v),
+                    rel_l2_floor=((vb - v).double().norm() / v.double().norm()).item(),
+                    fp16_storage_mse=_mse(v.half().float(), v), latents_sum=latents.double().sum().item(),
+                    enc_sum=enc.double().sum().item()), os.path.join(OUT, "config2_7b_49x512_v0.pt"))
+
+
 FULL_LOOP_DIMS = (3, 40, 56, 256)      # latent frames, latent H, W, text tokens -> 3 * 20 * 28 = 1680 video tokens
 
 

@@ -373,18 +373,6 @@ def test_roofline_table_reproduces_the_survey_totals():
     assert abs(enc / 4.7653e14 - 1) < 1e-3 and abs(dec / 7.4998e14 - 1) < 1e-3
 
 
-def test_attention_v4_stage_bookkeeping_model():
-    """tools/model_att4_stages.py: which K / V^T tile every fragment read of the one-wave-per-SIMD attention experiment sees, for
-    two and four LDS stages, 1..8 key tiles, and both extremes of DMA timing (each request lands at the last moment its vmcnt wait
-    allows / the moment it is issued)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("model_att4_stages", os.path.join(ROOT, "tools", "model_att4_stages.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    bad = [e for NS in (2, 4) for nt in range(1, 9) for early in (False, True) for e in mod.run(NS, nt, early)]
-    assert not bad, bad[:3]
-
-
 @pytest.mark.skipif(not os.path.isdir("/root/reference/easyanimate"), reason="/root/reference not present (GPU box)")
 def test_pipeline_rope_matches_the_reference_call_site_for_random_shapes():
     """EasyAnimatePipeline.rotary_embedding(height, width, latent_frames) against the reference's own call site

@@ -452,6 +452,11 @@ def _attn_ref(q, k, v, S):
     return o.transpose(1, 2).reshape(B, S, H * 64)
 
 
+def _has_variants():
+    from easyanimate_amd import _lib
+    return _lib.get_option("build_variants") == 1
+
+
 def _fold(q):
     """What ea_qknorm_rope_bf16(q_scale=FOLDED_Q_SCALE) hands the attention kernel: bf16(q * 64^-1/2 * log2 e)."""
     from easyanimate_amd import ops
@@ -463,6 +468,8 @@ def attn_kernel(request):
     """Run a test with the 32x32x16 (v2) and the 16x16x32 (v3, default) pipelined attention kernels.  v3 serves calls
     with the scale folded into Q; everything else falls through to v2."""
     from easyanimate_amd import _lib
+    if request.param != 3:
+        _needs_variants()          # the default library carries v3 only (round 4)
     _lib.set_option("attn_variant", request.param)
     yield request.param
     _lib.set_option("attn_variant", 3)
@@ -480,6 +487,7 @@ def test_attention(B, H, S, folded, attn_kernel):
         out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
         ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)   # the reference of the rounded, folded q
     else:
+        _needs_variants()          # un-folded scale: the v2 generation (cross-check libraries only)
         out = ops.attention(q, k, vt, S, 0.125)
         ref = _attn_ref(q, k, v, S)
     err, rel = _report(f"attention B{B}H{H}S{S} folded={folded}", out, ref)
@@ -512,21 +520,22 @@ def test_attention_forced_rescale_and_padding_garbage():
     k[:, :, 130] = q[:, :, 300] * 5
     q[:, :, S:] = 1e30
     k[:, :, S:] = -1e30
-    out = ops.attention(q, k, vt, S, 0.125)
-    ref = _attn_ref(q, k, v, S)
+    qs = _fold(q)
+    out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+    ref = _attn_ref((qs[:, :, :S].float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
     err, rel = _report("attention forced-rescale", out, ref)
     assert torch.isfinite(out.float()).all()
     assert rel < 8e-3 and err < 0.05
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_attention_extreme_dynamic_range(variant):
     """Scores spanning +-600 (log2 units) inside one query row, row maxima in either key half of a 32-key block:
     every exponential that is not the row maximum's under- or overflows.  (Caught a mis-compiled cross-half max in
     the rescale path: the running max came from the lower key half only, finite until the halves differ by 2^127.)"""
     from easyanimate_amd import _lib
     ops = _ops()
-    if variant == 1:
+    if variant != 3:
         _needs_variants()
     _lib.set_option("attn_variant", variant)
     try:
@@ -535,8 +544,13 @@ def test_attention_extreme_dynamic_range(variant):
         q = (q.float() * 30.0).to(torch.bfloat16)
         for (qq, kk, a) in [(3, 40, 3.0), (3, 70, 2.5), (17, 31, 4.0), (200, 999, 9.0), (777, 960, 5.0), (64, 0, 6.0)]:
             k[:, 0, kk] = (q[:, 0, qq].float() / 30.0 * a).to(torch.bfloat16)
-        out = ops.attention(q, k, vt, S, 0.125)
-        ref = _attn_ref(q, k, v, S)
+        if variant == 3:       # v3 takes the scale folded into Q: its RAW mode has to hand over to the shifted loop here
+            qs = _fold(q)
+            out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+            ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
+        else:
+            out = ops.attention(q, k, vt, S, 0.125)
+            ref = _attn_ref(q, k, v, S)
         assert torch.isfinite(out.float()).all()
         err, rel = _report(f"attention v{variant} extreme range", out, ref)
         assert rel < 8e-3 and err < 0.05
@@ -569,7 +583,7 @@ def test_attention_folded_leaves_raw_mode(amp, attn_kernel):
         assert rel < 8e-3 and err < 0.05, (h, err, rel)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_attention_variants_rescale_paths(variant):
     """Both kernels (v1: per-block rescale; v2: software-pipelined, deferred rescale with the pending P.V flushed in the
     rare branch) against an fp64 reference on inputs that force the rescale branch at chosen blocks (CDNA4 guide,
@@ -577,7 +591,7 @@ def test_attention_variants_rescale_paths(variant):
     the defer threshold, and a steady ramp whose cumulated growth crosses the threshold many times."""
     from easyanimate_amd import _lib
     ops = _ops()
-    if variant == 1:
+    if variant != 3:
         _needs_variants()
     _lib.set_option("attn_variant", variant)
     try:
@@ -593,8 +607,13 @@ def test_attention_variants_rescale_paths(variant):
         ramp = (torch.arange(S, device=DEV).float() / S)[None, :, None]
         k[:, 1, :S] = (k[:, 1, :S].float() * 0.3 + d.float()[None, None, :] * 3.0 * ramp).to(torch.bfloat16)
         # head 2: plain random
-        out = ops.attention(q, k, vt, S, 0.125)
-        ref = _attn_ref(q, k, v, S)
+        if variant == 3:
+            qs = _fold(q)
+            out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
+            ref = _attn_ref((qs[:, :, :S].float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
+        else:
+            out = ops.attention(q, k, vt, S, 0.125)
+            ref = _attn_ref(q, k, v, S)
         for h in range(H):
             err, rel = _report(f"attention v{variant} rescale-paths head{h}", out[:, :, h * 64:(h + 1) * 64],
                                ref[:, :, h * 64:(h + 1) * 64])
@@ -642,6 +661,7 @@ def test_attention_resumable_key_ranges(splits, folded, attn_kernel):
         qs, sc = _fold(q), ops.FOLDED_ATTN_SCALE
         ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
     else:
+        _needs_variants()
         qs, sc = q, 0.125
         ref = _attn_ref(q, k, v, S)
     qb, qe = 64, 900                   # a query sub-range, as a rank would own
@@ -768,81 +788,15 @@ def test_attention_query_range(attn_kernel):
     ops = _ops()
     B, H, S = 1, 2, 1300
     q, k, vt, v = _attn_inputs(B, H, S, 13)
-    for qs, sc, ref in ((q, 0.125, _attn_ref(q, k, v, S)),
-                        (_fold(q), ops.FOLDED_ATTN_SCALE, _attn_ref((_fold(q).float() / ops.FOLDED_Q_SCALE).double(), k, v, S))):
+    cases = [(_fold(q), ops.FOLDED_ATTN_SCALE, _attn_ref((_fold(q).float() / ops.FOLDED_Q_SCALE).double(), k, v, S))]
+    if _has_variants():
+        cases.append((q, 0.125, _attn_ref(q, k, v, S)))
+    for qs, sc, ref in cases:
         out = torch.full((B, S, H * 64), 7.0, dtype=torch.bfloat16, device=DEV)
         ops.attention(qs, k, vt, S, sc, out=out, q_begin=512, q_end=1024)
         err, rel = _report("attention q-range", out[:, 512:1024], ref[:, 512:1024])
         assert rel < 8e-3
         assert (out[:, :512] == 7.0).all() and (out[:, 1024:] == 7.0).all()
-
-
-@pytest.mark.parametrize("B,H,S", [(1, 2, 512), (1, 3, 1000), (2, 9, 2048 + 77), (1, 1, 5), (1, 8, 4096), (1, 2, 1300)])
-def test_attention_v4_experiment(B, H, S):
-    """The one-wave-per-SIMD attention experiment (ea_attention_v4.inc, EA_BUILD_VARIANTS=1 libraries, attn_variant 4): plain
-    calls with the scale folded into Q against fp64 softmax and against v3 (same MFMA products in the same order; the row sums
-    accumulate inside the sum MFMAs instead of per-block adds -> last-bit differences only); partial last key tile, several
-    query blocks of 512, a query range, untouched rows; repeated launches bit-identical (race screen for the moved hand-over)."""
-    from easyanimate_amd import _lib
-    ops = _ops()
-    _needs_variants()
-    q, k, vt, v = _attn_inputs(B, H, S, 7, scale_q=2.0)
-    qs = _fold(q)
-    ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
-    try:
-        _lib.set_option("attn_variant", 4)
-        _lib.reset_counters()
-        out4 = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
-        assert _lib.counters().get("attention_v4", 0) == 1, _lib.counters()
-        for _ in range(3):
-            assert torch.equal(ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE), out4)
-        if S >= 1024:
-            part = torch.full((B, S, H * 64), 7.0, dtype=torch.bfloat16, device=DEV)
-            ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE, out=part, q_begin=256, q_end=900)
-            assert torch.equal(part[:, 256:900], out4[:, 256:900]) and (part[:, :256] == 7.0).all() and (part[:, 900:] == 7.0).all()
-        _lib.set_option("attn_variant", 3)
-        out3 = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
-    finally:
-        _lib.set_option("attn_variant", 3)
-    err, rel = _report(f"attention v4 B{B}H{H}S{S}", out4, ref)
-    assert rel < 8e-3 and err < 0.05, (err, rel)
-    d = (out4.float() - out3.float()).abs()
-    tol = out3.float().abs().clamp_min(1e-3) * 2.0 ** -7
-    print(f"[parity] attention v4 vs v3: {(d > 0).float().mean().item() * 100:.3f} % of the outputs differ, max {(d / tol).max().item():.2f} bf16 ulp")
-    assert (d <= tol).all()
-
-
-@pytest.mark.parametrize("amp", [0.02, 1.0, 30.0])
-def test_attention_v4_fixup_pass(amp):
-    """The v4 experiment has no rescale path of its own: a wave whose queries end with a row sum outside [2^-60, 2^100) flags its
-    block of 256 queries and v3 redoes the flagged blocks right behind.  Same inputs as test_attention_folded_leaves_raw_mode:
-    scores scaled to +- a few (nothing flagged), to hundreds (exp2 overflows: head 0 / every key of a query far below zero until
-    a late block: head 1)."""
-    from easyanimate_amd import _lib
-    ops = _ops()
-    _needs_variants()
-    B, H, S = 1, 3, 1000
-    q, k, vt, v = _attn_inputs(B, H, S, 37)
-    q = (q.float() * amp).to(torch.bfloat16)
-    for (qq, kk, a) in [(3, 40, 3.0), (3, 70, 2.5), (17, 31, 4.0), (200, 999, 9.0), (777, 960, 5.0), (64, 0, 6.0)]:
-        k[:, 0, kk] = (q[:, 0, qq].float() / max(amp, 1e-3) * a).to(torch.bfloat16)
-    d = torch.ones(64, device=DEV)
-    q[:, 1, :S] = (d * 2.0 * amp).to(torch.bfloat16)
-    k[:, 1, :S] = (-d * 1.5 + 0.05 * torch.randn(S, 64, device=DEV)).to(torch.bfloat16)
-    k[:, 1, 900:905] = (d * 0.5).to(torch.bfloat16)
-    qs = _fold(q)
-    try:
-        _lib.set_option("attn_variant", 4)
-        _lib.reset_counters()
-        out = ops.attention(qs, k, vt, S, ops.FOLDED_ATTN_SCALE)
-        assert _lib.counters().get("attention_v4", 0) == 1
-    finally:
-        _lib.set_option("attn_variant", 3)
-    ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
-    assert torch.isfinite(out.float()).all()
-    for h in range(H):
-        err, rel = _report(f"attention v4 + fix-up amp {amp} head{h}", out[:, :, h * 64:(h + 1) * 64], ref[:, :, h * 64:(h + 1) * 64])
-        assert rel < 8e-3 and err < 0.05, (h, err, rel)
 
 
 def test_patchify_unpatchify_cfg_euler():
@@ -888,8 +842,8 @@ def test_errors_are_reported_not_fatal():
 
 
 # ---- round 3: K / V^T land in the rank's slot of the exchange buffer; K | V first; slot-relative key ranges ------------------
-@pytest.mark.parametrize("fused", [True, False])
-def test_qkv_projection_into_an_exchange_slot(fused):
+@pytest.mark.parametrize("fused,M", [(True, 512), (True, 1283), (True, 13104), (False, 200), (False, 1283)])
+def test_qkv_projection_into_an_exchange_slot(fused, M):
     """ea_qkv_gemm_norm_rope_bf16 / ea_qknorm_rope_bf16 with their own K / V^T geometry (kv_off, kv_rows): q goes to the
     workspace rows [seq_off, ..), K / V^T to rows [kv_off, ..) of a buffer with another number of rows per head -- bit-identical
     to the same launch into buffers of Q's geometry, nothing else written; the fused launch split into parts (K | V, then Q)
@@ -897,7 +851,7 @@ def test_qkv_projection_into_an_exchange_slot(fused):
     from easyanimate_amd import _lib
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(23)
-    B, H, M, K = 2, 4, 512 if fused else 200, 256
+    B, H, K = 2, 4, 256
     d = H * 64
     x = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
     ws = [_bf(torch.randn(d, K, generator=g) / K ** 0.5).to(DEV) for _ in range(3)]
@@ -907,7 +861,9 @@ def test_qkv_projection_into_an_exchange_slot(fused):
     ang = torch.rand(M, 32, generator=g) * 6.28
     cos, sin = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV), ang.sin().repeat_interleave(2, 1).contiguous().to(DEV)
     seq_off, kv_off = 64, 128
-    s_pad, kv_rows = ops.round_up(seq_off + M, 256), kv_off + M + 64
+    # kv_rows as the product chooses it (sequence_parallel.Layout.rows: a multiple of 256); M = 1283 / 13104 end in a ragged 256-row
+    # tile (round 3 ended on a red M = 1283 case whose kv_rows = kv_off + M + 64 was no multiple of 8: the entry point's own check)
+    s_pad, kv_rows = ops.round_up(seq_off + M, 256), ops.round_up(kv_off + M + 64, 256)
     full = lambda *shape: torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
 
     def run(q, k, vt, **kw):
@@ -939,6 +895,22 @@ def test_qkv_projection_into_an_exchange_slot(fused):
         torch.cuda.synchronize()
         assert torch.equal(q2, q1) and torch.equal(k2, k1) and torch.equal(vt2, vt1)
         assert _lib.counters() == {"gemm_qkv_fused": 2, "gemm_qkv_fused_kv_part": 1, "gemm_qkv_fused_q_part": 1}
+
+
+def test_qkv_exchange_slot_geometry_is_checked():
+    """What round 3's red case actually hit: K / V^T rows per head that are no multiple of 8 (the V^T store moves 16-byte groups)
+    are refused by the entry point -- an error string, not a wrong store."""
+    ops = _ops()
+    B, H, M, K, kv_off = 1, 4, 1283, 256, 128
+    d, kv_rows = H * 64, 128 + 1283 + 64          # 1475: the geometry of the removed test case
+    x = torch.zeros(B, M, K, dtype=torch.bfloat16, device=DEV)
+    w, b = torch.zeros(d, K, dtype=torch.bfloat16, device=DEV), torch.zeros(d, device=DEV)
+    n = torch.ones(64, device=DEV)
+    cs = torch.zeros(M, 64, device=DEV)
+    q = torch.zeros(B, H, ops.round_up(M, 256), 64, dtype=torch.bfloat16, device=DEV)
+    k, vt = torch.zeros(B, H, kv_rows, 64, dtype=torch.bfloat16, device=DEV), torch.zeros(B, H, 64, kv_rows, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.qkv_gemm_norm_rope(x, w, w, w, b, b, b, q, k, vt, n, n, n, n, cs, cs, 0, 1e-6, kv_off=kv_off)
 
 
 @pytest.mark.parametrize("P,rank,T,nl,n_last", [(4, 1, 64, 192, 192), (4, 3, 128, 192, 100), (2, 0, 64, 128, 70), (3, 0, 192, 64, 64)])
@@ -993,40 +965,3 @@ def test_attention_segments_slot_rows(P, rank, T, nl, n_last):
     assert rel < 8e-3
 
 
-# ---- round 3: the four-wave 256^2 GEMM (128 x 128 wave tiles, accumulators in AGPRs) -----------------------------------------
-@pytest.mark.parametrize("B,M,N,K", GEMM256_SHAPES + [(1, 256, 256, 320), (1, 4096, 3072, 3072)])
-@pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("sched", [1, 2])
-def test_gemm_w4_equals_the_eight_wave_kernel(B, M, N, K, epi, sched):
-    """gemm256_w4_kernel against fp64 (through test_gemm) and against gemm256_mi16_kernel: the same 16x16x32 products summed
-    in the same order per output element -> bit-identical, M / N tails, odd and even K-tile counts, strided batches;
-    repeated launches bit-identical (race screen for the one-barrier-per-tile schedule and, sched = 2, for the buffer-addressed
-    two-tiles-ahead schedule)."""
-    from easyanimate_amd import _lib
-    ops = _ops()
-    _needs_variants()
-    w4_default = _lib.get_option("gemm_w4")
-    _lib.set_option("gemm_tile", 256)
-    try:
-        _lib.set_option("gemm_w4", sched)
-        _lib.reset_counters()
-        test_gemm(B, M, N, K, epi)
-        assert _lib.counters().get("gemm_256_w4" if sched == 1 else "gemm_256_w4b", 0) == 1, _lib.counters()
-        g = torch.Generator(device="cpu").manual_seed(8)
-        A = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
-        W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
-        bias = torch.randn(N, generator=g).to(DEV)
-        res = _bf(torch.randn(B, M, N, generator=g)).to(DEV)
-        gate = torch.randn(B, N, generator=g).to(DEV)
-        run = lambda: ops.gemm(A, W, bias, epi, res=res if epi == 2 else None, gate=gate if epi == 2 else None)
-        y1 = run()
-        for _ in range(3):
-            assert torch.equal(run(), y1)
-        _lib.set_option("gemm_w4", 0)
-        _lib.reset_counters()
-        y0 = run()
-        assert _lib.counters().get("gemm_256_mi16", 0) == 1
-        assert torch.equal(y0, y1)
-    finally:
-        _lib.set_option("gemm_tile", 0)
-        _lib.set_option("gemm_w4", w4_default)

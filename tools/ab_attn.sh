@@ -3,6 +3,6 @@
 # ("cur" = the in-tree library).   bash tools/ab_attn.sh cur old L0G1 ...
 for v in "$@"; do
   if [ "$v" = cur ]; then unset EA_LIB_PATH; else export EA_LIB_PATH=$PWD/easyanimate_amd/lib/variants/libea_$v.so; fi
-  r=$(python tools/ab_v3.py 2>&1 | grep '"variant": 3' | sed 's/.*"folded_TF": \([0-9.]*\).*/\1/' | tr '\n' ' ')
+  r=$(python tools/ab_attn_lib.py 2>&1 | grep 'attention v3' | sed 's/.*"TFLOPs": \([0-9.]*\).*/\1/' | tr '\n' ' ')
   echo "variant=$v $r"
 done

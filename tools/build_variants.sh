@@ -2,7 +2,7 @@
 # Build libea variants that differ in the flags of ONE source file only (compiler-scheduling / experiment-switch A/B), on top of
 # the EA_BUILD_VARIANTS=1 library (so every cross-check / experiment kernel is selectable in them):
 #   bash tools/build_variants.sh [-f ea_gemm.hip] "TAG -DEA_ATT4_FINE=2" "OTHER -DEA_ATT3_LEAD=1 ..."
-#       -> easyanimate_amd/lib/variants/libea_<TAG>.so (run with EA_LIB_PATH=<that file>; tools/ab_attn_lib.py, tools/ab_gemm_w4.py)
+#       -> easyanimate_amd/lib/variants/libea_<TAG>.so (run with EA_LIB_PATH=<that file>; tools/ab_attn_lib.py, tools/ab_gemm.py)
 #          and the device assembly in /tmp/<file>_<TAG>.s (instruction mix of the hot block: tools/isa_hot_block.py)
 set -e
 cd "$(dirname "$0")/.."

@@ -55,10 +55,7 @@ def _bench_gemm(tile):
 
 def bench_attn():
     from easyanimate_amd import _lib
-    for var in (2, 2):
-        _lib.set_option("attn_variant", var)
-        _bench_attn(var)
-    _lib.set_option("attn_variant", 2)
+    _bench_attn(_lib.get_option("attn_variant"))
 
 
 def _bench_attn(var, waves=0):

@@ -7,7 +7,7 @@ from easyanimate_amd import _lib, ops
 
 what = sys.argv[1] if len(sys.argv) > 1 else "attn"
 if what == "attn":
-    var = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    var = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     _lib.set_option("attn_variant", var)
     B, H, S = 2, 48, 53504
     s_pad = ops.round_up(S, 256)
