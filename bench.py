@@ -212,6 +212,9 @@ def main():
                     help="with --emulate-rank: also move the bytes the per-block K / V^T all-gather would bring in (P'-1 slots) "
                          "device-to-device on a side stream under the own-slot attention pass (HBM / copy-engine contention "
                          "enters the model; xGMI link time does not)")
+    ap.add_argument("--sp-mode", default=os.environ.get("EA_SP_MODE", "keys"), choices=["keys", "heads"],
+                    help="multi-GPU exchange of the full-attention blocks: 'keys' = in-place K / V^T all-gather under the own-slot "
+                         "attention pass (default), 'heads' = head all-to-all around one contiguous attention launch")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE half of the metric (config 4), timed after the DiT steps at N=1")
     args = ap.parse_args()
 
@@ -250,7 +253,7 @@ def main():
     cfg = CONFIGS[args.config]
     model = build_model(cfg["layers"], device, cfg.get("in_channels", 16))
     if world > 1:
-        sequence_parallel.enable(model)
+        sequence_parallel.enable(model, mode=args.sp_mode)
     emu = None
     if args.emulate_rank:
         if world != 1:
@@ -258,6 +261,7 @@ def main():
         emu = tuple(int(v) for v in args.emulate_rank.split(","))
         model.sequence_parallel = sequence_parallel.EmulatedRank(*emu)
         model.sequence_parallel.emulate_exchange = bool(args.emulate_exchange)
+        model.sequence_parallel.mode = args.sp_mode
         args.no_vae = args.no_cpu_baseline = True
     sched = FlowMatchEulerDiscreteScheduler(shift=1.0)
     pipe = EasyAnimatePipeline(vae=None, transformer=model, scheduler=sched)
@@ -286,19 +290,31 @@ def main():
         if W > 0:
             latents = pipe.denoise(latents, embeds, rope, sched.timesteps[:W], 6.0, inpaint_latents=inpaint)
         sync()
+        if world > 1:
+            model.sequence_parallel.profile_wait = True    # HIP events around every stream-level wait for a collective
         t0 = time.perf_counter()
         with ops.KernelTimer("attention") as kt:
             latents = pipe.denoise(latents, embeds, rope, sched.timesteps[W:W + K], 6.0, inpaint_latents=inpaint)
         sync()
         elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
     finite = bool(torch.isfinite(latents.float()).all().item())
     gathered_devices = [None] * world
+    rank_reports = [None] * world
     if world > 1:   # which device each rank really ran on (a shared-device test run shows up here)
         dist.all_gather_object(gathered_devices, f"cuda:{local_rank}" + ("(shared)" if shared else ""))
+        # self-check of the first hardware run: every rank steps the SAME gathered prediction through the same scheduler
+        # kernel, so the final latents must be bit-identical on all ranks; and where the compute stream waited for a collective
+        import hashlib
+        waits = model.sequence_parallel.exposed_wait_ms()
+        dist.all_gather_object(rank_reports, {
+            "latents_sha1": hashlib.sha1(latents.detach().float().cpu().numpy().tobytes()).hexdigest(),
+            "exposed_wait_ms_per_step": {k: round(t / K, 3) for k, (n, t) in waits.items()},
+            "waits_per_step": {k: n / K for k, (n, t) in waits.items()}, "step_ms": round(elapsed_own / K * 1e3, 2)})
 
     # ---- roofline of the dominant kernel (attention forward): algorithmic FLOPs per block / HIP-event duration.
     # Multi-GPU: a rank runs its batch slice (CFG axis) and its query shard (sequence axis) as two or three key-range
@@ -311,8 +327,9 @@ def main():
         lo, hi = sp.shard_range()
         q_rows = 256 + (hi - lo)
         par = (f"cfg{sp.axis.cfg_degree} x sp{sp.size}: CFG pair split over rank halves, video-token sequence parallel "
-               f"inside a half; K | V projected first, in-place asynchronous K/V^T all-gather under the Q projection and the "
-               f"own-slot attention pass")
+               f"inside a half; " + ("K | V projected first, in-place asynchronous K/V^T all-gather under the Q projection and the "
+               f"own-slot attention pass" if sp.mode == "keys" else "head all-to-all (q, k, v^T out; o back) around one contiguous attention "
+               f"launch over H / P' heads"))
     else:
         b_loc, q_rows, par = B, S, "single GPU"
     att_ms = sum(durs) / max(n_blocks, 1)
@@ -352,6 +369,11 @@ def main():
     if world > 1:
         out["rccl"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
                        "devices": sorted(set(gathered_devices)), "launched_by": os.environ.get("TORCHELASTIC_RUN_ID", "external")}
+        out["rank_agreement"] = len({r["latents_sha1"] for r in rank_reports}) == 1
+        out["exchange"] = {"mode": model.sequence_parallel.mode,
+                           "what": "per rank: time the compute stream spent between two HIP events around each wait for a collective "
+                                   "(the EXPOSED part of the exchange), per denoise step; step_ms = the rank's own wall time per step",
+                           "per_rank": [{k: v for k, v in r.items() if k != "latents_sha1"} for r in rank_reports]}
     if emu:
         P, r = emu
         out["metric"] = f"MODELLED per-rank compute-side rate, rank {r} of {P} (not a measurement of {P} GPUs)"

@@ -10,6 +10,7 @@ from typing import Callable, Dict, Tuple
 import torch
 
 _cache: Dict[Tuple[int, str], Tuple[tuple, torch.Tensor]] = {}
+_finalized: set = set()      # (id(parameter), tag) keys that already carry a weakref.finalize
 
 
 def _key(p: torch.Tensor):
@@ -25,11 +26,18 @@ def derived(p: torch.Tensor, tag: str, fn: Callable[[torch.Tensor], torch.Tensor
     with torch.no_grad():
         val = fn(p.detach())
     _cache[k] = (sig, val)
-    try:
-        weakref.finalize(p, _cache.pop, k, None)
-    except TypeError:
-        pass
+    if k not in _finalized:      # ONE finalizer per (parameter, tag) for the parameter's lifetime: every pipeline call clears the
+        try:                     # cache (invalidate_weight_cache) and recomputes -- it must not also add a finalizer each time
+            weakref.finalize(p, _drop, k)
+            _finalized.add(k)
+        except TypeError:
+            pass
     return val
+
+
+def _drop(k) -> None:
+    _cache.pop(k, None)
+    _finalized.discard(k)
 
 
 def invalidate_weight_cache() -> None:

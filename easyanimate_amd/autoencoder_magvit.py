@@ -134,8 +134,20 @@ class Decoder(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.conv_in(x)
         x = self.mid_block(x)
+        # the virtual temporal x2 travels as a flag on the tensor (vae_modules.is_virtual): a flag an intervening op dropped would
+        # silently turn 2T - 1 logical frames into T.  The logical frame count is therefore checked after every block against
+        # what the block's up-sampler must produce.
+        from . import vae_parallel
+        from .vae_modules import SpatialTemporalUpsampler3D, is_virtual
+        expect = x.shape[0]
         for blk in self.up_blocks:
             x = blk(x)
+            if any(isinstance(mod, SpatialTemporalUpsampler3D) for mod in blk.modules()):
+                expect = 2 * expect - 1
+            logical = 2 * x.shape[0] - 1 if is_virtual(x) else x.shape[0]
+            if vae_parallel.current() is None and logical != expect:     # (a temporal split owns a frame RANGE and never goes virtual)
+                raise RuntimeError(f"VAE decoder: {logical} logical frames behind {type(blk).__name__}, expected {expect} -- the "
+                                   f"virtual-duplication flag of a temporally up-sampled clip was lost on the way")
         if getattr(x, "tvirt", False):
             # a temporal up-sampler in the LAST up block (not a V5 / V5.1 layout): nobody left to address the duplicated
             # frames virtually -- materialise them

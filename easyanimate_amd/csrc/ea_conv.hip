@@ -1566,6 +1566,7 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     const bool row_use = row_ok && (g_conv_tile == 1024 || (g_conv_tile == 0 && tiles256 * (C_out / bn) >= 512));
     EA_REQUIRE(!p.tmerge || (row_use && !ups && g_conv_mfma == 16),
                "ea_conv3d_cl_bf16: merged temporal taps are served by the 16x16x32 row-slab kernels only (ea_conv3d_cl_tmerge_ok)");
+    if (p.tmerge) ea_count("conv_tmerge_18_taps");   // (counted beside the kernel's own name, which follows and stays ea_last_dispatch)
     if (row_use) {
         p.tiles_m = (int)(p.M / 256);
         p.tiles_n = C_out / bn;

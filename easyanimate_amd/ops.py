@@ -220,7 +220,7 @@ def qkv_fused_ok(n_tok: int, inner: int, k: int, seq_off: int, kv_off: Optional[
     """Shapes ea_qkv_gemm_norm_rope_bf16 is used for: whole 256-row tiles, or a long stream with a ragged last tile (the video
     stream of every benchmark configuration, of the reference's published shapes -- 384x672, 576x1008, 768x1344: none a
     multiple of 256 tokens -- and of sequence-parallel shards); short ragged streams (unaligned text) stay on the 128-row GEMMs."""
-    return ((n_tok > 0 and n_tok % 256 == 0) or n_tok >= 1024) and inner % 256 == 0 and k % 64 == 0 and seq_off % 8 == 0 \
+    return ((n_tok > 0 and n_tok % 256 == 0) or n_tok >= 512) and inner % 256 == 0 and k % 64 == 0 and seq_off % 8 == 0 \
         and (kv_off or 0) % 8 == 0
 
 

@@ -502,9 +502,17 @@ class EasyAnimateInpaintPipeline(EasyAnimatePipeline):
                  timesteps=None):
         if num_images_per_prompt != 1:
             raise NotImplementedError("num_images_per_prompt > 1 (one video per call)")
-        if clip_image is not None and self.transformer.config.get("enable_clip_in_inpaint", True) and self.clip_image_encoder is not None:
-            raise NotImplementedError("the CLIP image encoder is a transformers model outside this build's scope; the V5.1 YAML sets "
-                                      "enable_clip_in_inpaint: false")
+        nc_ = self.vae.config.latent_channels if self.vae is not None else 16
+        if self.transformer.config.get("enable_clip_in_inpaint", True) and self.transformer.config.in_channels != nc_:
+            # pipeline_easyanimate_inpaint.py:1270-1311: an inpaint checkpoint with enable_clip_in_inpaint feeds CLIP tokens of
+            # clip_image -- or ZERO tokens when there is none -- through clip_proj into every forward.  The V5 / V5.1 YAMLs set the
+            # flag false; with it true the reference's own V5.1 transformer cannot run that branch either (transformer3d.py:1558-1561
+            # concatenates the CLIP tokens with ref_latents, which this pipeline never passes).  Skipping the tokens silently
+            # would be a different model: refuse.
+            raise NotImplementedError("enable_clip_in_inpaint=True on an inpaint transformer: the CLIP-token conditioning of "
+                                      "pipeline_easyanimate_inpaint.py:1270-1311 (clip_image, or zero tokens without one) is not part of "
+                                      "the V5 / V5.1 path (their YAMLs set enable_clip_in_inpaint: false); set it false in the transformer "
+                                      "config to run this checkpoint without CLIP conditioning")
         height = int(height // 16 * 16)
         width = int(width // 16 * 16)
         self._guidance_scale = guidance_scale

@@ -47,16 +47,16 @@ def _workspace_q(B: int, H: int, q_pad: int, device) -> torch.Tensor:
     return q
 
 
-def _workspace_heads(B: int, Hl: int, s_pad: int, device):
+def _workspace_heads(B: int, Hl: int, s_pad: int, device, dtype=torch.bfloat16):
     """q / k / v^T of ALL tokens for this rank's heads (head-parallel attention under sequence parallelism), zero-initialised
     once and reused by every block: rows >= seq are never written."""
-    key = ("heads", B, Hl, s_pad, str(device))
+    key = ("heads", B, Hl, s_pad, str(device), dtype)
     w = _ws.get(key)
     if w is None:
         for k in [k for k in _ws if k[0] == "heads"]:
             del _ws[k]
-        w = (torch.zeros(B, Hl, s_pad, 64, dtype=torch.bfloat16, device=device), torch.zeros(B, Hl, s_pad, 64, dtype=torch.bfloat16, device=device),
-             torch.zeros(B, Hl, 64, s_pad, dtype=torch.bfloat16, device=device))
+        w = (torch.zeros(B, Hl, s_pad, 64, dtype=dtype, device=device), torch.zeros(B, Hl, s_pad, 64, dtype=dtype, device=device),
+             torch.zeros(B, Hl, 64, s_pad, dtype=dtype, device=device))
         _ws[key] = w
     return w
 
@@ -114,7 +114,8 @@ class EasyAnimateAttnProcessor2_0:
         head0 = sp.rank * Hl
         q, k, vt = ws["q"], ws["k"], ws["vt"]
         n_own = lay.n_own
-        send = torch.empty(P, 3, B, Hl, nl * 64, dtype=torch.bfloat16, device=dev)
+        dt = q.dtype                     # bf16 in the product; the gloo / CPU tests drive the exchange with fp32 oracle tensors
+        send = torch.empty(P, 3, B, Hl, nl * 64, dtype=dt, device=dev)
         sv = send.view(P, 3, B, Hl, nl, 64)
         sv[:, 0, :, :, :n_own] = q[:, :, tp:tp + n_own].reshape(B, P, Hl, n_own, 64).transpose(0, 1)
         sv[:, 1, :, :, :n_own] = k[:, :, tp:tp + n_own].reshape(B, P, Hl, n_own, 64).transpose(0, 1)
@@ -124,7 +125,7 @@ class EasyAnimateAttnProcessor2_0:
             send[:, 2].view(P, B, Hl, 64, nl)[..., n_own:].zero_()
         recv = sp.all_to_all(send)                                   # [source rank, 3, B, Hl, nl * 64]
         s_pad = ops.round_up(T + Nt, 256)
-        qf, kf, vf = _workspace_heads(B, Hl, s_pad, dev)             # zero-initialised once; rows >= T + Nt are never written
+        qf, kf, vf = _workspace_heads(B, Hl, s_pad, dev, dt)         # zero-initialised once; rows >= T + Nt are never written
         hsl = slice(head0, head0 + Hl)
         qf[:, :, :T], kf[:, :, :T], vf[:, :, :, :T] = q[:, hsl, :T], k[:, hsl, :T], vt[:, hsl, :, :T]
         for g in range(P):
@@ -133,7 +134,7 @@ class EasyAnimateAttnProcessor2_0:
             kf[:, :, T + lo:T + hi] = recv[g, 1].view(B, Hl, nl, 64)[:, :, :hi - lo]
             vf[:, :, :, T + lo:T + hi] = recv[g, 2].view(B, Hl, 64, nl)[:, :, :, :hi - lo]
         ol = attend_heads(qf, kf, vf, Hl, head0, Nt)                  # [B, T + Nt, Hl * 64]
-        back = torch.empty(P, B, nl, Hl * 64, dtype=torch.bfloat16, device=dev)
+        back = torch.empty(P, B, nl, Hl * 64, dtype=dt, device=dev)
         for g in range(P):
             lo, hi = sp.shard_range(g)
             back[g, :, :hi - lo] = ol[:, T + lo:T + hi]
@@ -141,7 +142,7 @@ class EasyAnimateAttnProcessor2_0:
                 back[g, :, hi - lo:].zero_()
         mine = sp.all_to_all(back)                                    # [head owner, B, nl, Hl * 64]
         text = sp.all_gather(ol[:, :T].contiguous())                  # [head owner, B, T, Hl * 64]
-        o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        o = torch.zeros(B, S, d, dtype=dt, device=dev) if tp != T else torch.empty(B, S, d, dtype=dt, device=dev)   # (rows [T, tp): alignment gap)
         o[:, :T] = text.permute(1, 2, 0, 3).reshape(B, T, d)
         o[:, tp:tp + n_own] = mine.permute(1, 2, 0, 3).reshape(B, nl, d)[:, :n_own]
         return o
@@ -249,9 +250,9 @@ class EasyAnimateAttnProcessor2_0:
             nonlocal pending
             lq, lk, lv = mod.to_q, mod.to_k, mod.to_v
             nq, nk = mod.norm_q, mod.norm_k
-            # (under sequence parallelism a ragged shard keeps the three-GEMM route until the fused kernel's ragged tile has been
-            # run together with its kv_off / K | V-first forms on a GPU: tests/test_kernels_gpu.py covers the two separately)
-            if self.fuse_qkv and ops.qkv_fused_ok(n_tok, d, inp.shape[2], seq_off) and (lay is None or n_tok % 256 == 0):
+            # (ragged sequence-parallel shards included: the ragged last tile together with the exchange-slot geometry and the
+            # K | V-first split is covered by tests/test_kernels_gpu.py::test_qkv_projection_into_an_exchange_slot)
+            if self.fuse_qkv and ops.qkv_fused_ok(n_tok, d, inp.shape[2], seq_off):
                 # one launch: the [B, n, 3d] QKV buffer never exists (ea_qkv_gemm_norm_rope_bf16) -- or two, K | V first
                 args = (inp, gemm_weight(lq.weight), gemm_weight(lk.weight), gemm_weight(lv.weight),
                         f32(lq.bias), f32(lk.bias), f32(lv.bias), ws["q"], ws["k"], ws["vt"],

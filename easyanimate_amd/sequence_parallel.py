@@ -22,6 +22,15 @@ Two orthogonal axes, chosen per forward call:
   the key order; padding inside a short last shard is never part of a key range (a range may end anywhere, it only has
   to start on a multiple of 64).
 
+**The other exchange** (`EA_SP_MODE=heads` / `enable(mode="heads")`, SURVEY 5.7 design C): instead of gathering keys, a
+full-attention block swaps the partition for its attention -- an all-to-all hands every rank the q / k / v^T rows of ALL
+tokens for H / P' heads, ONE contiguous single-GPU attention launch runs on them (no second pass, no state round trip, the
+text queries computed once per head instead of on every rank), a second all-to-all returns each rank's rows for all heads.
+Per rank and block it moves 4 x (P'-1)/P' shard-sized tensors (q, k, v^T out, o back) against (P'-1) x 2 for the all-gather
+(equal at P' = 3, fewer from P' = 4 on), but nothing of it overlaps with the attention it feeds.  The sliding-window blocks
+always run this way (their scan orders scatter a shard over the whole sequence).  Both modes exist so that the first
+multi-GPU hardware session can compare them (`bench.py --gpus N --sp-mode heads`).
+
 One more all-gather (whole world) returns the velocity prediction of both batch elements / all shards to every rank,
 so that all ranks run the identical scheduler step.
 
@@ -34,6 +43,7 @@ covered by gloo/CPU tests (tests/test_sequence_parallel_cpu.py).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -96,16 +106,46 @@ class SequenceParallel:
         if cfg_parallel and self.world % 2 == 0:
             half = self.world // 2
             base = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
-            mine = None
-            for c in range(2):  # every rank creates every sub-group (collective call)
-                g = dist.new_group([base[c * half + i] for i in range(half)])
-                if self.world_rank // half == c:
-                    mine = g
+            # this rank's CFG half; created once per process and member-local (use_local_synchronization: `group` may be a
+            # strict sub-group of the world, and a second enable() does not leak another communicator)
+            c = self.world_rank // half
+            from .vae_parallel import _subgroup
+            mine = _subgroup([base[c * half + i] for i in range(half)])
             self._cfg = _Axis(self.world, self.world_rank, 2, mine)
         self.axis = self._flat
         self.n_total = 0
         self.n_loc = 0
         self._kv = None
+        self.mode = os.environ.get("EA_SP_MODE", "keys")
+        if self.mode not in ("keys", "heads"):
+            raise ValueError(f"EA_SP_MODE must be 'keys' or 'heads', not {self.mode!r}")
+        # bench.py: HIP events around every point where the compute stream waits for a collective (profile_wait = True)
+        self.profile_wait = False
+        self._waits = []
+
+    def _timed_wait(self, kind: str, fn, device):
+        """Run fn() -- something that makes the current stream wait for a collective -- between two HIP events on that stream:
+        the elapsed time between them is what the exchange costs the compute stream (the EXPOSED part; zero when the
+        collective finished under the kernels queued in front of the wait)."""
+        if not self.profile_wait or device is None or torch.device(device).type != "cuda":
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self._waits.append((kind, e0, e1))
+        return r
+
+    def exposed_wait_ms(self) -> dict:
+        """{kind: (count, total ms)} of the waits recorded since the last call (synchronises)."""
+        if self._waits:
+            torch.cuda.synchronize()
+        out = {}
+        for kind, e0, e1 in self._waits:
+            n, t = out.get(kind, (0, 0.0))
+            out[kind] = (n + 1, t + e0.elapsed_time(e1))
+        self._waits = []
+        return out
 
     # ---- per-call mode ------------------------------------------------------------------------
     def begin(self, batch: int) -> Tuple[int, int]:
@@ -212,33 +252,39 @@ class SequenceParallel:
 
     def exchange_finish(self, handle) -> None:
         """Wait for the all-gather (a stream-level wait with RCCL): the remote slots are then readable in place."""
-        if handle is not None and handle[0] is not None:
-            handle[0].wait()
+        if handle is not None:
+            self._timed_wait("kv_all_gather_wait", handle[0].wait if handle[0] is not None else (lambda: None), "cuda")
 
-    # ---- head parallelism of the sliding-window blocks -------------------------------------------
+    # ---- head parallelism (sliding-window blocks; every full-attention block with mode == "heads") --------------
     def all_to_all(self, send: torch.Tensor) -> torch.Tensor:
         """send[g] goes to sequence rank g; returns recv with recv[g] = what rank g sent here (equal chunks)."""
         if self.size == 1:
             return send
-        if not send.is_cuda or self._gloo_device_staging(send):
-            h, r = send.cpu().contiguous(), torch.empty(send.shape, dtype=send.dtype, device="cpu")
-            dist.all_to_all_single(r.view(-1), h.view(-1), group=self.axis.group)
-            return r.to(send.device)
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1), group=self.axis.group)
-        return recv
+
+        def run():
+            if not send.is_cuda or self._gloo_device_staging(send):
+                h, r = send.cpu().contiguous(), torch.empty(send.shape, dtype=send.dtype, device="cpu")
+                dist.all_to_all_single(r.view(-1), h.view(-1), group=self.axis.group)
+                return r.to(send.device)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1), group=self.axis.group)
+            return recv
+        return self._timed_wait("head_all_to_all", run, send.device)
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
         """[...] -> [P', ...] over the sequence ranks."""
         if self.size == 1:
             return x[None]
-        if not x.is_cuda or self._gloo_device_staging(x):
-            r = torch.empty((self.size,) + tuple(x.shape), dtype=x.dtype, device="cpu")
-            dist.all_gather_into_tensor(r.view(-1), x.cpu().contiguous().view(-1), group=self.axis.group)
-            return r.to(x.device)
-        recv = torch.empty((self.size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(recv.view(-1), x.contiguous().view(-1), group=self.axis.group)
-        return recv
+
+        def run():
+            if not x.is_cuda or self._gloo_device_staging(x):
+                r = torch.empty((self.size,) + tuple(x.shape), dtype=x.dtype, device="cpu")
+                dist.all_gather_into_tensor(r.view(-1), x.cpu().contiguous().view(-1), group=self.axis.group)
+                return r.to(x.device)
+            recv = torch.empty((self.size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(recv.view(-1), x.contiguous().view(-1), group=self.axis.group)
+            return recv
+        return self._timed_wait("text_all_gather", run, x.device)
 
     def all_reduce_sums(self, sums: torch.Tensor, n: int):
         """TeaCache: add the rel-L1 partial sums / element counts of every rank (batch slices and token shards)."""
@@ -293,6 +339,17 @@ class EmulatedRank(SequenceParallel):
         self._kv = None
         self._scratch = None
         self.emulate_exchange = False
+        self.mode = os.environ.get("EA_SP_MODE", "keys")
+        self.profile_wait = False
+        self._waits = []
+
+    # head-parallel blocks (EA_SP_MODE=heads, sliding-window blocks): the rank receives what it sent -- its own rows stand in
+    # for every peer's (same size, same statistics); no link time in the model
+    def all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+        return send
+
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        return x[None].expand((self.size,) + tuple(x.shape))
 
     def kv_buffer(self, B: int, H: int, lay: Layout, device, dtype=torch.bfloat16) -> torch.Tensor:
         key = (self.size, B, H, lay.rows, str(device), dtype)
@@ -345,10 +402,15 @@ class EmulatedRank(SequenceParallel):
 
 
 def enable(transformer, group: Optional[dist.ProcessGroup] = None, cfg_parallel: bool = True,
-           force: bool = False) -> SequenceParallel:
+           force: bool = False, mode: Optional[str] = None) -> SequenceParallel:
     """Attach multi-GPU sampling to an EasyAnimateTransformer3DModel (all ranks hold identical weights).
-    force=True keeps the multi-rank code path on even in a world of one rank (bring-up, see force_exchange)."""
+    force=True keeps the multi-rank code path on even in a world of one rank (bring-up, see force_exchange).
+    mode: "keys" (K / V^T all-gather, the default) or "heads" (head all-to-all); None = EA_SP_MODE from the environment."""
     sp = SequenceParallel(group, cfg_parallel=cfg_parallel)
+    if mode is not None:
+        if mode not in ("keys", "heads"):
+            raise ValueError(f"mode must be 'keys' or 'heads', not {mode!r}")
+        sp.mode = mode
     sp.force_exchange = bool(force)
     transformer.sequence_parallel = sp if (sp.world > 1 or force) else None
     return sp

@@ -40,6 +40,20 @@ import torch
 import torch.distributed as dist
 
 _ACTIVE: Optional["TemporalParallel"] = None
+_SUBGROUPS: dict = {}
+
+
+def _subgroup(ranks: List[int]) -> dist.ProcessGroup:
+    """The process group of `ranks` (global rank numbers), created ONCE per process and reused by every later
+    enable_temporal_parallel call.  use_local_synchronization: only the members take part in the creation, so `group` may be a
+    strict sub-group of the world (one CFG half, one replica of a serving node) -- the plain new_group is collective over the
+    DEFAULT group and would hang there."""
+    key = tuple(ranks)
+    g = _SUBGROUPS.get(key)
+    if g is None:
+        g = dist.new_group(list(ranks), use_local_synchronization=True)
+        _SUBGROUPS[key] = g
+    return g
 
 
 def current() -> Optional["TemporalParallel"]:
@@ -62,10 +76,7 @@ class TemporalParallel:
         self.row_group = None
         if spatial > 1:
             base = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
-            for t in range(self.pt):           # every rank creates every sub-group (collective call)
-                g = dist.new_group([base[t * spatial + i] for i in range(spatial)])
-                if t == self.rank_t:
-                    self.row_group = g
+            self.row_group = _subgroup([base[self.rank_t * spatial + i] for i in range(spatial)])
 
     # ---- partition ---------------------------------------------------------------------------------------------
     def plan(self, latent_frames: int) -> List[Tuple[int, int]]:

@@ -352,6 +352,33 @@ def gen_vae_ragged(ns, shim):
           {k: v for k, v in out.items() if k.endswith("floor_mse")})
 
 
+@section("vae_dec_wide")
+def gen_vae_dec_wide(ns, shim):
+    # ---- round 4 (VERDICT r3 next #3b): full-width decoder at 5 x 256 x 1024 -- output rows of 1024 voxels = TWO 512-voxel tiles
+    # per row, the geometry of every full-resolution layer of a 49 x 1024^2 decode; source rows of 256 / 512 voxels for the two
+    # large up-samplers (the sub-pixel kernels) and 3 -> 5 frames behind a virtual x2 (the merged-tap layers).  The reference in
+    # its chunked / cached mode, fp32; every second pixel stored (fp16), plus the reference's own bf16 floor.
+    vkw = dict(FULL_VAE)
+    vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()
+    shapes = _load_sd(vae, 2, "default")
+    _, zlat = vae_ragged_inputs(seed=14, frames=5, height=256, width=1024)
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        dec = vae.decode(zlat)[0]
+    print("  decode fp32 5x256x1024", time.time() - t0, flush=True)
+    out = dict(cfg=vkw, shapes=shapes, seed=2, style="default", input_seed=14, frames=5, height=256, width=1024,
+               z_sum=zlat.double().sum().item(), dec_sub_f16=dec[..., ::2, ::2].to(torch.float16).contiguous(), dec_std=dec.std().item(),
+               dec_shape=tuple(dec.shape))
+    torch.save(out, os.path.join(OUT, "vae_dec_5x256x1024.pt"))
+    t0 = time.time()
+    with torch.no_grad():
+        db = vae.to(torch.bfloat16).decode(zlat.bfloat16())[0].float()
+    out["dec_floor_mse"] = _mse(db, dec)
+    torch.save(out, os.path.join(OUT, "vae_dec_5x256x1024.pt"))
+    print("  bf16 pass", time.time() - t0, "dec std", out["dec_std"], "shape", out["dec_shape"], "floor", out["dec_floor_mse"], flush=True)
+
+
 def _ref_loop(ns, shim, m, latents, enc, rope, steps, guidance, dt, keep=None):
     """The reference's sampling loop (pipeline_easyanimate.py:1069-1111) over the shim-hosted reference transformer."""
     mm = copy.deepcopy(m).to(dt)

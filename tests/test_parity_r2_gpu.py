@@ -281,6 +281,37 @@ def test_vae_decoder_512_rows_vs_golden():
     print(f"[parity] full-width decoder 5x512^2: MSE={mse:.3e} (ref std {g['dec_std']:.3f}); kernels {c}")
     assert mse < BAR
     assert c.get("conv_row16_m512", 0) >= 6 and c.get("conv_row16_256_ups", 0) >= 1 and c.get("conv_row16_256", 0) >= 1
+    # the two algebraic shortcuts are in play in this decode: the 256-voxel source rows of the last up-sampler take the sub-pixel
+    # kernel, and the first convolution behind each virtual temporal x2 runs 18 merged taps
+    assert c.get("conv_row16_256_subpixel", 0) >= 1 and c.get("conv_tmerge_18_taps", 0) >= 1, c
+
+
+def test_vae_decoder_two_tile_rows_vs_golden():
+    """Full-width decoder at 5 x 256 x 1024 against the reference (fp32, chunked mode; every second pixel stored): output rows of
+    1024 voxels = TWO 512-voxel tiles per row (the geometry of every full-resolution layer of a 49 x 1024^2 decode), both large
+    up-samplers on the sub-pixel kernel (source rows of 256 and 512 voxels), merged temporal taps behind both virtual x2 -- all
+    of the round-3 shortcuts active together at depth, against the unchanged reference (vaemodules/upsamplers.py:123-153,
+    omnigen_enc_dec.py:555-677)."""
+    from easyanimate_amd import AutoencoderKLMagvit, _lib
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle.gen_golden import vae_ragged_inputs
+    g = _load("vae_dec_5x256x1024.pt")
+    _, z = vae_ragged_inputs(g["input_seed"], g["frames"], g["height"], g["width"])
+    assert abs(z.double().sum().item() - g["z_sum"]) < 1e-4
+    vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    vae.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    _lib.reset_counters()
+    with torch.no_grad():
+        dec = vae.decode(z.to(DEV).bfloat16())[0]
+    torch.cuda.synchronize()
+    c = _lib.counters()
+    assert tuple(dec.shape) == tuple(g["dec_shape"]) == (1, 3, 5, 256, 1024)
+    mse = _mse(dec[..., ::2, ::2].float(), g["dec_sub_f16"].float())
+    print(f"[parity] full-width decoder 5x256x1024 (two 512-voxel tiles per row): MSE={mse:.3e} (ref std {g['dec_std']:.3f}; the reference's "
+          f"own bf16 decode: {g.get('dec_floor_mse', float('nan')):.3e}); kernels {c}")
+    assert mse < BAR
+    assert c.get("conv_row16_m512", 0) >= 6 and c.get("conv_row16_256_subpixel", 0) >= 2 and c.get("conv_tmerge_18_taps", 0) >= 2, c
 
 
 # ---------------------------------------------------------------------------------------------------------

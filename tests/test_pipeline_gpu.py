@@ -19,7 +19,7 @@ def _models(in_channels):
     gv = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
     sd_t = synth_state_dict(gt["shapes"], gt["seed"], gt["style"])
     sd_v = synth_state_dict(gv["shapes"], gv["seed"], gv["style"])
-    m = EasyAnimateTransformer3DModel.from_config(gt["cfg"])
+    m = EasyAnimateTransformer3DModel.from_config(dict(gt["cfg"], enable_clip_in_inpaint=False))     # the V5 / V5.1 YAML value
     m.load_state_dict(sd_t, strict=True)
     vae = AutoencoderKLMagvit.from_config(gv["cfg"])
     vae.load_state_dict(sd_v, strict=True)
@@ -208,6 +208,21 @@ def test_guidance_rescale_kernel_and_loop():
     print(f"[parity] 6-step loop with guidance_rescale 0.7: latent MSE vs oracle {mse:.3e} (the rescale moves the result by "
           f"{((ref - ref0) ** 2).mean().item():.3e})")
     assert mse < 1e-4 and not torch.equal(ref, ref0)
+
+
+def test_inpaint_pipeline_refuses_clip_conditioning():
+    """An inpaint checkpoint whose config says enable_clip_in_inpaint (the constructor default) would receive CLIP tokens -- zeros
+    without a clip_image -- in every forward of the reference (pipeline_easyanimate_inpaint.py:1296-1311,1509-1513): not built,
+    and never skipped silently."""
+    from easyanimate_amd import EasyAnimateInpaintPipeline, EasyAnimateTransformer3DModel, FlowMatchEulerDiscreteScheduler
+    gt = torch.load(os.path.join(GOLD, "transformer_inp.pt"), weights_only=False)
+    with torch.device("meta"):
+        m = EasyAnimateTransformer3DModel.from_config(gt["cfg"])
+    assert m.config.get("enable_clip_in_inpaint", True) is True and m.config.in_channels == 33
+    pipe = EasyAnimateInpaintPipeline(vae=None, transformer=m, scheduler=FlowMatchEulerDiscreteScheduler(shift=1.0))
+    with pytest.raises(NotImplementedError, match="enable_clip_in_inpaint"):
+        pipe(prompt_embeds=torch.zeros(1, 7, 48), negative_prompt_embeds=torch.zeros(1, 7, 48), video_length=9, height=64, width=64,
+             num_inference_steps=2)
 
 
 def test_inpaint_pipeline_branches():

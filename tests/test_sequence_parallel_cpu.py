@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
+def _worker(rank, world, port, n_video, T, cfg_parallel, ret, mode="keys", H=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -34,7 +34,7 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
         from oracle import restatement as R
         torch.manual_seed(0)
         torch.set_num_threads(1)
-        d, H, B = 128, 2, 2
+        d, B = 64 * H, 2
         shapes = {}
         for n in ("norm1", "norm2"):
             shapes.update({f"{n}.linear.weight": (6 * d, 32), f"{n}.linear.bias": (6 * d,), f"{n}.norm.weight": (d,), f"{n}.norm.bias": (d,)})
@@ -114,6 +114,23 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
             assert torch.allclose(vtr[:, :, :, vo:vo + rhi - rlo], v_full[:, :, rlo:rhi].transpose(2, 3), atol=1e-5)
             assert not kr[:, :, vo + rhi - rlo:].any()    # tail of a short shard and the pad to 256 rows: zero
 
+        use_heads = mode == "heads" and sp.size > 1      # one sequence rank (CFG split only): nothing to exchange in either mode
+        if use_heads:
+            # ---- EA_SP_MODE=heads: the product's own exchange code (processor._head_parallel: head all-to-all, contiguous operands
+            # of all tokens for H / P' heads, all-to-all back, text rows all-gathered) around the oracle's attention
+            from easyanimate_amd.processor import EasyAnimateAttnProcessor2_0
+            sp.mode = "heads"
+            proc = EasyAnimateAttnProcessor2_0()
+            assert proc._heads_mode(lay, sp, H)
+            seen = []
+
+            def attend_heads(qf, kf, vf, Hl, head0, Nt):
+                seen.append((Hl, head0, Nt))
+                S_ = T + Nt
+                assert not qf[:, :, S_:].any() and not vf[:, :, :, S_:].any()
+                return F.scaled_dot_product_attention(qf[:, :, :S_], kf[:, :, :S_], vf[:, :, :, :S_].transpose(2, 3)).transpose(1, 2).reshape(Bl, S_, Hl * 64)
+            o = proc._head_parallel(dict(q=qws, k=k_own, vt=vt_own), Bl, H, T, lay.q_end, d, "cpu", lay, sp, attend_heads)
+            assert seen == [(H // sp.size, sp.rank * (H // sp.size), n_video)]
         # ---- queries = text rows + own rows; keys = the own slot's ranges, then the shard rows of every other slot
         Ks = [k_own[:, :, lo_:hi_] for lo_, hi_ in lay.own_ranges]
         Vs = [vt_own[:, :, :, lo_:hi_] for lo_, hi_ in lay.own_ranges]
@@ -126,11 +143,12 @@ def _worker(rank, world, port, n_video, T, cfg_parallel, ret):
             Ks.append(kr[:, :, vo:vo + take]); Vs.append(vtr[:, :, :, vo:vo + take])
             left -= take
         assert left == 0
-        K_, V_ = torch.cat(Ks, 2), torch.cat(Vs, 3).transpose(2, 3)
-        assert K_.shape[2] == T + n_video
-        ws = dict(q=qws)
-        oo = F.scaled_dot_product_attention(ws["q"][:, :, :lay.q_end], K_, V_)
-        o = oo.transpose(1, 2).reshape(Bl, lay.q_end, d)
+        if not use_heads:
+            K_, V_ = torch.cat(Ks, 2), torch.cat(Vs, 3).transpose(2, 3)
+            assert K_.shape[2] == T + n_video
+            ws = dict(q=qws)
+            oo = F.scaled_dot_product_attention(ws["q"][:, :, :lay.q_end], K_, V_)
+            o = oo.transpose(1, 2).reshape(Bl, lay.q_end, d)
         o_t, o_v = o[:, :T], o[:, vo:]
         ah = F.linear(o_v, sd["attn1.to_out.0.weight"], sd["attn1.to_out.0.bias"])
         ae = F.linear(o_t, sd["attn2.to_out.0.weight"], sd["attn2.to_out.0.bias"])
@@ -159,6 +177,25 @@ def test_sequence_parallel_block_equals_unsharded(world, n_video, T, cfg_paralle
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_video, T, cfg_parallel, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        err_h, err_e = ret[r]
+        assert err_h < 2e-5 and err_e < 2e-5, (r, err_h, err_e)
+
+
+@pytest.mark.parametrize("world,n_video,T,cfg_parallel,H", [
+    (2, 200, 7, False, 2),       # flat split, ragged last shard, unaligned text
+    (3, 330, 16, True, 3),       # odd world: three sequence ranks, one head each
+    (4, 330, 64, True, 4),       # 2 (CFG) x 2 (sequence)
+    (4, 256, 7, False, 4),       # four sequence ranks of both batch elements
+    (8, 900, 16, True, 8),       # 2 x 4: the shape of `bench.py --gpus 8 --sp-mode heads`
+])
+def test_head_parallel_block_equals_unsharded(world, n_video, T, cfg_parallel, H):
+    """EA_SP_MODE=heads (SURVEY 5.7 design C): the full-attention block exchanges heads instead of keys -- the product's
+    exchange code (processor._head_parallel) over gloo around the oracle's arithmetic equals the unsharded oracle block."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_video, T, cfg_parallel, ret, "heads", H), nprocs=world, join=True)
     assert len(ret) == world
     for r in range(world):
         err_h, err_e = ret[r]

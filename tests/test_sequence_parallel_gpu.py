@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cfg_parallel, ret):
+def _worker(rank, world, port, cfg_parallel, ret, mode="keys"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -41,8 +41,8 @@ def _worker(rank, world, port, cfg_parallel, ret):
         rope = get_3d_rotary_pos_embed(64, ((0, 8), (30, 38)), (16, 12), 5)
         with torch.no_grad():
             ref = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
-            sp = sequence_parallel.enable(m, cfg_parallel=cfg_parallel)
-            assert m.sequence_parallel is sp and sp.world == world
+            sp = sequence_parallel.enable(m, cfg_parallel=cfg_parallel, mode=mode)
+            assert m.sequence_parallel is sp and sp.world == world and sp.mode == mode
             out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]
             out2 = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0]  # workspace reuse
         err = (out.float() - ref.float()).abs().max().item()
@@ -51,13 +51,16 @@ def _worker(rank, world, port, cfg_parallel, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cfg_parallel", [(2, True), (4, True), (3, True)])
-def test_sp_transformer_equals_single_rank(world, cfg_parallel):
+@pytest.mark.parametrize("world,cfg_parallel,mode", [(2, True, "keys"), (4, True, "keys"), (3, True, "keys"),
+                                                     (4, True, "heads"), (2, False, "heads")])     # (the tiny model has 2 heads)
+def test_sp_transformer_equals_single_rank(world, cfg_parallel, mode):
+    """mode "keys": K / V^T all-gather + two-pass segment attention; "heads" (EA_SP_MODE=heads): head all-to-all around one
+    contiguous attention launch per block."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), cfg_parallel, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), cfg_parallel, ret, mode), nprocs=world, join=True)
     assert len(ret) == world
-    print(f"[parity] world {world} cfg_parallel {cfg_parallel} vs single:", dict(ret))
+    print(f"[parity] world {world} cfg_parallel {cfg_parallel} mode {mode} vs single:", dict(ret))
     seq = world // 2 if (cfg_parallel and world % 2 == 0) else world
     n_loc = {1: 960, 2: 512, 3: 320}[seq]
     for r in range(world):
@@ -247,6 +250,21 @@ def test_bench_self_launches_its_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1 and out["value"] > 0
     assert out["rccl"]["ranks_seen"] == 2 and out["rccl"]["backend"] == "gloo"
     assert out["config"]["finite_output"] and out["config"]["parallelism"].startswith("cfg2 x sp1")
+    # the self-check of the first hardware run: the final latents are bit-identical on every rank, and every rank reports where
+    # its compute stream waited for a collective (CFG split only: no per-block exchange, nothing to wait for)
+    assert out["rank_agreement"] is True and out["exchange"]["mode"] == "keys" and len(out["exchange"]["per_rank"]) == 2
+    # four ranks = CFG 2 x sequence 2, both exchanges: K / V^T all-gather (one wait per block) and head all-to-all (two per block
+    # + the text rows' all-gather)
+    for mode, kinds in (("keys", {"kv_all_gather_wait"}), ("heads", {"head_all_to_all", "text_all_gather"})):
+        r4 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--config", "tiny", "--steps", "1", "--warmup", "1",
+                             "--no-cpu-baseline", "--no-vae", "--sp-mode", mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r4.returncode == 0, r4.stderr[-3000:]
+        o4 = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][0])
+        print(f"[bench --gpus 4 --sp-mode {mode}]", o4["exchange"], o4["rank_agreement"])
+        assert o4["rank_agreement"] is True and o4["exchange"]["mode"] == mode and o4["config"]["parallelism"].startswith("cfg2 x sp2")
+        for rr in o4["exchange"]["per_rank"]:
+            assert set(rr["waits_per_step"]) == kinds, rr
+            assert rr["waits_per_step"].get("kv_all_gather_wait", 2.0) == 2.0 and rr["waits_per_step"].get("head_all_to_all", 4.0) == 4.0   # 2 blocks
     # without the shared-device switch a 1-GPU box refuses (one rank per GPU), with a clear message and a non-zero code
     env.pop("EA_BENCH_SHARED_DEVICE")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "tiny"], env=env,
@@ -301,7 +319,7 @@ def test_sp_sliding_window_blocks_equal_single_rank(world, cfg_parallel):
         assert n_win == 1 and err <= 2e-2 * max(1.0, scale) and mse < 1e-4
 
 
-def _worker_full_width(rank, world, port, ret):
+def _worker_full_width(rank, world, port, ret, mode="keys"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -316,7 +334,7 @@ def _worker_full_width(rank, world, port, ret):
         m = EasyAnimateTransformer3DModel.from_config(g["cfg"])
         m.load_state_dict(synth_state_dict(g["shapes"], g["seed"], g["style"]), strict=True)
         m = m.to(torch.bfloat16).to("cuda:0").eval()
-        sp = sequence_parallel.enable(m)
+        sp = sequence_parallel.enable(m, mode=mode)
         _lib.reset_counters()
         with torch.no_grad():
             out = m(lat.to("cuda:0").bfloat16(), g["t"].to("cuda:0").bfloat16(), encoder_hidden_states=enc.to("cuda:0").bfloat16(),
@@ -329,18 +347,26 @@ def _worker_full_width(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_sp_full_width_forward_vs_reference_golden():
+@pytest.mark.parametrize("mode", ["keys", "heads"])
+def test_sp_full_width_forward_vs_reference_golden(mode):
     """The multi-GPU path at FULL WIDTH (d = 3072, 48 heads: the 256^2 GEMMs projecting K | V^T into the exchange slots, the
-    range + segment attention passes) against the REFERENCE's golden, not against the single-rank product: CFG 2 x sequence 2
-    on the ragged grid of the published 384 x 672 shape (N = 2016: shards of 1024 and 992 tokens)."""
+    range + segment attention passes -- or, mode "heads", the head all-to-all around one contiguous launch over 24 heads) against
+    the REFERENCE's golden, not against the single-rank product: CFG 2 x sequence 2 on the ragged grid of the published
+    384 x 672 shape (N = 2016: shards of 1024 and 992 tokens -- the second one ends in a ragged 256-row tile, and it takes the
+    fused QKV launch too: K | V thirds first, into the exchange slot, then the Q third)."""
     world = 4
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_full_width, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker_full_width, args=(world, _free_port(), ret, mode), nprocs=world, join=True)
     assert len(ret) == world
-    print("[parity] full-width transformer under CFG 2 x sequence 2 vs the reference golden:", dict(ret))
+    print(f"[parity] full-width transformer under CFG 2 x sequence 2 ({mode}) vs the reference golden:", dict(ret))
     for r in range(world):
         mse, size, rng, cnt = ret[r]
         assert size == 2 and rng == ((0, 1024) if r % 2 == 0 else (1024, 2016))
         assert mse < 1e-4
-        assert cnt.get("attention_v3_segments", 0) == 2 and cnt.get("gemm_qkv_fused", 0) >= 2, cnt   # remote-slot pass once per block
+        if mode == "keys":
+            assert cnt.get("attention_v3_segments", 0) == 2, cnt          # remote-slot pass once per block
+            # text stream (256 rows) in one launch, video shard (1024 / 992 rows: ragged on the odd ranks) K | V first, then Q
+            assert cnt.get("gemm_qkv_fused_kv_part", 0) == 2 and cnt.get("gemm_qkv_fused_q_part", 0) == 2 and cnt.get("gemm_qkv_fused", 0) == 6, cnt
+        else:
+            assert cnt.get("attention_v3", 0) == 2 and "attention_v3_segments" not in cnt and cnt.get("gemm_qkv_fused", 0) == 4, cnt
