@@ -618,6 +618,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 // SWAP = 1 exchanges the MFMA operand roles (activation fragment as A, weight fragment as B): the accumulator tile is
 // then the transpose -- a lane holds 4 consecutive output ROWS of one column (the fused QKV kernel's V^T tiles).
 // W8 = the fp8-weight variant (needs `W8Lane w8`, set up by the kernel): W tiles through registers instead of LDS-DMA.
+#define EA_G3_STAMP1
 #define EA_G3_MAINLOOP(SWAP, W8)                                                                \
     {                                                                                           \
         int w8k = 0;                                                                            \
@@ -637,6 +638,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         __builtin_amdgcn_s_barrier();                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                      \
+        EA_G3_STAMP1                                                                            \
         if (wr == 1) __builtin_amdgcn_s_barrier(); /* stagger: group 1 runs one barrier behind group 0 */ \
         __builtin_amdgcn_sched_barrier(0);                                                      \
         for (int t = 0; t < nk; t += 2) {                                                       \
@@ -652,70 +654,14 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         if (wr == 0) __builtin_amdgcn_s_barrier(); /* balance the stagger */                    \
     }
 
-template <int EPI, bool W8>
-__global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+// ---- epilogue of ONE wave tile (128 output rows x 64 columns, acc[i][j]: MFMA tile (row block i, column block j), C^T
+// orientation: a lane holds 4 consecutive columns of row lr) through the wave-private 16 KiB LDS image `img` (rows = the wave's
+// 128 output rows, 128 B = its 64 columns, 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and
+// the read-out use).  Shared by the eight-wave 256 x 256 kernel and the four-wave 128 x 256 kernel.
+template <int EPI>
+__device__ __forceinline__ void gemm_wave_epilogue(const GemmArgs& p, int b, f32x4_t (&acc)[8][4], char* const img, const int mrow0,
+                                                   const int ncol0, const int lane) {
     const int lr = lane & 15, lq = lane >> 4;
-
-    int tm, tn;
-    if (!tile_of_block(p, tm, tn)) return;
-    const int b = blockIdx.y;
-    const int row0 = tm * 256, col0 = tn * 256;
-    const unsigned short* Ab = p.A + b * p.abs_;
-
-    const unsigned short* asrc[4];
-    const unsigned short* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
-        const int cs = c ^ (r & 7);
-        int ra = row0 + r;
-        ra = ra < p.M ? ra : p.M - 1;
-        int rw = col0 + r;
-        rw = rw < p.N ? rw : p.N - 1;
-        asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
-        wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
-    }
-    char* const dma_a = smem + wave * 4096;
-    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-    // fragment byte offsets: row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 * ks2 + lq; + 2048 per 16-row MFMA tile
-    unsigned a_k[2], w_k[2];
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-        w_k[ks2] = 2 * OPER2 + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-    }
-    const int nk = p.K / BK;
-    bf16x8 wf[4];
-    W8Lane w8;
-    if (W8) {   // thread (row tid / 2, k half tid % 2): 32 fp8 weights per K tile
-        const int r = tid >> 1, h = tid & 1;
-        int rw = col0 + r;
-        rw = rw < p.N ? rw : p.N - 1;
-        w8.src = reinterpret_cast<const unsigned char*>(p.W) + (int64_t)rw * p.K + h * 32;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w8.lds[c] = r * 128 + (((h * 4 + c) ^ (r & 7)) << 4);
-    }
-
-    EA_G3_MAINLOOP(0, W8)
-
-    // ---- epilogue through the wave-private 16 KiB image (rows = the wave's 128 output rows, 128 B = its 64 columns,
-    // 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and the read-out already use)
-    char* const img = smem + wave * 16384;
-    const int mrow0 = row0 + wr * 128, ncol0 = col0 + wc * 64;
     const int r8 = lane >> 3, c8 = lane & 7;
     if (EPI == EA_EPI_BIAS_GATE_RES) {
         const unsigned short* Rb = p.res + b * p.rbs;
@@ -772,6 +718,94 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
         const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
         if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8) = o;
     }
+}
+
+template <int EPI, bool W8>
+__global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lq = lane >> 4;
+#ifdef EA_GEMM_TIMESTAMPS
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+    unsigned long long ts1 = 0;
+#endif
+
+    int tm, tn;
+    if (!tile_of_block(p, tm, tn)) return;
+    const int b = blockIdx.y;
+    const int row0 = tm * 256, col0 = tn * 256;
+    const unsigned short* Ab = p.A + b * p.abs_;
+
+    const unsigned short* asrc[4];
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ (r & 7);
+        int ra = row0 + r;
+        ra = ra < p.M ? ra : p.M - 1;
+        int rw = col0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
+        wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
+    }
+    char* const dma_a = smem + wave * 4096;
+    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment byte offsets: row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 * ks2 + lq; + 2048 per 16-row MFMA tile
+    unsigned a_k[2], w_k[2];
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+        w_k[ks2] = 2 * OPER2 + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+    }
+    const int nk = p.K / BK;
+    bf16x8 wf[4];
+    W8Lane w8;
+    if (W8) {   // thread (row tid / 2, k half tid % 2): 32 fp8 weights per K tile
+        const int r = tid >> 1, h = tid & 1;
+        int rw = col0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        w8.src = reinterpret_cast<const unsigned char*>(p.W) + (int64_t)rw * p.K + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w8.lds[c] = r * 128 + (((h * 4 + c) ^ (r & 7)) << 4);
+    }
+
+#ifdef EA_GEMM_TIMESTAMPS
+#undef EA_G3_STAMP1
+#define EA_G3_STAMP1 ts1 = __builtin_readcyclecounter();
+#endif
+    EA_G3_MAINLOOP(0, W8)
+#ifdef EA_GEMM_TIMESTAMPS
+#undef EA_G3_STAMP1
+#define EA_G3_STAMP1
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
+
+    // ---- epilogue through the wave-private 16 KiB image (rows = the wave's 128 output rows, 128 B = its 64 columns,
+    // 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and the read-out already use)
+    char* const img = smem + wave * 16384;
+    const int mrow0 = row0 + wr * 128, ncol0 = col0 + wc * 64;
+    gemm_wave_epilogue<EPI>(p, b, acc, img, mrow0, ncol0, lane);
+#ifdef EA_GEMM_TIMESTAMPS
+    if (g_gemm_ts && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g_gemm_ts + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 5;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
+        d[4] = 0;
+    }
+#endif
 }
 
 // =================================================================================================

@@ -965,3 +965,4 @@ def test_attention_segments_slot_rows(P, rank, T, nl, n_last):
     assert rel < 8e-3
 
 
+

@@ -11,6 +11,7 @@ from easyanimate_amd import _lib, ops
 
 lib = _lib.load()
 _lib.set_option("gemm_tile", 256)
+print(json.dumps({"gemm_mfma": _lib.get_option("gemm_mfma")}))
 for (M, N, K, epi) in [(106496, 3072, 3072, 0), (106496, 12288, 3072, 1), (106496, 3072, 12288, 2), (8192, 8192, 8192, 0)]:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
