@@ -37,6 +37,8 @@ PROTOTYPES = {
     "ea_attention_fwd_segments_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _F, _P, _I, _P],
     "ea_attention_d512_fwd_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _F, _P],
     "ea_attention_window_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "ea_attention_window_mapped_fwd_bf16": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P],
+    "ea_permute_cols_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_attention_fwd_range_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "ea_patchify": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_unpatchify": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -175,11 +175,24 @@ constexpr int ATT_LDS = 2 * ATT_STAGE;      // 32 KiB
 // are visited; inside them the band is masked with -inf.  A query whose visited tiles so far held none of its keys has a
 // running maximum of -inf: the exponent shift is then taken as 0 (every p = exp2(-inf) = 0, alpha = exp2(-inf) = 0 on
 // all-zero state) instead of forming -inf - (-inf); every query sees at least itself, so the final row sum is > 0.
-template <bool WINDOW>
+// MAPPED (round 4, the SWA processor's six scan orders without index copies): the queries / keys of head h are visited in the
+// scan order map[h][p] (scan position p -> token), but q / k stay where the projection wrote them -- row `row_off + token` of
+// the natural-order workspace -- and are ADDRESSED through the map: the Q fragments of position p come from row
+// row_off + map[h][p], and the K tile's LDS-DMA rows point at the mapped tokens (the per-lane row index of tile t + 1 is loaded
+// one tile ahead).  V^T cannot be gathered by row DMA (a key is a COLUMN of it): it comes from a buffer permuted beforehand
+// (ea_gather_cols_bf16; rows of vt_pad elements).  The result row of position p goes back to token order in the store,
+// with the cross pass (token order, like out) added (processor.py:435): out[r] = bf16(bf16(window result) + cross[r]), r = row_off + map[h][p].
+struct AttWindowMap {
+    const int* map;                    // [heads, seq] int32: scan position -> token
+    const unsigned short* cross;       // [batch, row_off + seq, heads*64] (out's strides), token order
+    int row_off, vt_pad;
+};
+template <bool WINDOW, bool MAPPED = false>
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K, const unsigned short* __restrict__ Vt,
     unsigned short* __restrict__ O, int64_t o_bs, int heads, int bh_total, int seq, int s_pad, int q_begin,
-    int q_end, int nqb, float scale_log2e, int window) {
+    int q_end, int nqb, float scale_log2e, int window, AttWindowMap wm = AttWindowMap()) {
+    static_assert(!MAPPED || WINDOW, "the mapped form serves the window pass only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -194,16 +207,19 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     const int b = bh / heads, h = bh % heads;
     const int q0 = q_begin + qb * ATT_QB + wave * 64;  // first query row of this wave
 
+    const int v_pad = MAPPED ? wm.vt_pad : s_pad;
     const unsigned short* Qh = Q + (int64_t)bh * s_pad * 64;
     const unsigned short* Kh = K + (int64_t)bh * s_pad * 64;
-    const unsigned short* Vh = Vt + (int64_t)bh * 64 * s_pad;
+    const unsigned short* Vh = Vt + (int64_t)bh * 64 * v_pad;
+    const int* const hm = MAPPED ? wm.map + (int64_t)h * seq : nullptr;
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane (n = query l31, k-half hi)
     bf16x8 qf[2][4];
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         int qr = q0 + qi * 32 + l31;
-        qr = qr < s_pad ? qr : s_pad - 1;
+        if (MAPPED) qr = wm.row_off + hm[qr < seq ? qr : seq - 1];
+        else qr = qr < s_pad ? qr : s_pad - 1;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds)
             qf[qi][ds] = *reinterpret_cast<const bf16x8*>(Qh + (int64_t)qr * 64 + ds * 16 + hi * 8);
@@ -212,21 +228,31 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
     // ---- DMA source pointers: per wave 2 pieces of K tile + 2 pieces of V^T tile (1 KiB each)
     const unsigned short* ksrc[2];
     const unsigned short* vsrc[2];
+    int krel[2], kcs[2], mrow[2] = {0, 0};    // MAPPED: tile-relative key row of the lane's two pieces, its source chunk, the mapped token
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int L = (wave * 2 + i) * 64 + lane;
         const int r = L >> 3, c = L & 7;
         const int cs = c ^ ((r >> 1) & 7);
+        krel[i] = r; kcs[i] = cs * 8;
         ksrc[i] = Kh + (int64_t)r * 64 + cs * 8;       // + kv0*64 per tile
-        vsrc[i] = Vh + (int64_t)r * s_pad + cs * 8;    // + kv0 per tile
+        vsrc[i] = Vh + (int64_t)r * v_pad + cs * 8;    // + kv0 per tile
     }
+    auto load_map = [&](int t) {      // the tokens behind the lane's two key rows of tile t (masked rows: any valid token)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kp = t * ATT_KV + krel[i];
+            mrow[i] = hm[kp < seq ? kp : seq - 1];
+        }
+    };
     auto issue = [&](int t, int stage) {
         char* sk = smem + stage * ATT_STAGE + wave * 2048;
         char* sv = sk + ATT_TILE;
         const int kv0 = t * ATT_KV;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            glds16(ksrc[i] + (int64_t)kv0 * 64, sk + i * 1024);
+            if (MAPPED) glds16(Kh + (int64_t)(wm.row_off + mrow[i]) * 64 + kcs[i], sk + i * 1024);
+            else glds16(ksrc[i] + (int64_t)kv0 * 64, sk + i * 1024);
             glds16(vsrc[i] + kv0, sv + i * 1024);
         }
     };
@@ -262,12 +288,21 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
         const int t_hi = hi_key / ATT_KV + 1;
         nt = t_hi < nt ? t_hi : nt;
     }
+    if (MAPPED) {
+        load_map(t_lo);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mrow[0]), "+v"(mrow[1]) :: "memory");
+    }
     issue(t_lo, t_lo & 1);
+    if (MAPPED && t_lo + 1 < nt) load_map(t_lo + 1);
     for (int t = t_lo; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (MAPPED: the wait also covers the map rows of tile t + 1, requested a tile ago; the asm's operands keep their uses behind it)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mrow[0]), "+v"(mrow[1]) :: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        if (t + 1 < nt) {
+            issue(t + 1, (t + 1) & 1);
+            if (MAPPED && t + 2 < nt) load_map(t + 2);
+        }
         const char* sk = smem + (t & 1) * ATT_STAGE;
         const char* sv = sk + ATT_TILE;
         const int kv0 = t * ATT_KV;
@@ -361,7 +396,9 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
         const float inv = 1.0f / l;
         const int qr = q0 + qi * 32 + l31;
         if (qr < q_end) {
-            unsigned short* dst = O + b * o_bs + (int64_t)qr * heads * 64 + h * 64;
+            const int orow = MAPPED ? wm.row_off + hm[qr] : qr;          // back to token order in the store
+            unsigned short* dst = O + b * o_bs + (int64_t)orow * heads * 64 + h * 64;
+            const unsigned short* cr = MAPPED ? wm.cross + b * o_bs + (int64_t)orow * heads * 64 + h * 64 : nullptr;   // cross: token order, out's strides
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -369,6 +406,11 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(
                     u16x8 ov;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16_bits(o[dt][qi][g * 8 + e] * inv);
+                    if (MAPPED) {   // + the cross pass: two bf16 results added in fp32, rounded once (the reference adds two bf16 tensors)
+                        const u16x8 cv = *reinterpret_cast<const u16x8*>(cr + dt * 32 + g * 16 + hi * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16_bits(bf16_bits_to_f32(ov[e]) + bf16_bits_to_f32(cv[e]));
+                    }
                     *reinterpret_cast<u16x8*>(dst + dt * 32 + g * 16 + hi * 8) = ov;
                 }
         }
@@ -550,6 +592,27 @@ extern "C" int ea_attention_window_fwd_bf16(const ea_bf16* q, const ea_bf16* k, 
                        (unsigned short*)out, out_batch_stride, heads, bh, seq, s_pad, 0, seq, nqb,
                        scale * 1.4426950408889634f, window);
     return ea_check_launch("ea_attention_window_fwd_bf16");
+}
+
+extern "C" int ea_attention_window_mapped_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt_perm, const ea_bf16* cross,
+                                                   ea_bf16* out, int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
+                                                   int vt_pad, int row_off, const int* map, int window, float scale, void* stream) {
+    EA_REQUIRE(q && k && vt_perm && cross && out && map, "ea_attention_window_mapped_fwd_bf16: null tensor");
+    EA_REQUIRE(batch > 0 && heads > 0 && seq > 0 && window >= 0 && row_off >= 0, "ea_attention_window_mapped_fwd_bf16: bad sizes");
+    EA_REQUIRE(row_off + seq <= s_pad && vt_pad % ATT_KV == 0 && vt_pad >= (seq + ATT_KV - 1) / ATT_KV * ATT_KV,
+               "ea_attention_window_mapped_fwd_bf16: q / k hold rows [row_off, row_off + seq) of s_pad; vt_perm rows of vt_pad >= seq rounded up to 64");
+    EA_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt_perm | (uintptr_t)cross | (uintptr_t)out) & 15) == 0 && ((uintptr_t)map & 3) == 0 &&
+               out_batch_stride % 8 == 0, "ea_attention_window_mapped_fwd_bf16: pointers must be 16-byte aligned");
+    const int nqb = (seq + ATT_QB - 1) / ATT_QB;
+    const int bh = batch * heads;
+    const int64_t blocks = (int64_t)((bh + 7) / 8) * nqb * 8;
+    EA_REQUIRE(blocks < (1ll << 31), "ea_attention_window_mapped_fwd_bf16: grid too large");
+    AttWindowMap wm;
+    wm.map = map; wm.cross = cross; wm.row_off = row_off; wm.vt_pad = vt_pad;
+    ea_count("attention_window_mapped");
+    hipLaunchKernelGGL((attention_fwd_kernel<true, true>), dim3((unsigned)blocks), dim3(256), ATT_LDS, (hipStream_t)stream, q, k, vt_perm,
+                       (unsigned short*)out, out_batch_stride, heads, bh, seq, s_pad, 0, seq, nqb, scale * 1.4426950408889634f, window, wm);
+    return ea_check_launch("ea_attention_window_mapped_fwd_bf16");
 }
 
 extern "C" int64_t ea_attention_state_bytes(int batch, int heads, int q_begin, int q_end) {

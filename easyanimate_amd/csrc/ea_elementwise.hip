@@ -334,6 +334,113 @@ extern "C" int ea_teacache_rel_l1_bf16(const ea_bf16* cur, const ea_bf16* prev, 
     return ea_check_launch("ea_teacache_rel_l1_bf16");
 }
 
+// ---- SWA scan orders: V^T of a head re-ordered along its token axis by an AXIS PERMUTATION of the (f, h, w) token grid
+// (processor.py:400-417) -- dst[c, p] = src[c, col_off + token(p)] for all 64 channels.  A key is a COLUMN of V^T, so this is a
+// transposition-like move of 2-byte elements; a gather by token index would pull a 64-byte line per element.  It is done as
+// tiled transposes through LDS instead: the tile spans 32 consecutive w (contiguous in the source) x 64 consecutive values of
+// the destination's fastest axis y (contiguous in the destination) at a fixed third coordinate z, 8 channels at a time --
+// 64-byte runs on the read side, 128-byte runs on the write side.  Orders whose fastest axis is w are row copies (same kernel,
+// y := the middle axis, the tile is then written the way it was read).
+struct PermuteArgs {
+    const unsigned short* src;
+    unsigned short* dst;
+    const int* head_order;     // [heads]: index into the six axis orders (f h w), (f w h), (h f w), (h w f), (w f h), (w h f)
+    int heads, F, Hh, Ww, src_pad, dst_pad, col_off;
+};
+__global__ __launch_bounds__(256) void permute_cols_kernel(PermuteArgs a) {
+    __shared__ unsigned short tile[8][64][34];
+    const int bh = blockIdx.z, cs = blockIdx.y;                 // 8-channel slab
+    const int ord = a.head_order[bh % a.heads];
+    const int o0 = ord >> 1;                                     // orders in lexicographic order of (o0, o1, o2)
+    const int o1 = (ord & 1) ? (o0 == 2 ? 1 : 2) : (o0 == 0 ? 1 : 0);
+    const int o2 = 3 - o0 - o1;
+    const int dim[3] = {a.F, a.Hh, a.Ww};
+    // y = the destination's fastest axis unless that is w itself (then the middle axis), z = the third one
+    const int ya = o2 == 2 ? o1 : o2;
+    const int za = 3 - 2 - ya;
+    const int Dy = dim[ya], Dz = dim[za];
+    const int ty = (Dy + 63) / 64, tw = (a.Ww + 31) / 32;
+    int t = blockIdx.x;
+    const int w0 = (t % tw) * 32; t /= tw;
+    const int y0 = (t % ty) * 64; t /= ty;
+    const int z = t;
+    if (z >= Dz) return;
+    const int64_t sbase = ((int64_t)bh * 64 + cs * 8) * a.src_pad + a.col_off;
+    const int64_t dbase = ((int64_t)bh * 64 + cs * 8) * a.dst_pad;
+    auto token = [&](int y, int w) {          // natural token index (f h w)
+        int c[3];
+        c[ya] = y; c[za] = z; c[2] = w;
+        return (c[0] * a.Hh + c[1]) * a.Ww + c[2];
+    };
+    auto position = [&](int y, int w) {       // scan position in the order (o0 o1 o2)
+        int c[3];
+        c[ya] = y; c[za] = z; c[2] = w;
+        return (c[o0] * dim[o1] + c[o1]) * dim[o2] + c[o2];
+    };
+    const int tid = threadIdx.x;
+    {   // read: lane -> w (32 consecutive source elements), 8 rows of y per pass
+        const int wl = tid & 31, yl = tid >> 5;
+        const int w = w0 + wl;
+#pragma unroll 2
+        for (int yy = yl; yy < 64; yy += 8) {
+            const int y = y0 + yy;
+            if (y < Dy && w < a.Ww) {
+                const int64_t n = token(y, w);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tile[c][yy][wl] = a.src[sbase + (int64_t)c * a.src_pad + n];
+            }
+        }
+    }
+    __syncthreads();
+    if (o2 == 2) {   // w is the destination's fastest axis too: write the rows the way they were read
+        const int wl = tid & 31, yl = tid >> 5;
+        const int w = w0 + wl;
+        for (int yy = yl; yy < 64; yy += 8) {
+            const int y = y0 + yy;
+            if (y < Dy && w < a.Ww) {
+                const int64_t p = position(y, w);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a.dst[dbase + (int64_t)c * a.dst_pad + p] = tile[c][yy][wl];
+            }
+        }
+    } else {         // lane -> y (64 consecutive destination elements), 4 columns of w per pass
+        const int yl = tid & 63, wq = tid >> 6;
+        const int y = y0 + yl;
+        for (int ww = wq; ww < 32; ww += 4) {
+            const int w = w0 + ww;
+            if (y < Dy && w < a.Ww) {
+                const int64_t p = position(y, w);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a.dst[dbase + (int64_t)c * a.dst_pad + p] = tile[c][yl][ww];
+            }
+        }
+    }
+}
+
+extern "C" int ea_permute_cols_bf16(const ea_bf16* src, ea_bf16* dst, const int* head_order, int batch, int heads, int frames, int height,
+                                    int width, int src_pad, int dst_pad, int col_off, void* stream) {
+    EA_REQUIRE(src && dst && head_order, "ea_permute_cols_bf16: null tensor");
+    EA_REQUIRE(batch > 0 && heads > 0 && frames > 0 && height > 0 && width > 0 && col_off >= 0, "ea_permute_cols_bf16: bad sizes");
+    const int64_t n = (int64_t)frames * height * width;
+    EA_REQUIRE(n < (1ll << 30) && col_off + n <= src_pad && n <= dst_pad, "ea_permute_cols_bf16: the token grid must fit the source / destination rows");
+    EA_REQUIRE((int64_t)batch * heads <= 65535, "ea_permute_cols_bf16: grid too large");
+    PermuteArgs a;
+    a.src = src; a.dst = dst; a.head_order = head_order; a.heads = heads; a.F = frames; a.Hh = height; a.Ww = width;
+    a.src_pad = src_pad; a.dst_pad = dst_pad; a.col_off = col_off;
+    // tiles: z x ceil(Dy / 64) x ceil(W / 32) -- bounded by the largest case over the six orders (blocks beyond a head's own count return)
+    const int dims[3] = {frames, height, width};
+    int64_t tiles = 0;
+    for (int ya = 0; ya < 2; ++ya) {
+        const int za = 1 - ya;
+        const int64_t t = (int64_t)dims[za] * ((dims[ya] + 63) / 64) * ((width + 31) / 32);
+        tiles = t > tiles ? t : tiles;
+    }
+    EA_REQUIRE(tiles < (1ll << 31), "ea_permute_cols_bf16: grid too large");
+    ea_count("permute_cols");
+    hipLaunchKernelGGL(permute_cols_kernel, dim3((unsigned)tiles, 8, (unsigned)(batch * heads)), dim3(256), 0, (hipStream_t)stream, a);
+    return ea_check_launch("ea_permute_cols_bf16");
+}
+
 extern "C" int ea_bf16_binary(const ea_bf16* a, const ea_bf16* b, ea_bf16* out, int64_t n, int op, void* stream) {
     EA_REQUIRE(a && b && out, "ea_bf16_binary: null tensor");
     EA_REQUIRE(n >= 0 && n % 8 == 0 && (op == 0 || op == 1), "ea_bf16_binary: n must be a multiple of 8, op 0 (sub) or 1 (add)");

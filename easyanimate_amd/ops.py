@@ -311,6 +311,38 @@ def attention_window(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: in
     return out
 
 
+def attention_window_mapped(q: torch.Tensor, k: torch.Tensor, vt_perm: torch.Tensor, cross: torch.Tensor, out: torch.Tensor,
+                            seq: int, row_off: int, head_map: torch.Tensor, window: int, scale: float) -> torch.Tensor:
+    """The SWA window pass without index copies: q, k bf16 [B,H,S_pad,64] in token order (video token n at row row_off + n),
+    visited in the scan order head_map int32 [H, seq] (scan position -> token); vt_perm bf16 [B,H,64,vt_pad] already in scan
+    order (permute_cols); out[b, row_off + token, h*64..] = window result + cross[same row] (out, cross bf16 [B, >= row_off+seq, H*64])."""
+    _dev(q, k, vt_perm, cross, out, head_map)
+    B, H, s_pad, dh = q.shape
+    vt_pad = vt_perm.shape[3]
+    assert dh == 64 and q.is_contiguous() and k.is_contiguous() and vt_perm.is_contiguous() and k.shape == q.shape
+    assert vt_perm.shape == (B, H, 64, vt_pad) and head_map.dtype == torch.int32 and head_map.shape == (H, seq) and head_map.is_contiguous()
+    assert out.shape == cross.shape and out.shape[0] == B and out.shape[1] >= row_off + seq and out.shape[2] == H * 64
+    assert out.stride() == cross.stride() and out.stride(2) == 1 and out.stride(1) == H * 64
+    _timed("attention", lambda: _lib.call("ea_attention_window_mapped_fwd_bf16", _p(q), _p(k), _p(vt_perm), _p(cross), _p(out), out.stride(0),
+                                          B, H, seq, s_pad, vt_pad, int(row_off), _p(head_map), int(window), float(scale), _stream()))
+    return out
+
+
+def permute_cols(src: torch.Tensor, dst: torch.Tensor, head_order: torch.Tensor, grid, col_off: int) -> torch.Tensor:
+    """dst[b,h,c,p] = src[b,h,c,col_off + token(p)]: V^T bf16 [B,H,64,src_pad] -> [B,H,64,dst_pad] with the token axis of head h
+    re-ordered by scan order head_order[h] (int32 [H], 0..5 = (f h w), (f w h), (h f w), (h w f), (w f h), (w h f)) of the
+    (frames, height, width) grid."""
+    _dev(src, dst, head_order)
+    _chk(src, _BF16, "src"); _chk(dst, _BF16, "dst")
+    B, H, c, src_pad = src.shape
+    F_, Hh, Ww = grid
+    assert c == 64 and dst.shape[:3] == (B, H, 64) and src.is_contiguous() and dst.is_contiguous()
+    assert head_order.dtype == torch.int32 and head_order.shape == (H,) and head_order.is_contiguous()
+    _lib.call("ea_permute_cols_bf16", _p(src), _p(dst), _p(head_order), B, H, int(F_), int(Hh), int(Ww), src_pad, dst.shape[3], int(col_off),
+              _stream())
+    return dst
+
+
 def attention_d512(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, n_keys: int, scale: float,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Single-head, head_dim 512 flash attention per frame (VAE mid block): q bf16 [T, n_q, 512], k bf16 [T, n_kpad, 512],

@@ -26,7 +26,7 @@ def _workspace(B: int, H: int, s_pad: int, device) -> dict:
     key = (B, H, s_pad, str(device))
     ws = _ws.get(key)
     if ws is None:
-        for k in [k for k in _ws if k[0] not in ("state", "q", "heads")]:  # one live shape at a time keeps the footprint bounded
+        for k in [k for k in _ws if k[0] not in ("state", "q", "heads", "vtp")]:  # one live shape at a time keeps the footprint bounded
             del _ws[k]
         ws = dict(q=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
                   k=torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=device),
@@ -57,6 +57,18 @@ def _workspace_heads(B: int, Hl: int, s_pad: int, device, dtype=torch.bfloat16):
             del _ws[k]
         w = (torch.zeros(B, Hl, s_pad, 64, dtype=dtype, device=device), torch.zeros(B, Hl, s_pad, 64, dtype=dtype, device=device),
              torch.zeros(B, Hl, 64, s_pad, dtype=dtype, device=device))
+        _ws[key] = w
+    return w
+
+
+def _workspace_vt_perm(B: int, Hl: int, n_pad: int, device) -> torch.Tensor:
+    """V^T in scan order for the sliding-window pass, zero-initialised once (columns behind the sequence must be finite)."""
+    key = ("vtp", B, Hl, n_pad, str(device))
+    w = _ws.get(key)
+    if w is None:
+        for k in [k for k in _ws if k[0] == "vtp"]:
+            del _ws[k]
+        w = torch.zeros(B, Hl, 64, n_pad, dtype=torch.bfloat16, device=device)
         _ws[key] = w
     return w
 
@@ -307,25 +319,17 @@ class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
         (f h w) order (:422-434);
 
     text rows leave as cross + cross, video rows as window + cross (:435 adds `cross` to a tensor whose text rows already
-    are `cross`).  Each pass rounds to bf16 like the two flash_attn_func calls do.  The strided key gather and the scan-order
-    permutations are index copies (torch indexing); the two attention passes are ea_attention_fwd_range_bf16 and
-    ea_attention_window_fwd_bf16."""
+    are `cross`).  Each pass rounds to bf16 like the two flash_attn_func calls do.  The cross pass is
+    ea_attention_fwd_segments_bf16 over one small gathered key segment; the window pass is ea_attention_window_mapped_fwd_bf16:
+    q / k are addressed through the per-head scan-order map where the projection wrote them, V^T is re-ordered once
+    (ea_permute_cols_bf16), and the kernel's store returns to token order and adds the cross pass -- no index copies."""
 
     _ORDERS = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
 
     def __init__(self, cross_attention_size: int = 1024):
         super().__init__()
         self.cross_attention_size = cross_attention_size
-        self._perm = {}
         self._maps = None
-
-    def _scan_orders(self, F_: int, Hh: int, Ww: int, heads: int, dev):
-        key = (F_, Hh, Ww, heads, str(dev))
-        if key not in self._perm:
-            base = torch.arange(F_ * Hh * Ww, device=dev).view(F_, Hh, Ww)
-            groups = torch.tensor_split(torch.arange(heads, device=dev), 6)
-            self._perm = {key: [(hs, base.permute(*o).reshape(-1).contiguous()) for hs, o in zip(groups, self._ORDERS) if hs.numel()]}
-        return self._perm[key]
 
     exchange_in_attend = True   # under sequence parallelism this processor exchanges HEADS (all-to-all), not keys
 
@@ -348,40 +352,54 @@ class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
         seg[1].view(B, Hl, 64, rows_c)[:, :, :, :nc] = vt[:, :, :, idx]
         cross = torch.empty(B, S, Hl * 64, dtype=torch.bfloat16, device=dev)
         ops.attention_segments(q, seg, 1, -1, rows_c, nc, 0, S, out=cross)
-        # ---- window pass over the re-ordered video tokens: ONE gather per operand with a per-head row map (the six scan
-        # orders side by side), not one per head group
-        n_pad = ops.round_up(N, 256)
-        hmap, inv = self._head_maps(F_, Hh, Ww, H_total, head0, Hl, dev)          # [Hl, N]: scan position -> token, token -> scan position
-        hh = torch.arange(Hl, device=dev)[:, None]
-        qp = torch.empty(B, Hl, n_pad, 64, dtype=torch.bfloat16, device=dev)
-        kp = torch.empty_like(qp)
-        vtp = torch.empty(B, Hl, 64, n_pad, dtype=torch.bfloat16, device=dev)
-        qp[:, :, :N] = q[:, hh, T + hmap]
-        kp[:, :, :N] = k[:, hh, T + hmap]
-        vtp[:, :, :, :N] = vt[:, :, :, T:T + N].gather(3, hmap[None, :, None, :].expand(B, Hl, 64, N))
-        if n_pad != N:      # rows behind the sequence: masked as keys, but V^T must be finite there
-            qp[:, :, N:].zero_(); kp[:, :, N:].zero_(); vtp[:, :, :, N:].zero_()
-        win = ops.attention_window(qp, kp, vtp, N, Hh * Ww, ops.FOLDED_ATTN_SCALE).view(B, N, Hl, 64)
-        back = win.transpose(1, 2)[:, hh, inv].transpose(1, 2)        # [B, N, Hl, 64] in (f h w) order again
-        # ---- text rows: cross + cross; video rows: window + cross
+        # ---- window pass over the video tokens in the six scan orders.  q / k stay in token order and are ADDRESSED through the
+        # per-head map inside the kernel; V^T (a key is a column of it) is re-ordered once by tiled transposes; the kernel's store
+        # brings the result back to token order and adds the cross pass (round 4: no index copies -- the first version gathered
+        # q / k / v^T into scan order and scattered the result back with torch indexing: 7 of 24 ms per block at config-3 size)
+        hmap, inv, hmap32, order = self._head_maps(F_, Hh, Ww, H_total, head0, Hl, dev)   # scan position -> token, token -> scan position
         o = torch.empty(B, S, Hl * 64, dtype=torch.bfloat16, device=dev)
+        if self.index_copies:
+            n_pad = ops.round_up(N, 256)
+            hh = torch.arange(Hl, device=dev)[:, None]
+            qp = torch.empty(B, Hl, n_pad, 64, dtype=torch.bfloat16, device=dev)
+            kp = torch.empty_like(qp)
+            vtp = torch.empty(B, Hl, 64, n_pad, dtype=torch.bfloat16, device=dev)
+            qp[:, :, :N] = q[:, hh, T + hmap]
+            kp[:, :, :N] = k[:, hh, T + hmap]
+            vtp[:, :, :, :N] = vt[:, :, :, T:T + N].gather(3, hmap[None, :, None, :].expand(B, Hl, 64, N))
+            if n_pad != N:      # rows behind the sequence: masked as keys, but V^T must be finite there
+                qp[:, :, N:].zero_(); kp[:, :, N:].zero_(); vtp[:, :, :, N:].zero_()
+            win = ops.attention_window(qp, kp, vtp, N, Hh * Ww, ops.FOLDED_ATTN_SCALE).view(B, N, Hl, 64)
+            back = win.transpose(1, 2)[:, hh, inv].transpose(1, 2)        # [B, N, Hl, 64] in (f h w) order again
+            o[:, T:] = ops.bf16_add_(back.reshape(B, N, Hl * 64).contiguous(), cross[:, T:].contiguous())
+        else:
+            vtp = _workspace_vt_perm(B, Hl, ops.round_up(N, 64), dev)            # zero-initialised once: columns >= N stay zero
+            ops.permute_cols(vt, vtp, order, (F_, Hh, Ww), T)
+            ops.attention_window_mapped(q, k, vtp, cross, o, N, T, hmap32, Hh * Ww, ops.FOLDED_ATTN_SCALE)
+        # ---- text rows: cross + cross; video rows: window + cross (added in the kernel's store)
         o[:, :T] = ops.bf16_add_(cross[:, :T].contiguous(), cross[:, :T].contiguous())
-        o[:, T:] = ops.bf16_add_(back.reshape(B, N, Hl * 64).contiguous(), cross[:, T:].contiguous())
         return o
 
+    index_copies = os.environ.get("EA_SWA_INDEX_COPIES", "0") == "1"   # the first version's torch index copies (cross-check, tests)
+
     def _head_maps(self, F_, Hh, Ww, H_total, head0, Hl, dev):
+        """Per local head: scan position -> token (long and int32), token -> scan position, and the index of its scan order."""
         key = (F_, Hh, Ww, H_total, head0, Hl, str(dev))
         if self._maps is None or self._maps[0] != key:
             N = F_ * Hh * Ww
             hmap = torch.empty(Hl, N, dtype=torch.long, device=dev)
-            for hs, src in self._scan_orders(F_, Hh, Ww, H_total, dev):   # head groups are defined over ALL heads (:400-417)
+            order = torch.zeros(Hl, dtype=torch.int32, device=dev)
+            base = torch.arange(N, device=dev).view(F_, Hh, Ww)
+            groups = torch.tensor_split(torch.arange(H_total, device=dev), 6)          # head groups are defined over ALL heads (:400-417)
+            for oi, (hs, o) in enumerate(zip(groups, self._ORDERS)):
                 loc = hs[(hs >= head0) & (hs < head0 + Hl)] - head0
                 if loc.numel():
-                    hmap[loc] = src
+                    hmap[loc] = base.permute(*o).reshape(-1)
+                    order[loc] = oi
             inv = torch.empty_like(hmap)
             inv.scatter_(1, hmap, torch.arange(N, device=dev)[None].expand(Hl, N))
-            self._maps = (key, hmap, inv)
-        return self._maps[1], self._maps[2]
+            self._maps = (key, hmap, inv, hmap.to(torch.int32).contiguous(), order)
+        return self._maps[1:]
 
     def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid, pending=None):
         if sp is None:

@@ -228,6 +228,26 @@ int ea_attention_window_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf
                                  int64_t out_batch_stride, int batch, int heads, int seq, int s_pad, int window,
                                  float scale, void* stream);
 
+/* The window pass of the SWA processor WITHOUT index copies (processor.py:400-435: six head groups, each visiting the video tokens
+ * in its own scan order; results brought back to (f h w) order and added to the cross pass).  map: int32 [heads, seq], scan
+ * position -> token of the (f h w) grid.  q / k stay where the projection wrote them -- [batch, heads, s_pad, 64], video token n
+ * at row row_off + n -- and are addressed through the map (Q fragments by row, the K tiles' LDS-DMA rows through a per-lane row
+ * index loaded one tile ahead).  vt_perm: V^T already in scan order, [batch, heads, 64, vt_pad] (ea_permute_cols_bf16: a key is a
+ * column of V^T and cannot be gathered by row DMA; columns >= seq must be finite).  The result row of scan position p is stored
+ * at token order with the cross pass added: out[b, r, h*64..] = bf16(bf16(window result) + cross[b, r, h*64..]), r = row_off +
+ * map[h][p]; cross has out's strides.  Rows < row_off of out are not written.  Same arithmetic as ea_attention_window_fwd_bf16
+ * on gathered operands followed by a bf16 add: bit-identical (tested). */
+int ea_attention_window_mapped_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt_perm, const ea_bf16* cross,
+                                        ea_bf16* out, int64_t out_batch_stride, int batch, int heads, int seq, int s_pad,
+                                        int vt_pad, int row_off, const int* map, int window, float scale, void* stream);
+
+/* dst[bh, c, p] = src[bh, c, col_off + token(p)] for the 64 channels of every (batch, head): V^T re-ordered along its token axis
+ * by an axis permutation of the (frames, height, width) token grid -- head_order[h] in 0..5 picks the scan order of head h among
+ * (f h w), (f w h), (h f w), (h w f), (w f h), (w h f) (processor.py:400-417).  src rows of src_pad elements, dst rows of dst_pad
+ * (columns >= frames*height*width of dst are not written).  Tiled transposes through LDS: 64-byte runs read, 128-byte runs written. */
+int ea_permute_cols_bf16(const ea_bf16* src, ea_bf16* dst, const int* head_order, int batch, int heads, int frames, int height,
+                         int width, int src_pad, int dst_pad, int col_off, void* stream);
+
 /* The same attention, resumable over key ranges: keys [kv_begin, kv_end) only (kv_begin % 64 == 0, kv_end
  * arbitrary), with the online-softmax state (un-normalised O, running max, partial row sums; fp32) carried in a
  * caller-owned `state` buffer of ea_attention_state_bytes(batch, heads, q_begin, q_end) bytes:

@@ -764,6 +764,31 @@ def gen_config2_forward(ns, shim):
                     enc_sum=enc.double().sum().item()), os.path.join(OUT, "config2_7b_49x512_v0.pt"))
 
 
+@section("transformer_full_length")
+def gen_transformer_full_length(ns, shim):
+    # ---- round 4: config 3's REAL sequence length through the unchanged reference -- full width (d = 3072, 48 heads), 2 layers,
+    # latents [1,16,13,128,128] = 53 248 video + 256 text tokens (S = 53 504: 49 f x 1024^2), one batch element, fp32 on the host
+    # cores (~1e14 FLOP; the 12B model's 48 layers at this length are hours of CPU time).  This is the one place the attention
+    # kernel's 836-tile online softmax, the 208-tile GEMM grids and the RoPE tables of the benchmark shape meet a reference
+    # output.  Stored at every second latent pixel (fp16).  Inputs regenerated from seeds by the test (dit_full_inputs).
+    import time
+    cfg = dict(FULL_DIT)
+    m, shapes = _meta_build(lambda: ns.transformer3d.EasyAnimateTransformer3DModel(**cfg), 5, "stress")
+    dims = (1, 13, 128, 128, 256)
+    B, Fr, H, W, T = dims
+    lat, extra, enc = dit_full_inputs(cfg, 29, *dims)
+    t = torch.tensor([799.0] * B).to(torch.bfloat16).float()
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((H // 2, W // 2), 45, 30)
+    cos, sin = shim.get_3d_rotary_pos_embed(64, cc, (H // 2, W // 2), Fr, use_real=True)
+    t0 = time.time()
+    with torch.no_grad():
+        out = m(lat, t, encoder_hidden_states=enc, image_rotary_emb=(cos, sin), return_dict=False)[0]
+    print(f"  transformer_full_length: fp32 forward {time.time() - t0:.1f} s, out std {out.std().item():.3f}, |out| max {out.abs().max().item():.2f}", flush=True)
+    torch.save(dict(cfg=cfg, shapes=shapes, seed=5, style="stress", input_seed=29, dims=dims, t=t, crops=cc,
+                    lat_sum=lat.double().sum().item(), enc_sum=enc.double().sum().item(), out_sub_f16=out[..., ::2, ::2].half().contiguous(),
+                    out_std=out.std().item(), out_shape=tuple(out.shape)), os.path.join(OUT, "transformer_full_length_s53504.pt"))
+
+
 FULL_LOOP_DIMS = (3, 40, 56, 256)      # latent frames, latent H, W, text tokens -> 3 * 20 * 28 = 1680 video tokens
 
 

@@ -966,3 +966,65 @@ def test_attention_segments_slot_rows(P, rank, T, nl, n_last):
 
 
 
+
+
+# ---- round 4: the SWA window pass without index copies ---------------------------------------------------------------------------
+@pytest.mark.parametrize("grid", [(3, 70, 45), (2, 64, 64), (13, 8, 33), (1, 5, 7)])
+def test_permute_cols_six_scan_orders(grid):
+    """ea_permute_cols_bf16: V^T re-ordered along its token axis by each of the six axis orders of the (f, h, w) grid, against a
+    torch gather with the reference's own permutation (base.permute(*order).reshape(-1), processor.py:400-417); tile tails in
+    every axis (w not a multiple of 32, the destination's fastest axis not a multiple of 64), a column offset (the text rows in
+    front), nothing written behind the sequence."""
+    ops = _ops()
+    F_, Hh, Ww = grid
+    N = F_ * Hh * Ww
+    B, H, T = 2, 7, 40
+    orders = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    src_pad, dst_pad = ops.round_up(T + N, 256), ops.round_up(N, 64)
+    src = torch.randn(B, H, 64, src_pad, generator=g).to(torch.bfloat16).to(DEV)
+    dst = torch.full((B, H, 64, dst_pad), 7.0, dtype=torch.bfloat16, device=DEV)
+    head_order = torch.tensor([h % 6 for h in range(H)], dtype=torch.int32, device=DEV)
+    ops.permute_cols(src, dst, head_order, grid, T)
+    torch.cuda.synchronize()
+    base = torch.arange(N, device=DEV).view(F_, Hh, Ww)
+    for h in range(H):
+        tok = base.permute(*orders[h % 6]).reshape(-1)
+        assert torch.equal(dst[:, h, :, :N], src[:, h, :, T + tok]), (h, orders[h % 6])
+    assert (dst[:, :, :, N:] == 7).all()
+
+
+@pytest.mark.parametrize("grid,T,H,cross_size", [((3, 16, 24), 64, 12, 256), ((2, 20, 13), 7, 6, 128), ((5, 8, 8), 40, 7, 96)])
+def test_swa_window_mapped_equals_index_copies(grid, T, H, cross_size):
+    """The SWA attend with the mapped window kernel (q / k addressed through the scan-order map, V^T permuted by tiled transposes,
+    token-order store with the cross pass added) against its first version (torch index copies into scan order,
+    ea_attention_window_fwd_bf16, index copy back, bf16 add): the same MFMA products on the same values in the same order ->
+    bit-identical.  Unaligned text length, head counts that do not divide by six, grids whose window (h * w positions) truncates."""
+    from easyanimate_amd import _lib
+    from easyanimate_amd.processor import EasyAnimateSWAttnProcessor2_0
+    ops = _ops()
+    F_, Hh, Ww = grid
+    N, B = F_ * Hh * Ww, 2
+    S = T + N
+    s_pad = ops.round_up(S, 256)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    q = torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device=DEV)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=DEV)
+    q[:, :, :S] = (torch.randn(B, H, S, 64, generator=g) * ops.FOLDED_Q_SCALE).to(torch.bfloat16).to(DEV)
+    k[:, :, :S] = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16).to(DEV)
+    vt[:, :, :, :S] = torch.randn(B, H, 64, S, generator=g).to(torch.bfloat16).to(DEV)
+    proc = EasyAnimateSWAttnProcessor2_0(cross_attention_size=cross_size)
+    outs = {}
+    for copies in (True, False):
+        proc.index_copies = copies
+        _lib.reset_counters()
+        outs[copies] = proc._swa(q, k, vt, B, H, 0, H, T, N, DEV, grid)
+        torch.cuda.synchronize()
+        c = _lib.counters()
+        assert (c.get("attention_window_mapped", 0), c.get("permute_cols", 0), c.get("attention_window", 0)) == ((0, 0, 1) if copies else (1, 1, 0)), c
+    assert torch.isfinite(outs[False].float()).all()
+    assert torch.equal(outs[False], outs[True])
+    again = proc._swa(q, k, vt, B, H, 0, H, T, N, DEV, grid)
+    assert torch.equal(again, outs[False])
+

@@ -155,7 +155,7 @@ def test_transformer_swa_vs_golden(name):
     cnt = _lib.counters()
     mse = _mse(out.float(), g["out"].float())
     print(f"[parity] {name}: new-bf16 vs ref-fp32 MSE={mse:.3e} | ref-bf16 floor {g['floor_mse']:.3e} | ref std {g['out_std']:.3f} | kernels {cnt}")
-    assert mse < BAR and cnt.get("attention_window", 0) == len(g["cfg"]["swa_layers"])
+    assert mse < BAR and cnt.get("attention_window_mapped", 0) == len(g["cfg"]["swa_layers"]) == cnt.get("permute_cols", 0)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -190,6 +190,39 @@ def test_transformer_full_width_vs_golden(name):
     assert cnt.get("attention_v3", 0) == 2                             # the product attention kernel, once per block
     if name.endswith("t2v"):
         assert cnt.get("gemm_256_mi16", 0) > 0                          # M = 2 x 5120 rows: the large-tile GEMM path
+
+
+def test_transformer_full_length_s53504_vs_golden():
+    """Config 3's REAL sequence length against the unchanged reference (round 4): full width (d = 3072, 48 heads), 2 layers, latents
+    [1,16,13,128,128] = 53 248 video + 256 text tokens (S = 53 504 = 49 f x 1024^2), one batch element; golden = the reference in fp32
+    on the host cores (132 s), stored at every second latent pixel.  The one place where the attention kernel's 836-tile online
+    softmax, the 208-row-tile GEMM grids and the RoPE tables of the benchmark shape meet a reference OUTPUT (the kernel-level test
+    at this length compares with an fp64 softmax of synthetic q / k / v)."""
+    from easyanimate_amd import _lib
+    from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
+    from oracle.gen_golden import dit_full_inputs
+    g = _load("transformer_full_length_s53504.pt")
+    cfg = g["cfg"]
+    B, Fr, H, W, T = g["dims"]
+    assert (B, Fr * (H // 2) * (W // 2) + T) == (1, 53504) and cfg["num_attention_heads"] * 64 == 3072
+    lat, extra, enc = dit_full_inputs(cfg, g["input_seed"], *g["dims"])
+    assert abs(lat.double().sum().item() - g["lat_sum"]) < 1e-5 and abs(enc.double().sum().item() - g["enc_sum"]) < 1e-4
+    rope = get_3d_rotary_pos_embed(64, g["crops"], grid_size=(H // 2, W // 2), temporal_size=Fr, use_real=True)
+    m = _model(cfg, g["shapes"], g["seed"], g["style"])
+    _lib.reset_counters()
+    with torch.no_grad():
+        out = m(lat.to(DEV).bfloat16(), g["t"].to(DEV).bfloat16(), encoder_hidden_states=enc.to(DEV).bfloat16(), image_rotary_emb=rope,
+                return_dict=False)[0]
+    torch.cuda.synchronize()
+    cnt = _lib.counters()
+    assert tuple(out.shape) == tuple(g["out_shape"])
+    ref = g["out_sub_f16"].double()
+    d = out[..., ::2, ::2].float().cpu().double() - ref
+    mse, rel = (d ** 2).mean().item(), (d.norm() / ref.norm()).item()
+    print(f"[parity] full-width 2-layer transformer at S = 53504 (49f x 1024^2): new-bf16 vs ref-fp32 MSE={mse:.3e} rel_l2={rel:.3e} "
+          f"ref std {g['out_std']:.3f} | kernels {cnt}")
+    assert mse < BAR and torch.isfinite(out.float()).all()
+    assert cnt.get("attention_v3", 0) == 2 and cnt.get("gemm_qkv_fused", 0) == 4 and cnt.get("gemm_256_mi16", 0) >= 6, cnt
 
 
 def test_vae_full_width_ragged_shape_vs_golden():

@@ -298,7 +298,7 @@ def _worker_swa(rank, world, port, cfg_parallel, ret):
             out = m(*args, **kw)[0]
             cnt = _lib.counters()
         ret[rank] = ((out.float() - ref.float()).abs().max().item(), ref.float().abs().max().item(),
-                     ((out.float().cpu() - g["out"].float()) ** 2).mean().item(), cnt.get("attention_window", 0), sp.size)
+                     ((out.float().cpu() - g["out"].float()) ** 2).mean().item(), cnt.get("attention_window_mapped", 0), sp.size)
     finally:
         dist.destroy_process_group()
 
