@@ -106,11 +106,10 @@ class SequenceParallel:
         if cfg_parallel and self.world % 2 == 0:
             half = self.world // 2
             base = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
-            # this rank's CFG half; created once per process and member-local (use_local_synchronization: `group` may be a
-            # strict sub-group of the world, and a second enable() does not leak another communicator)
-            c = self.world_rank // half
-            from .vae_parallel import _subgroup
-            mine = _subgroup([base[c * half + i] for i in range(half)])
+            # the two CFG halves: created once per process (a second enable() reuses them), by every rank of the world in the same
+            # order -- with an eagerly initialised RCCL world a sub-group is an ncclCommSplit the non-members take part in
+            from .vae_parallel import _subgroups
+            mine = _subgroups([[base[c * half + i] for i in range(half)] for c in range(2)], group)
             self._cfg = _Axis(self.world, self.world_rank, 2, mine)
         self.axis = self._flat
         self.n_total = 0
@@ -119,6 +118,9 @@ class SequenceParallel:
         self.mode = os.environ.get("EA_SP_MODE", "keys")
         if self.mode not in ("keys", "heads"):
             raise ValueError(f"EA_SP_MODE must be 'keys' or 'heads', not {self.mode!r}")
+        self.inplace = os.environ.get("EA_SP_INPLACE", "1") != "0"
+        self._inplace_checked = False
+        self._recv = None
         # bench.py: HIP events around every point where the compute stream waits for a collective (profile_wait = True)
         self.profile_wait = False
         self._waits = []
@@ -247,13 +249,38 @@ class SequenceParallel:
                 if g != self.rank:
                     buf[g].copy_(r[g])
             return (None,)
+        if not self.inplace:
+            # EA_SP_INPLACE=0 -- the out-of-place form of the same exchange (a second buffer of the same shape receives every
+            # slot; the remote pass reads THAT one): the fallback if the in-place collective misbehaves on some RCCL build
+            if self._recv is None or self._recv.shape != buf.shape or self._recv.device != buf.device:
+                self._recv = torch.empty_like(buf)
+            work = dist.all_gather_into_tensor(self._recv.view(-1), own, group=self.axis.group, async_op=True)
+            return (work, self._recv)
+        if self.size > 1 and not self._inplace_checked:
+            # first exchange of the process: the in-place form (input = the rank's slot of the output, sendbuff == recvbuff +
+            # rank * count as NCCL's in-place all-gather requires) is checked ONCE against an out-of-place gather of the same slots
+            # -- it has only ever run in a world of one rank before the first multi-GPU session
+            ref = torch.empty_like(buf)
+            dist.all_gather_into_tensor(ref.view(-1), own.clone(), group=self.axis.group)
+            dist.all_gather_into_tensor(buf.view(-1), own, group=self.axis.group)
+            torch.cuda.synchronize(buf.device)
+            if not torch.equal(ref, buf):
+                raise RuntimeError("sequence parallel: the in-place K / V^T all-gather does not reproduce the out-of-place one on this "
+                                   "RCCL build; set EA_SP_INPLACE=0")
+            self._inplace_checked = True
+            del ref
+            return (None,)
         work = dist.all_gather_into_tensor(buf.view(-1), own, group=self.axis.group, async_op=True)
         return (work,)
 
-    def exchange_finish(self, handle) -> None:
-        """Wait for the all-gather (a stream-level wait with RCCL): the remote slots are then readable in place."""
+    def exchange_finish(self, handle) -> Optional[torch.Tensor]:
+        """Wait for the all-gather (a stream-level wait with RCCL): the remote slots are then readable in place.  Returns the
+        buffer the remote slots are in when that is not the exchange buffer itself (EA_SP_INPLACE=0), else None."""
         if handle is not None:
             self._timed_wait("kv_all_gather_wait", handle[0].wait if handle[0] is not None else (lambda: None), "cuda")
+            if len(handle) > 1:
+                return handle[1]
+        return None
 
     # ---- head parallelism (sliding-window blocks; every full-attention block with mode == "heads") --------------
     def all_to_all(self, send: torch.Tensor) -> torch.Tensor:
@@ -342,6 +369,7 @@ class EmulatedRank(SequenceParallel):
         self.mode = os.environ.get("EA_SP_MODE", "keys")
         self.profile_wait = False
         self._waits = []
+        self.inplace, self._inplace_checked, self._recv = True, True, None
 
     # head-parallel blocks (EA_SP_MODE=heads, sliding-window blocks): the rank receives what it sent -- its own rows stand in
     # for every peer's (same size, same statistics); no link time in the model
@@ -386,6 +414,7 @@ class EmulatedRank(SequenceParallel):
     def exchange_finish(self, handle) -> None:
         if handle is not None and handle[0] is not None:
             torch.cuda.current_stream().wait_event(handle[0])
+        return None
 
     def all_reduce_sums(self, sums: torch.Tensor, n: int):
         return sums.to(torch.float64) * self.world, n * self.world

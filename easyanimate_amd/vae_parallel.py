@@ -43,21 +43,38 @@ _ACTIVE: Optional["TemporalParallel"] = None
 _SUBGROUPS: dict = {}
 
 
-def _subgroup(ranks: List[int]) -> dist.ProcessGroup:
-    """The process group of `ranks` (global rank numbers), created ONCE per process and reused by every later
-    enable_temporal_parallel call.  use_local_synchronization: only the members take part in the creation, so `group` may be a
-    strict sub-group of the world (one CFG half, one replica of a serving node) -- the plain new_group is collective over the
-    DEFAULT group and would hang there."""
-    key = tuple(ranks)
-    g = _SUBGROUPS.get(key)
-    if g is None:
-        g = dist.new_group(list(ranks), use_local_synchronization=True)
-        _SUBGROUPS[key] = g
-    return g
+def _subgroups(rank_lists: List[List[int]], parent: Optional[dist.ProcessGroup]) -> dist.ProcessGroup:
+    """Partition `parent` (None = the world) into the sub-groups `rank_lists` (global rank numbers) and return the one this rank
+    belongs to.  Groups are created ONCE per process and reused by every later enable_* call (no communicator leak).
 
-
-def current() -> Optional["TemporalParallel"]:
-    return _ACTIVE
+    * parent spans the world: every rank creates every sub-group, in the same order -- `dist.new_group` is collective over the
+      default group, and with an eagerly initialised RCCL world (`init_process_group(..., device_id=...)`, what bench.py does) it is
+      an ncclCommSplit in which the NON-members take part too.  Member-local creation would hang there.
+    * parent is a strict sub-group (one CFG half, one replica of a serving node): the ranks outside it never get here, so a
+      world-collective call cannot be made; the groups are created member-locally (`use_local_synchronization=True`) -- possible
+      only when the default group has no eagerly bound communicator to split from; otherwise the caller has to create the groups
+      up front, world-collectively."""
+    key = tuple(tuple(r) for r in rank_lists)
+    me = dist.get_rank()
+    if key not in _SUBGROUPS:
+        world = dist.get_world_size()
+        spans_world = parent is None or dist.get_world_size(parent) == world
+        made = {}
+        if spans_world:
+            for ranks in rank_lists:
+                made[tuple(ranks)] = dist.new_group(list(ranks))
+        else:
+            if getattr(dist.distributed_c10d._get_default_group(), "bound_device_id", None) is not None:
+                raise NotImplementedError("sub-groups of a strict sub-group cannot be created member-locally when the default process group was "
+                                          "initialised with device_id (communicator split is world-collective): create them up front")
+            for ranks in rank_lists:
+                if me in ranks:
+                    made[tuple(ranks)] = dist.new_group(list(ranks), use_local_synchronization=True)
+        _SUBGROUPS[key] = made
+    for ranks, g in _SUBGROUPS[key].items():
+        if me in ranks:
+            return g
+    raise RuntimeError(f"rank {me} is in none of the sub-groups {rank_lists}")
 
 
 class TemporalParallel:
@@ -76,7 +93,7 @@ class TemporalParallel:
         self.row_group = None
         if spatial > 1:
             base = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
-            self.row_group = _subgroup([base[self.rank_t * spatial + i] for i in range(spatial)])
+            self.row_group = _subgroups([[base[t * spatial + i] for i in range(spatial)] for t in range(self.pt)], group)
 
     # ---- partition ---------------------------------------------------------------------------------------------
     def plan(self, latent_frames: int) -> List[Tuple[int, int]]:

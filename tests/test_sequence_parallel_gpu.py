@@ -161,6 +161,12 @@ def _nccl_world1_worker(rank, port, ret):
             gathered_ok = torch.equal(buf, sent)                 # the IN-PLACE all-gather leaves the own slot as it was
             buf.zero_()
             outs = [m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0] for _ in range(3)]
+            # EA_SP_INPLACE=0: the out-of-place form of the exchange (second buffer) -- the same result
+            sp.inplace = False
+            h2 = sp.exchange_start(buf)
+            assert h2 is not None and len(h2) == 2 and sp.exchange_finish(h2) is h2[1] and h2[1].shape == buf.shape
+            outs.append(m(lat, t, encoder_hidden_states=enc, image_rotary_emb=rope, return_dict=False)[0])
+            sp.inplace = True
             s2, n2 = sp.all_reduce_sums(torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda:0"), 10)
         err = max((o.float() - ref.float()).abs().max().item() for o in outs)
         ret[0] = (err, ref.float().abs().max().item(), gathered_ok, all(torch.equal(outs[0], o) for o in outs[1:]),
