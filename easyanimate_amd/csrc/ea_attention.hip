@@ -509,8 +509,9 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
 #endif
     (void)plain;
     ea_count("attention_v3");
+    const dim3 grid3((unsigned)att3_grid_blocks(bh, nqb));
 #define EA_ATT_LAUNCH(MODE)                                                                                               \
-    hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid, blk, ATT_LDS, st, q, k, vt, o16,                             \
+    hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid3, blk, ATT_LDS, st, q, k, vt, o16,                            \
                        out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4)
     switch (flags) {
         case 0: EA_ATT_LAUNCH(0); break;
@@ -560,7 +561,7 @@ extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k
     AttSegments sg;
     sg.rows = seg_rows; sg.tiles = seg_used_rows / ATT_KV; sg.skip = (skip_seg >= 0 && skip_seg < n_seg) ? skip_seg : n_seg;
     sg.total_tiles = used * sg.tiles; sg.stride = seg_stride; sg.first = seg_first_row / ATT_KV;
-    const dim3 grid((unsigned)blocks), blk(256);
+    const dim3 grid((unsigned)att3_grid_blocks(bh, nqb)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     unsigned short* o16 = (unsigned short*)out;
     f32x4* st4 = reinterpret_cast<f32x4*>(state);

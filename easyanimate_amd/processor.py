@@ -180,7 +180,9 @@ class EasyAnimateAttnProcessor2_0:
             for i, (lo, hi) in enumerate(lay.own_ranges):       # the own slot is a plain K / V^T operand (same rows as q)
                 ops.attention_range(ws["q"], ws["k"], ws["vt"], ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
                                     store_state=True)
-            buf = sp.exchange_finish(pending) or buf      # (EA_SP_INPLACE=0: the remote slots arrived in a second buffer)
+            other = sp.exchange_finish(pending)
+            if other is not None:                          # (EA_SP_INPLACE=0: the remote slots arrived in a second buffer)
+                buf = other
             if lay.bringup_ranges is not None:
                 # bring-up mode (a world of one rank with force_exchange): the "remote" keys are the second half of its own rows
                 (lo, hi), = lay.bringup_ranges
