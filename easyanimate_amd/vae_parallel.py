@@ -77,6 +77,10 @@ def _subgroups(rank_lists: List[List[int]], parent: Optional[dist.ProcessGroup])
     raise RuntimeError(f"rank {me} is in none of the sub-groups {rank_lists}")
 
 
+def current() -> Optional["TemporalParallel"]:
+    return _ACTIVE
+
+
 class TemporalParallel:
     def __init__(self, group: Optional[dist.ProcessGroup] = None, spatial: int = 1):
         self.group = group

@@ -401,3 +401,11 @@ def test_pipeline_rope_matches_the_reference_call_site_for_random_shapes():
     def prop(h, w, f):
         check(16 * h, 16 * w, f)
     prop()
+
+
+def test_vae_parallel_module_surface():
+    """What vae_modules / autoencoder_magvit reach for in vae_parallel on EVERY decode (a missing name only shows up on a GPU)."""
+    from easyanimate_amd import vae_parallel
+    assert vae_parallel.current() is None
+    for name in ("TemporalParallel", "current", "_subgroups"):
+        assert hasattr(vae_parallel, name), name
