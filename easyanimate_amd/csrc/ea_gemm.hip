@@ -94,11 +94,8 @@ __device__ __forceinline__ int swap23(int m) {  // swap bits 2 and 3
 // group, so the workgroups resident on an XCD at any time cover an 8 x {8 (128^2 tiles) | 4 (256^2 tiles)} patch
 // of tiles: per K-step they pull 8 A-tiles + a few W-tiles through that L2 instead of ~3 + 24 (round-1 PMC:
 // 10-20x HBM over-fetch with the plain N-fastest order).
-__device__ __forceinline__ bool tile_of_vblock(const GemmArgs& p, int vb, int& tm, int& tn);
-__device__ __forceinline__ bool tile_of_block(const GemmArgs& p, int& tm, int& tn) { return tile_of_vblock(p, blockIdx.x, tm, tn); }
-// vb: the (virtual) block index -- a persistent workgroup walks vb = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of
-// 8, so every index it visits belongs to its own XCD)
-__device__ __forceinline__ bool tile_of_vblock(const GemmArgs& p, int vb, int& tm, int& tn) {
+__device__ __forceinline__ bool tile_of_block(const GemmArgs& p, int& tm, int& tn) {
+    const int vb = blockIdx.x;
     if (p.rows_per_xcd > 0) {
         const int xcd = vb & 7, idx = vb >> 3;
         const int m_lo = xcd * p.rows_per_xcd;
@@ -813,64 +810,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
 }
 
 // =================================================================================================
-// Round 4 experiment: the product kernel as a PERSISTENT workgroup -- one workgroup per CU walks its share of the tiles (virtual
-// block indices blockIdx.x + j * gridDim.x: the same per-XCD band order) instead of 78 (FFN-up) or 20 (out-projection) workgroups
-// being dispatched to that CU one after the other.  Identical tile code; what it can save is the dispatch gap between
-// consecutive workgroups of a CU (a 512-thread, 128 KiB workgroup can only start once its predecessor has left).
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_mi16p_kernel(GemmArgs p, int nblocks) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int lr = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.y;
-    const unsigned short* Ab = p.A + b * p.abs_;
-    char* const dma_a = smem + wave * 4096;
-    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
-    unsigned a_k[2], w_k[2];
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-        w_k[ks2] = 2 * OPER2 + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-    }
-    const int nk = p.K / BK;
-    for (int vb = blockIdx.x; vb < nblocks; vb += gridDim.x) {
-        int tm, tn;
-        if (!tile_of_vblock(p, vb, tm, tn)) continue;
-        const int row0 = tm * 256, col0 = tn * 256;
-        const unsigned short* asrc[4];
-        const unsigned short* wsrc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
-            const int cs = c ^ (r & 7);
-            int ra = row0 + r;
-            ra = ra < p.M ? ra : p.M - 1;
-            int rw = col0 + r;
-            rw = rw < p.N ? rw : p.N - 1;
-            asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
-            wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
-        }
-        f32x4_t acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-        bf16x8 wf[4];
-        W8Lane w8;
-        EA_G3_MAINLOOP(0, false)
-        gemm_wave_epilogue<EPI>(p, b, acc, smem + wave * 16384, row0 + wr * 128, col0 + wc * 64, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();      // every wave is done with its image before the next tile's DMA lands on it
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// =================================================================================================
 // Fused QKV projection: ONE launch computes q, k, v = Linear_{q,k,v}(x) for a token stream and finishes each
 // (128 tokens x one head) wave tile in its epilogue -- bias, qk-LayerNorm(64), interleaved RoPE, softmax scale on q,
 // head-major scatter of q / k rows, transposed scatter of v -- i.e. processor.py:244-285 without the [B,n,3d] QKV
@@ -1104,10 +1043,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     }
 }
 
-#ifndef EA_GEMM_PERSIST_DEFAULT
-#define EA_GEMM_PERSIST_DEFAULT 0
-#endif
-int g_gemm_persist = EA_GEMM_PERSIST_DEFAULT;   // ea_set_option("gemm_persist", 0 | 1 | 2): n x 256 persistent workgroups walk the tiles of the large bf16-weight GEMMs
 int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of the 256^2 kernel (32: the first version, kept as cross-check)
 
 template <int EPI, bool W8>
@@ -1121,22 +1056,6 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
     p.rows_per_xcd = p.tiles_m >= 64 ? (p.tiles_m + 7) / 8 : 0;
     dim3 grid(p.rows_per_xcd ? 8 * p.rows_per_xcd * p.tiles_n : p.tiles_m * p.tiles_n, batch);
     static bool attr_done[2] = {false, false};
-    if (tile == 256 && g_gemm_persist && g_gemm_mfma == 16 && !W8 && EPI != EA_EPI_F32_OUT) {
-        // persistent form: g_gemm_persist x 256 workgroups in all (a multiple of 8 per batch element), each walking its share of the tiles
-        int gx = g_gemm_persist * 256 / batch / 8 * 8;
-        gx = gx < 8 ? 8 : gx;
-        const int nblocks = (int)grid.x;
-        if (gx < nblocks) {
-            static bool attrp_done = false;
-            if (!attrp_done) {
-                hipFuncSetAttribute((const void*)gemm256_mi16p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                attrp_done = true;
-            }
-            ea_count("gemm_256_mi16_persistent");
-            hipLaunchKernelGGL(gemm256_mi16p_kernel<EPI>, dim3(gx, batch), dim3(threads), lds, st, p, nblocks);
-            return EA_OK;
-        }
-    }
     if (tile == 256) {
         if (!attr_done[1]) {
             hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1307,12 +1226,6 @@ int ea_gemm_tile_get() { return g_gemm_tile; }
 int ea_gemm_tile_set(int v) {
     if (v != 0 && v != 128 && v != 256) return -1;
     g_gemm_tile = v;
-    return 0;
-}
-int ea_gemm_persist_get() { return g_gemm_persist; }
-int ea_gemm_persist_set(int v) {
-    if (v < 0 || v > 4) return -1;
-    g_gemm_persist = v;
     return 0;
 }
 int ea_gemm_mfma_get() { return g_gemm_mfma; }

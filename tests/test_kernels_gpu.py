@@ -1027,42 +1027,3 @@ def test_swa_window_mapped_equals_index_copies(grid, T, H, cross_size):
     assert torch.equal(outs[False], outs[True])
     again = proc._swa(q, k, vt, B, H, 0, H, T, N, DEV, grid)
     assert torch.equal(again, outs[False])
-
-
-
-# ---- round 4: the 256 x 256 GEMM as persistent workgroups (experiment) ----
-@pytest.mark.parametrize("B,M,N,K", GEMM256_SHAPES + [(1, 4096, 3072, 3072), (2, 9000, 2304, 192), (1, 70000, 512, 128), (3, 5000, 1024, 64)])
-@pytest.mark.parametrize("epi", [0, 1, 2])
-def test_gemm_persistent_workgroups_equal_the_product_kernel(B, M, N, K, epi):
-    """gemm256_mi16p_kernel (ea_set_option("gemm_persist", 1): 256 persistent workgroups walk the tiles in the product kernel's own
-    per-XCD order) against fp64 (through test_gemm) and against the product launch: identical tile code -> bit-identical; shapes
-    with fewer tiles than workgroups fall back to the plain launch (counted as such), strided batches split the persistent grid."""
-    from easyanimate_amd import _lib
-    ops = _ops()
-    persist_default = _lib.get_option("gemm_persist")
-    _lib.set_option("gemm_tile", 256)
-    try:
-        _lib.set_option("gemm_persist", 1)
-        _lib.reset_counters()
-        test_gemm(B, M, N, K, epi)
-        c = _lib.counters()
-        tiles = ((M + 255) // 256) * ((N + 255) // 256)
-        assert c.get("gemm_256_mi16_persistent", 0) == (1 if tiles > max(8, 256 // B // 8 * 8) else 0) and sum(c.values()) == 1, c
-        g = torch.Generator(device="cpu").manual_seed(8)
-        A = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
-        W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
-        bias = torch.randn(N, generator=g).to(DEV)
-        res = _bf(torch.randn(B, M, N, generator=g)).to(DEV)
-        gate = torch.randn(B, N, generator=g).to(DEV)
-        run = lambda: ops.gemm(A, W, bias, epi, res=res if epi == 2 else None, gate=gate if epi == 2 else None)
-        y1 = run()
-        for _ in range(3):
-            assert torch.equal(run(), y1)
-        _lib.set_option("gemm_persist", 0)
-        _lib.reset_counters()
-        y0 = run()
-        assert _lib.counters().get("gemm_256_mi16", 0) == 1
-        assert torch.equal(y0, y1)
-    finally:
-        _lib.set_option("gemm_tile", 0)
-        _lib.set_option("gemm_persist", persist_default)
