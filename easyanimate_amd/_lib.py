@@ -29,6 +29,7 @@ PROTOTYPES = {
     "ea_linear_small_m": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ea_timestep_sinusoid": [_P, _P, _I, _I, _I, _P],
     "ea_gemm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _I, _P],
+    "ea_gemm_bf16_kblocked": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _I, _I, _P],
     "ea_gemm_bf16_w8": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _I, _P],
     "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ea_qkv_gemm_norm_rope_bf16": [_P] * 16 + [_I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P],

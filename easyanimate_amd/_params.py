@@ -80,3 +80,9 @@ def bf16_weight(p, k_pad: int | None = None):
     if p.dtype == torch.bfloat16 and p.dim() == 2 and p.is_contiguous() and (k_pad is None or k_pad == p.shape[1]):
         return p.detach()
     return derived(p, f"bf16w{k_pad}", make)
+
+
+def kblocked_weight(p):
+    """The K-blocked copy [K / 64, N, 64] of a bf16 Linear weight [N, K] (ops.gemm_kblocked; cached like every derived weight,
+    so load_state_dict / LoRA merges are observed): 2 more bytes per weight for the layers that use it."""
+    return derived(p, "kblock", lambda t: t.to(torch.bfloat16).reshape(t.shape[0], t.shape[1] // 64, 64).permute(1, 0, 2).contiguous())

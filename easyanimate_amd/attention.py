@@ -9,10 +9,14 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
+import os
+
 from . import ops
-from ._params import f32, gemm_weight
+from ._params import f32, gemm_weight, kblocked_weight
 from .norm import EasyAnimateLayerNormZero, FP32LayerNorm
 from .processor import EasyAnimateAttnProcessor2_0, EasyAnimateSWAttnProcessor2_0
+
+KBLOCKED_FFN = os.environ.get("EA_KBLOCKED_FFN", "1") != "0"   # False: the feed-forward pair on row-major operands (A/B, tests)
 
 
 class Attention(nn.Module):
@@ -88,6 +92,20 @@ class FeedForward(nn.Module):
                 gate: Optional[torch.Tensor] = None, *args, **kwargs) -> torch.Tensor:
         x = hidden_states if hidden_states.dtype == torch.bfloat16 else hidden_states.to(torch.bfloat16)
         fc1, fc2 = self.net[0].proj, self.net[2]
+        w1, w2 = gemm_weight(fc1.weight), gemm_weight(fc2.weight)
+        if (KBLOCKED_FFN and x.dim() == 3 and x.is_contiguous() and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+                and ops.kblocked_ok(x.shape[0], x.shape[1], w1.shape[0], x.shape[2])
+                and ops.kblocked_ok(x.shape[0], x.shape[1], w2.shape[0], w1.shape[0])):
+            # the inner activation lives K-BLOCKED ([B, inner / 64, M, 64]): the first GEMM's 64-column wave tiles write whole blocks,
+            # and the second GEMM's LDS-DMA reads a K tile of 256 rows as one contiguous 32 KiB block instead of 256 pieces 24 KiB
+            # apart (inner = 12 288) -- the layout that GEMM's main loop was waiting on; its weight likewise (cached)
+            B = x.shape[0]
+            h = ops.gemm_kblocked(x, w1, f32(fc1.bias), ops.EPI_BIAS_GELU_TANH, ops.LAYOUT_C)
+            w2b = kblocked_weight(fc2.weight)
+            if residual is not None:
+                return ops.gemm_kblocked(h, w2b, f32(fc2.bias), ops.EPI_BIAS_GATE_RES, ops.LAYOUT_A | ops.LAYOUT_W,
+                                         res=residual if residual.is_contiguous() else residual.contiguous(), gate=gate.reshape(B, -1))
+            return ops.gemm_kblocked(h, w2b, f32(fc2.bias), ops.EPI_BIAS, ops.LAYOUT_A | ops.LAYOUT_W)
         h = ops.gemm(x, gemm_weight(fc1.weight), f32(fc1.bias), ops.EPI_BIAS_GELU_TANH)
         if residual is not None:
             B = x.shape[0]

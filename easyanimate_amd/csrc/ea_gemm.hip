@@ -32,6 +32,10 @@ struct GemmArgs {
     int M, N, K;
     int64_t lda, abs_, ldc, cbs, ldres, rbs, gbs;
     int tiles_m, tiles_n, rows_per_xcd;
+    // K-blocked operands of the 256 x 256 kernel (ea_gemm_bf16_kblocked): an operand laid out [K / 64][rows][64] -- a 64-deep K
+    // tile of 256 rows is ONE contiguous 32 KiB block instead of 256 pieces a row stride apart.  Row-major defaults: a_kstep =
+    // w_kstep = 64 (elements to the next K tile), ldw = K, c_kstep = 0 (C row-major).
+    int64_t a_kstep = 64, w_kstep = 64, ldw = 0, c_kstep = 0;
 };
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
@@ -570,13 +574,13 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
             af[i] = *reinterpret_cast<const bf16x8*>(smem + (a_k[(P) >> 1] + (S) * OPER2 + (((P) & 1) * 4 + i) * 2048)); \
         if ((P) == 0 && (HAS_NEXT)) {                                                                         \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-                asrc[i] += BK;                                                                                \
+                asrc[i] += a_kst;                                                                             \
                 glds16(asrc[i], dma_a + ((S) ^ 1) * OPER2 + i * 1024);                                        \
             }                                                                                                 \
         }                                                                                                     \
         if ((P) == 1 && (HAS_NEXT) && !(W8)) {                                                                \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-                wsrc[i] += BK;                                                                                \
+                wsrc[i] += w_kst;                                                                             \
                 glds16(wsrc[i], dma_w + ((S) ^ 1) * OPER2 + i * 1024);                                        \
             }                                                                                                 \
         }                                                                                                     \
@@ -717,7 +721,10 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmArgs& p, int b, f32
         const int r = q * 8 + r8;
         const int m = mrow0 + r;
         const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
-        if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8) = o;
+        // (K-blocked C: the wave's 64 columns are one [rows][64] block of the next GEMM's A operand -- 128 rows x 128 B, contiguous)
+        unsigned short* const crow = p.c_kstep ? Cb + (int64_t)(ncol0 >> 6) * p.c_kstep + (int64_t)m * 64 + c8 * 8
+                                               : Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8;
+        if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(crow) = o;
     }
 }
 
@@ -751,8 +758,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
         int rw = col0 + r;
         rw = rw < p.N ? rw : p.N - 1;
         asrc[i] = Ab + (int64_t)ra * p.lda + cs * 8;
-        wsrc[i] = p.W + (int64_t)rw * p.K + cs * 8;
+        wsrc[i] = p.W + (int64_t)rw * p.ldw + cs * 8;
     }
+    const int64_t a_kst = p.a_kstep, w_kst = p.w_kstep;      // elements to the next K tile (64 row-major; rows * 64 K-blocked)
     char* const dma_a = smem + wave * 4096;
     char* const dma_w = smem + 2 * OPER2 + wave * 4096;
 
@@ -882,6 +890,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
         asrc[i] = Ab + (int64_t)ra * q.lda + cs * 8;
         wsrc[i] = Wb + (int64_t)(col0 + r) * q.K + cs * 8;
     }
+    constexpr int64_t a_kst = BK, w_kst = BK;                     // row-major operands: the next K tile is 64 elements on
     char* const dma_a = smem + wave * 4096;
     char* const dma_w = smem + 2 * OPER2 + wave * 4096;
 
@@ -1048,6 +1057,7 @@ int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of th
 template <int EPI, bool W8>
 int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
     GemmArgs p = p0;
+    if (p.ldw == 0) p.ldw = p.K;
     const int bm = tile, threads = tile == 256 ? 512 : 256;
     const int lds = tile == 256 ? GEMM2_LDS : GEMM_LDS;
     p.tiles_m = (p.M + bm - 1) / bm;
@@ -1090,7 +1100,7 @@ int g_gemm_tile = 0;   // 0 = auto, 128 / 256 = forced (ea_set_option("gemm_tile
 template <bool W8>
 int gemm_entry(const ea_bf16* A, const void* W, const float* bias, ea_bf16* C, const ea_bf16* res, const float* gate, int batch,
                int M, int N, int K, int64_t lda, int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
-               int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream) {
+               int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream, int layout = 0) {
     EA_REQUIRE(A && W && C, "ea_gemm_bf16: null tensor");
     EA_REQUIRE(batch > 0 && batch <= 65535 && M >= 0 && N > 0 && K > 0, "ea_gemm_bf16: bad sizes");
     EA_REQUIRE(K % BK == 0, "ea_gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -1112,6 +1122,17 @@ int gemm_entry(const ea_bf16* A, const void* W, const float* bias, ea_bf16* C, c
     int tile = g_gemm_tile;
     if (tile != 128 && tile != 256)
         tile = ((int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch >= 512 && N % 256 == 0) ? 256 : 128;
+    if (layout) {
+        // K-blocked operands (ea_gemm_bf16_kblocked): bit 0 = A is [K / 64][M][64] per batch element, bit 1 = W is [K / 64][N][64],
+        // bit 2 = C is written as [N / 64][M][64] per batch element (the A operand of a following GEMM).  Served by the 256 x 256
+        // 16x16x32 kernel only (its DMA rows and its epilogue's 64-column wave tiles are what the layout is made for).
+        EA_REQUIRE((layout & ~7) == 0 && !W8 && epilogue != EA_EPI_F32_OUT && g_gemm_mfma == 16 && N % 256 == 0,
+                   "ea_gemm_bf16_kblocked: bf16 weights, bf16 output, N a multiple of 256 (the 256 x 256 kernel)");
+        tile = 256;
+        if (layout & 1) { p.lda = 64; p.a_kstep = (int64_t)M * 64; }
+        if (layout & 2) { p.ldw = 64; p.w_kstep = (int64_t)N * 64; }
+        if (layout & 4) { p.ldc = 64; p.c_kstep = (int64_t)M * 64; }
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case EA_EPI_BIAS: launch_gemm<0, W8>(p, batch, tile, st); break;
@@ -1130,6 +1151,15 @@ extern "C" int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bia
                             int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream) {
     return gemm_entry<false>(A, W, bias, C, res, gate, batch, M, N, K, lda, a_batch_stride, ldc, c_batch_stride, ldres,
                              res_batch_stride, gate_batch_stride, epilogue, stream);
+}
+
+extern "C" int ea_gemm_bf16_kblocked(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16* C,
+                                     const ea_bf16* res, const float* gate, int batch, int M, int N, int K,
+                                     int64_t a_batch_stride, int64_t c_batch_stride, int64_t ldres, int64_t res_batch_stride,
+                                     int64_t gate_batch_stride, int epilogue, int layout, void* stream) {
+    // lda / ldc are used for the operands that stay row-major (contiguous rows: K and N elements)
+    return gemm_entry<false>(A, W, bias, C, res, gate, batch, M, N, K, K, a_batch_stride, N, c_batch_stride, ldres,
+                             res_batch_stride, gate_batch_stride, epilogue, stream, layout);
 }
 
 extern "C" int ea_gemm_bf16_w8(const ea_bf16* A, const uint8_t* W_fp8, const float* bias, ea_bf16* C,

@@ -187,6 +187,56 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     return out.squeeze(0) if squeeze else out
 
 
+LAYOUT_A, LAYOUT_W, LAYOUT_C = 1, 2, 4     # ea_gemm_bf16_kblocked: which operands are K-blocked ([K / 64][rows][64])
+
+
+def kblocked_ok(B: int, M: int, N: int, K: int) -> bool:
+    """Shapes the K-blocked GEMM serves: the 256 x 256 kernel's (enough tiles, N % 256 == 0) with K % 64 == 0."""
+    return N % 256 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 256) * B >= 512
+
+
+def to_kblocked(w: torch.Tensor) -> torch.Tensor:
+    """[rows, K] -> [K / 64, rows, 64] (contiguous): the K-blocked form of a row-major operand (weights: once, cached)."""
+    rows, K = w.shape
+    return w.view(rows, K // 64, 64).permute(1, 0, 2).contiguous()
+
+
+def gemm_kblocked(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int, layout: int,
+                  out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ea_gemm_bf16 with K-blocked operands (layout = LAYOUT_A | LAYOUT_W | LAYOUT_C): A bf16 [B, M, K] (row-major, contiguous) or
+    [B, K/64, M, 64]; W bf16 [N, K] or [K/64, N, 64]; out bf16 [B, M, N] or [B, N/64, M, 64]; res / gate as gemm()."""
+    _dev(A, W, bias, out, res, gate)
+    _chk(A, _BF16, "A"); _chk(W, _BF16, "W")
+    if layout & LAYOUT_A:
+        B, kb, M, c = A.shape
+        K = kb * 64
+        assert c == 64 and A[0].is_contiguous()
+    else:
+        B, M, K = A.shape
+        assert A[0].is_contiguous()
+    if layout & LAYOUT_W:
+        kbw, N, c = W.shape
+        assert c == 64 and kbw * 64 == K and W.is_contiguous()
+    else:
+        N = W.shape[0]
+        assert W.shape == (N, K) and W.is_contiguous()
+    oshape = (B, N // 64, M, 64) if layout & LAYOUT_C else (B, M, N)
+    if out is None:
+        out = torch.empty(oshape, dtype=_BF16, device=A.device)
+    assert out.shape == oshape and out[0].is_contiguous() and kblocked_ok(B, M, N, K)
+    if bias is not None:
+        _chk(bias, _F32, "bias")
+    ldres = rbs = gbs = 0
+    if epilogue == EPI_BIAS_GATE_RES:
+        assert res is not None and gate is not None and not (layout & LAYOUT_C)
+        _chk(res, _BF16, "res"); _chk(gate, _F32, "gate")
+        assert res.shape == (B, M, N) and res.stride(2) == 1 and gate.shape == (B, N) and gate.stride(1) == 1
+        ldres, rbs, gbs = res.stride(1), res.stride(0), gate.stride(0)
+    _timed("gemm", lambda: _lib.call("ea_gemm_bf16_kblocked", _p(A), _p(W), _p(bias), _p(out), _p(res), _p(gate), B, M, N, K, A.stride(0),
+                                     out.stride(0), ldres, rbs, gbs, int(epilogue), int(layout), _stream()))
+    return out
+
+
 # Softmax scale of head_dim 64 folded into Q (exp2 domain): q_scale = 64^-1/2 * log2(e) at ea_qknorm_rope_bf16, and
 # scale = ln(2) at ea_attention_fwd_* (scale * log2(e) == 1 selects the kernel that exponentiates raw scores).
 FOLDED_Q_SCALE = 0.125 * 1.4426950408889634

@@ -116,6 +116,19 @@ int ea_gemm_bf16(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16*
                  int64_t a_batch_stride, int64_t ldc, int64_t c_batch_stride, int64_t ldres,
                  int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, void* stream);
 
+/* ea_gemm_bf16 on K-BLOCKED operands (round 4; the feed-forward pair attention.py:1156-1162 / diffusers FeedForward): an operand
+ * laid out [K / 64][rows][64] makes a 64-deep K tile of 256 rows ONE contiguous 32 KiB block for the kernel's LDS-DMA instead of
+ * 256 pieces a row stride apart -- with K = 12 288 (24 KiB between rows) the strided form fills the LDS at 53 GB/s per CU against
+ * 85 GB/s (tools/ubench/lds_dma_rate.hip), and the second FFN GEMM is bound by exactly that.  layout bit 0: A is
+ * [batch][K / 64][M][64]; bit 1: W is [K / 64][N][64]; bit 2: C is written as [batch][N / 64][M][64] (the A operand of the next
+ * call: the first FFN GEMM writes what the second one reads).  Operands without their bit are row-major with contiguous rows
+ * (lda = K, ldc = N); res / gate / bias / epilogue as ea_gemm_bf16.  Same products in the same order: results identical to
+ * ea_gemm_bf16 on the row-major form of the same values.  Requires bf16 weights, N % 256 == 0 (served by the 256 x 256 kernel). */
+int ea_gemm_bf16_kblocked(const ea_bf16* A, const ea_bf16* W, const float* bias, ea_bf16* C, const ea_bf16* res,
+                          const float* gate, int batch, int M, int N, int K, int64_t a_batch_stride, int64_t c_batch_stride,
+                          int64_t ldres, int64_t res_batch_stride, int64_t gate_batch_stride, int epilogue, int layout,
+                          void* stream);
+
 /* The same GEMM with the weight stored as fp8: W_fp8 = torch.float8_e4m3fn (OCP E4M3) bytes, [N,K] row-major, the storage
  * mode of the reference's `model_cpu_offload_and_qfloat8` (utils/fp8_optimization.py:17-35 keeps every Linear weight in fp8
  * and up-casts it to bf16 for each call).  The kernel reads the fp8 bytes, widens them to bf16 on the way into the LDS

@@ -1027,3 +1027,60 @@ def test_swa_window_mapped_equals_index_copies(grid, T, H, cross_size):
     assert torch.equal(outs[False], outs[True])
     again = proc._swa(q, k, vt, B, H, 0, H, T, N, DEV, grid)
     assert torch.equal(again, outs[False])
+
+
+# ---- round 4: K-blocked operands for the feed-forward pair -------------------------------------------------------------------------
+@pytest.mark.parametrize("B,M,dim,inner", [(1, 140000, 256, 1024), (2, 70000, 512, 2048), (1, 66000 + 77, 1024, 1536)])
+def test_gemm_kblocked_ffn_pair_equals_row_major(B, M, dim, inner):
+    """ea_gemm_bf16_kblocked: the first FFN GEMM writing its GELU output K-blocked ([B, inner / 64, M, 64]) and the second one
+    reading it K-blocked together with a K-blocked weight, against the same two GEMMs on row-major operands: the same products
+    in the same order -> bit-identical; the blocked intermediate equals the permuted row-major one; ragged M (a last tile of 77
+    rows), batch 2 with its own block stride."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(19)
+    x = _bf(torch.randn(B, M, dim, generator=g)).to(DEV)
+    w1 = _bf(torch.randn(inner, dim, generator=g) / math.sqrt(dim)).to(DEV)
+    w2 = _bf(torch.randn(dim, inner, generator=g) / math.sqrt(inner)).to(DEV)
+    b1, b2 = torch.randn(inner, generator=g).to(DEV), torch.randn(dim, generator=g).to(DEV)
+    res = _bf(torch.randn(B, M, dim, generator=g)).to(DEV)
+    gate = torch.randn(B, dim, generator=g).to(DEV)
+    _lib.set_option("gemm_tile", 256)
+    try:
+        h_ref = ops.gemm(x, w1, b1, ops.EPI_BIAS_GELU_TANH)
+        y_ref = ops.gemm(h_ref, w2, b2, ops.EPI_BIAS_GATE_RES, res=res, gate=gate)
+        y_ref0 = ops.gemm(h_ref, w2, b2, ops.EPI_BIAS)
+    finally:
+        _lib.set_option("gemm_tile", 0)
+    assert ops.kblocked_ok(B, M, inner, dim) and ops.kblocked_ok(B, M, dim, inner)
+    _lib.reset_counters()
+    h = ops.gemm_kblocked(x, w1, b1, ops.EPI_BIAS_GELU_TANH, ops.LAYOUT_C)
+    w2b = ops.to_kblocked(w2)
+    y = ops.gemm_kblocked(h, w2b, b2, ops.EPI_BIAS_GATE_RES, ops.LAYOUT_A | ops.LAYOUT_W, res=res, gate=gate)
+    y0 = ops.gemm_kblocked(h, w2b, b2, ops.EPI_BIAS, ops.LAYOUT_A | ops.LAYOUT_W)
+    y1 = ops.gemm_kblocked(h, w2, b2, ops.EPI_BIAS, ops.LAYOUT_A)              # blocked A with a row-major weight
+    torch.cuda.synchronize()
+    assert _lib.counters() == {"gemm_256_mi16": 4}, _lib.counters()
+    assert h.shape == (B, inner // 64, M, 64)
+    assert torch.equal(h.permute(0, 2, 1, 3).reshape(B, M, inner), h_ref)
+    assert torch.equal(y, y_ref) and torch.equal(y0, y_ref0) and torch.equal(y1, y_ref0)
+
+
+def test_feed_forward_kblocked_path_equals_row_major():
+    """attention.FeedForward: the K-blocked pair (default) against EA_KBLOCKED_FFN=0 on the same module -- bit-identical, and the
+    blocked path is the one taken at a config-2-sized stream."""
+    from easyanimate_amd import _lib, attention
+    g = torch.Generator(device="cpu").manual_seed(4)
+    ff = attention.FeedForward(512, activation_fn="gelu-approximate", final_dropout=True).to(torch.bfloat16).to(DEV).eval()
+    x = _bf(torch.randn(2, 70000, 512, generator=g)).to(DEV)
+    res = _bf(torch.randn(2, 70000, 512, generator=g)).to(DEV)
+    gate = torch.randn(2, 1, 512, generator=g).to(DEV)
+    outs = {}
+    for blocked in (True, False):
+        attention.KBLOCKED_FFN = blocked
+        try:
+            with torch.no_grad():
+                outs[blocked] = (ff(x, residual=res, gate=gate), ff(x))
+        finally:
+            attention.KBLOCKED_FFN = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
