@@ -73,6 +73,56 @@ __global__ __launch_bounds__(512, 2) void k(const char* __restrict__ src, float*
     out[blockIdx.x * 512 + tid] = s;
 }
 
+// The attention kernel's pattern: 256 threads, two workgroups per CU, per 64-key tile 8 KiB of K (contiguous rows) and 8 KiB of V^T
+// (64 channel rows of 128 B, `vstride` bytes apart: S_pad * 2 in the product layout [B, H, 64, S_pad]; 128 = key-blocked).  The
+// workgroups of an XCD stream the same head.
+__global__ __launch_bounds__(256, 2) void katt(const char* __restrict__ src, float* out, int tiles, long vstride, long head_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7;
+    const char* kb = src + (long)xcd * 2 * head_bytes;
+    const char* vb = kb + head_bytes;
+    const char* ks[2];
+    const char* vs[2];
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wave * 2 + i) * 64 + lane, r = L >> 3, c = L & 7;
+        ks[i] = kb + (long)r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+        vs[i] = vb + (long)r * vstride + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    const long vtile = vstride == 128 ? 8192 : 128;     // bytes to the next 64-key tile of V^T
+    for (int t = 0; t < tiles; ++t) {
+        char* st = smem + (t & 1) * 16384 + wave * 2048;
+        for (int i = 0; i < 2; ++i) {
+            glds16(ks[i] + (long)t * 8192, st + i * 1024);
+            glds16(vs[i] + (long)t * vtile, st + 8192 + i * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[blockIdx.x * 256 + tid] = (float)smem[tid];
+}
+
+void run_att(const char* name, const char* src, float* out, long vstride, int tiles) {
+    const long head_bytes = (long)tiles * 8192 + 64 * 128;      // K rows then V^T rows of one head (tiles * 64 keys)
+    hipFuncSetAttribute((const void*)katt, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(katt, dim3(512), dim3(256), 32768, 0, src, out, tiles, vstride, head_bytes);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        for (int l = 0; l < 5; ++l) hipLaunchKernelGGL(katt, dim3(512), dim3(256), 32768, 0, src, out, tiles, vstride, head_bytes);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double us_tile = ms * 1e3 / 5 / tiles;
+        printf("{\"what\": \"%s\", \"vt_row_stride_B\": %ld, \"us_per_64_key_tile_per_WG\": %.3f, \"dma_GBps_per_CU\": %.1f, \"needed_at_1300_TFLOPs_us\": 0.83}\n", name,
+               vstride, us_tile, 2 * 16384.0 / us_tile / 1e3);
+    }
+}
+
 template <int MODE>
 void run(const char* name, const char* src, float* out, long ld, int share, long wg_stride) {
     const int iters = 2000, grid = 256;
@@ -110,5 +160,7 @@ int main() {
         }
     }
     run<4>("MFMA only", src, out, 6144, 4, 512 * 6144);
+    run_att("attention DMA pattern, V^T [64][S_pad]", src, out, 53504l * 2, 836);
+    run_att("attention DMA pattern, V^T key-blocked", src, out, 128, 836);
     return 0;
 }
