@@ -123,6 +123,49 @@ void run_att(const char* name, const char* src, float* out, long vstride, int ti
     }
 }
 
+// The row-slab convolution's pattern (conv3d_cl_row16_k32_kernel): a slab = 514 voxels x 32 channels = LDS rows of 64 B, one voxel
+// `vstride` bytes after the other (channels-last activations: C * 2 bytes; 64 = channel-blocked [C / 32][voxels][32]).  512 threads,
+// one workgroup per CU, 33 pieces of 1 KiB (16 rows) per slab; `share` workgroups of an XCD read the same rows.
+__global__ __launch_bounds__(512, 2) void kslab(const char* __restrict__ src, float* out, int slabs, long vstride, int share) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long row_bytes = 1024l * vstride;                               // one image row of 1024 voxels
+    const char* base = src + ((long)xcd * 32 + slot / share) * 8 * row_bytes;
+    for (int t = 0; t < slabs; ++t) {
+        const char* rowp = base + (long)(t % 7) * row_bytes + (t / 7 % 4) * 64 * (vstride == 64 ? 0 : 1);
+        char* st = smem + (t & 1) * 34816;
+        for (int q = wave; q < 33; q += 8) {
+            const int r = q * 16 + (lane >> 2), c = lane & 3;
+            glds16(rowp + (long)r * vstride + ((c ^ ((r >> 1) & 3)) << 4), st + q * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[blockIdx.x * 512 + tid] = (float)smem[tid];
+}
+
+void run_slab(const char* name, const char* src, float* out, long vstride, int share) {
+    const int slabs = 4000;
+    hipFuncSetAttribute((const void*)kslab, hipFuncAttributeMaxDynamicSharedMemorySize, 69632);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kslab, dim3(256), dim3(512), 69632, 0, src, out, slabs / 4, vstride, share);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        for (int l = 0; l < 5; ++l) hipLaunchKernelGGL(kslab, dim3(256), dim3(512), 69632, 0, src, out, slabs, vstride, share);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double us = ms * 1e3 / 5 / slabs;
+        printf("{\"what\": \"%s\", \"voxel_stride_B\": %ld, \"share\": %d, \"us_per_slab\": %.3f, \"dma_GBps_per_CU\": %.1f, \"mfma_time_of_a_slab_us\": 0.75}\n", name, vstride, share, us,
+               33 * 1024.0 / us / 1e3);
+    }
+}
+
 template <int MODE>
 void run(const char* name, const char* src, float* out, long ld, int share, long wg_stride) {
     const int iters = 2000, grid = 256;
@@ -160,6 +203,11 @@ int main() {
         }
     }
     run<4>("MFMA only", src, out, 6144, 4, 512 * 6144);
+    for (int share : {1, 4}) {
+        run_slab("conv slab, channels-last C = 128", src, out, 256, share);
+        run_slab("conv slab, channels-last C = 256", src, out, 512, share);
+        run_slab("conv slab, channel-blocked [C/32][voxels][32]", src, out, 64, share);
+    }
     run_att("attention DMA pattern, V^T [64][S_pad]", src, out, 53504l * 2, 836);
     run_att("attention DMA pattern, V^T key-blocked", src, out, 128, 836);
     return 0;
