@@ -409,3 +409,18 @@ def test_vae_parallel_module_surface():
     assert vae_parallel.current() is None
     for name in ("TemporalParallel", "current", "_subgroups"):
         assert hasattr(vae_parallel, name), name
+
+
+def test_kblocked_layout_helpers():
+    """ops.to_kblocked / kblocked_ok (host side of ea_gemm_bf16_kblocked): [rows, K] -> [K / 64, rows, 64] is a pure re-indexing, and
+    the shape rule is the 256 x 256 kernel's (>= 512 tiles, N % 256 == 0, K % 64 == 0)."""
+    from easyanimate_amd import ops
+    w = torch.arange(6 * 192, dtype=torch.float32).view(6, 192)
+    b = ops.to_kblocked(w)
+    assert b.shape == (3, 6, 64) and b.is_contiguous()
+    for kb in range(3):
+        assert torch.equal(b[kb], w[:, kb * 64:(kb + 1) * 64])
+    assert torch.equal(b.permute(1, 0, 2).reshape(6, 192), w)
+    assert ops.kblocked_ok(2, 53248, 3072, 12288) and ops.kblocked_ok(2, 13312, 12288, 3072) and ops.kblocked_ok(1, 13312, 3072, 12288)
+    assert not ops.kblocked_ok(2, 5120, 3072, 12288)          # 20 x 12 x 2 = 480 tiles: the 128-row kernels' territory
+    assert not ops.kblocked_ok(2, 53248, 3072 + 64, 12288) and not ops.kblocked_ok(2, 53248, 3072, 12288 + 32)

@@ -292,3 +292,37 @@ def test_self_loop_bring_up_mode_equals_whole_clip(frames, virtual):
     mp.spawn(_worker_self_loop, args=(1, _free_port(), frames, virtual, ret), nprocs=1, join=True)
     err, msgs, active = ret[0]
     assert err < 1e-12 and active == virtual and msgs == 4 * (virtual - 1)     # 4 causal convolutions in _decode
+
+
+def _subgroup_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easyanimate_amd import vae_parallel
+        # (1) partitions of the WORLD: created by every rank in the same order, cached (the second call returns the same objects)
+        pairs = [[0, 1], [2, 3]]
+        g1 = vae_parallel._subgroups(pairs, None)
+        g2 = vae_parallel._subgroups(pairs, None)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t, group=g1)
+        ok_world = g1 is g2 and dist.get_world_size(g1) == 2 and t.item() == (1.0 if rank < 2 else 5.0)
+        # (2) a partition of a STRICT sub-group (one CFG half): only its members get here; member-local creation
+        ok_sub = True
+        if rank < 2:
+            singles = vae_parallel._subgroups([[0], [1]], g1)
+            ok_sub = dist.get_world_size(singles) == 1 and vae_parallel._subgroups([[0], [1]], g1) is singles
+        dist.barrier()
+        ret[rank] = (ok_world, ok_sub)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_subgroups_are_cached_and_world_collective():
+    """vae_parallel._subgroups (the CFG halves of sequence_parallel, the row groups of the VAE split): one creation per process,
+    world-collective for partitions of the world (an eagerly initialised RCCL world splits communicators with every rank taking
+    part), member-local only for partitions of a strict sub-group."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_subgroup_worker, args=(4, _free_port(), ret), nprocs=4, join=True)
+    assert len(ret) == 4 and all(a and b for a, b in ret.values()), dict(ret)
