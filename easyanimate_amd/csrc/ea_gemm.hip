@@ -662,7 +662,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 // ---- epilogue of ONE wave tile (128 output rows x 64 columns, acc[i][j]: MFMA tile (row block i, column block j), C^T
 // orientation: a lane holds 4 consecutive columns of row lr) through the wave-private 16 KiB LDS image `img` (rows = the wave's
 // 128 output rows, 128 B = its 64 columns, 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and
-// the read-out use).  Shared by the eight-wave 256 x 256 kernel and the four-wave 128 x 256 kernel.
+// the read-out use).  p.c_kstep != 0 writes the tile K-blocked (one [rows][64] block of the next GEMM's A operand).
 template <int EPI>
 __device__ __forceinline__ void gemm_wave_epilogue(const GemmArgs& p, int b, f32x4_t (&acc)[8][4], char* const img, const int mrow0,
                                                    const int ncol0, const int lane) {
