@@ -30,7 +30,8 @@ def observes_weight_writes(fn):
     """Wrap a function that edits parameters through `.data` (the reference's utils/lora_utils.py merge_lora /
     unmerge_lora): the derived-weight cache is dropped after it returns.  The pipelines also do this at the start of every
     __call__, so `pipeline = merge_lora(pipeline, ...); pipeline(...)` needs nothing; use this when driving
-    transformer.forward / vae.decode directly."""
+    transformer.forward / vae.decode directly.  (bf16 Linear weights are read in place and need nothing; their one derived copy,
+    the K-blocked ff.net.2 weight, is refreshed by FeedForward on every call outside _params.weights_frozen().)"""
     import functools
 
     @functools.wraps(fn)

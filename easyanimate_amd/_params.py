@@ -43,8 +43,40 @@ def _drop(k) -> None:
 def invalidate_weight_cache() -> None:
     """Drop every derived copy.  Needed only after writes the version counter cannot see, i.e. `param.data.add_(...)`
     style updates (the reference's utils/lora_utils.py:merge_lora / unmerge_lora) on parameters that are NOT used in
-    place -- contiguous 2-D bf16 Linear weights are read directly and need nothing."""
+    place -- contiguous 2-D bf16 Linear weights are read directly and need nothing.  One derived copy of a bf16 Linear weight
+    exists: the K-blocked form of ff.net.2 (kblocked_weight); FeedForward refreshes it on every un-frozen call
+    (weights_frozen), so a forward -> `.data` merge -> forward sequence on the bare transformer sees the merged weight too."""
     _cache.clear()
+
+
+def drop_tag(tag: str) -> None:
+    """Drop the derived copies of one kind (e.g. "kblock")."""
+    for k in [k for k in _cache if k[1] == tag]:
+        del _cache[k]
+
+
+_frozen = 0
+
+
+class weights_frozen:
+    """`with weights_frozen():` -- the caller promises that no parameter is written inside (a sampling loop).  Outside of it
+    FeedForward.forward re-derives the K-blocked copy of its ff.net.2 weight on each call (kblocked_weight: 1.5 ms per forward at
+    the 12B size), because a `weight.data += delta` LoRA merge (utils/lora_utils.py:369-433) between two forwards is invisible
+    to the version counter; the pipelines' loops run frozen (they drop every derived copy once per call instead)."""
+
+    def __enter__(self):
+        global _frozen
+        _frozen += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _frozen
+        _frozen -= 1
+        return False
+
+
+def frozen() -> bool:
+    return _frozen > 0
 
 
 def f32(p):
@@ -83,6 +115,14 @@ def bf16_weight(p, k_pad: int | None = None):
 
 
 def kblocked_weight(p):
-    """The K-blocked copy [K / 64, N, 64] of a bf16 Linear weight [N, K] (ops.gemm_kblocked; cached like every derived weight,
-    so load_state_dict / LoRA merges are observed): 2 more bytes per weight for the layers that use it."""
-    return derived(p, "kblock", lambda t: t.to(torch.bfloat16).reshape(t.shape[0], t.shape[1] // 64, 64).permute(1, 0, 2).contiguous())
+    """The K-blocked copy [K / 64, N, 64] of a bf16 Linear weight [N, K] (ops.gemm_kblocked; cached like every derived weight:
+    load_state_dict / in-place writes are seen through the version counter).  `.data` writes are not, so outside a
+    weights_frozen() region the copy is re-derived IN PLACE on every use (2 x 75 MB of traffic = 30 us at the 12B size): 2 more
+    bytes per weight for the layers that use it."""
+    make = lambda t: t.to(torch.bfloat16).reshape(t.shape[0], t.shape[1] // 64, 64).permute(1, 0, 2)
+    ent = _cache.get((id(p), "kblock"))
+    val = derived(p, "kblock", lambda t: make(t).contiguous())
+    if ent is not None and ent[1] is val and not frozen():
+        with torch.no_grad():
+            val.copy_(make(p.detach()))
+    return val

@@ -191,8 +191,12 @@ LAYOUT_A, LAYOUT_W, LAYOUT_C = 1, 2, 4     # ea_gemm_bf16_kblocked: which operan
 
 
 def kblocked_ok(B: int, M: int, N: int, K: int) -> bool:
-    """Shapes the K-blocked GEMM serves: the 256 x 256 kernel's (enough tiles, N % 256 == 0) with K % 64 == 0."""
-    return N % 256 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 256) * B >= 512
+    """Shapes the K-blocked GEMM serves: the 256 x 256 kernel's (enough tiles, N % 256 == 0) with K % 64 == 0 -- and only while
+    the library's tuning switches leave that kernel selectable (ea_gemm_bf16_kblocked is the 16x16x32 256 x 256 kernel: with
+    "gemm_mfma" = 32 or "gemm_tile" = 128 the callers fall back to ops.gemm, so results never depend on the switches)."""
+    if not (N % 256 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 256) * B >= 512):
+        return False
+    return _lib.get_option("gemm_mfma") == 16 and _lib.get_option("gemm_tile") in (0, 256)
 
 
 def to_kblocked(w: torch.Tensor) -> torch.Tensor:

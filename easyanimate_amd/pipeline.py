@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import _params
 from ._params import invalidate_weight_cache
 from .embeddings import get_3d_rotary_pos_embed, get_resize_crop_region_for_grid
 from .scheduler import FlowMatchEulerDiscreteScheduler
@@ -319,24 +320,28 @@ class EasyAnimatePipeline:
         out_dtype = latents.dtype
         if self.latents_fp32 and latents.dtype != torch.float32:
             latents = latents.float()
-        for i, t in enumerate(timesteps):
-            if self._interrupt:
-                continue
-            latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
-            t_expand = t.reshape(1).expand(latent_model_input.shape[0]).to(dtype=latent_model_input.dtype)
-            noise_pred = self.transformer(
-                latent_model_input, t_expand, encoder_hidden_states=prompt_embeds,
-                encoder_hidden_states_t5=prompt_embeds_2, image_rotary_emb=image_rotary_emb,
-                inpaint_latents=inpaint_latents, return_dict=False)[0]
-            if noise_pred.size(1) != latents.size(1):
-                noise_pred, _ = noise_pred.chunk(2, dim=1)
-                noise_pred = noise_pred.contiguous()
-            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False,
-                                          guidance_scale=guidance_scale if do_cfg else None,
-                                          guidance_rescale=guidance_rescale if do_cfg else 0.0)[0]
-            if callback_on_step_end is not None:
-                out = callback_on_step_end(self, i, t, {"latents": latents})
-                latents = out.pop("latents", latents) if out else latents
+        # no parameter is written inside the loop: the derived K-blocked ff.net.2 weights are re-derived once here (a `.data` LoRA
+        # merge since the last call is invisible to the version counter), not once per forward (_params.weights_frozen)
+        _params.drop_tag("kblock")
+        with _params.weights_frozen():
+            for i, t in enumerate(timesteps):
+                if self._interrupt:
+                    continue
+                latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
+                t_expand = t.reshape(1).expand(latent_model_input.shape[0]).to(dtype=latent_model_input.dtype)
+                noise_pred = self.transformer(
+                    latent_model_input, t_expand, encoder_hidden_states=prompt_embeds,
+                    encoder_hidden_states_t5=prompt_embeds_2, image_rotary_emb=image_rotary_emb,
+                    inpaint_latents=inpaint_latents, return_dict=False)[0]
+                if noise_pred.size(1) != latents.size(1):
+                    noise_pred, _ = noise_pred.chunk(2, dim=1)
+                    noise_pred = noise_pred.contiguous()
+                latents = self.scheduler.step(noise_pred, t, latents, return_dict=False,
+                                              guidance_scale=guidance_scale if do_cfg else None,
+                                              guidance_rescale=guidance_rescale if do_cfg else 0.0)[0]
+                if callback_on_step_end is not None:
+                    out = callback_on_step_end(self, i, t, {"latents": latents})
+                    latents = out.pop("latents", latents) if out else latents
         return latents.to(out_dtype)
 
     @torch.no_grad()

@@ -47,29 +47,47 @@ def _workspace_q(B: int, H: int, q_pad: int, device) -> torch.Tensor:
     return q
 
 
-def _workspace_heads(B: int, Hl: int, s_pad: int, device, dtype=torch.bfloat16):
+_ws_live: dict = {}      # workspace key -> live length of the last call (rows / columns behind it are zero)
+
+
+def _workspace_heads(B: int, Hl: int, s_pad: int, device, dtype=torch.bfloat16, live: int = None):
     """q / k / v^T of ALL tokens for this rank's heads (head-parallel attention under sequence parallelism), zero-initialised
-    once and reused by every block: rows >= seq are never written."""
+    once and reused by every block.  Rows >= `live` (the caller's T + Nt) are zero: the workspace is keyed by the PADDED length,
+    so when a later call has a shorter sequence with the same padding, the rows the longer one wrote are zeroed again."""
     key = ("heads", B, Hl, s_pad, str(device), dtype)
     w = _ws.get(key)
     if w is None:
         for k in [k for k in _ws if k[0] == "heads"]:
             del _ws[k]
+            _ws_live.pop(k, None)
         w = (torch.zeros(B, Hl, s_pad, 64, dtype=dtype, device=device), torch.zeros(B, Hl, s_pad, 64, dtype=dtype, device=device),
              torch.zeros(B, Hl, 64, s_pad, dtype=dtype, device=device))
         _ws[key] = w
+    elif live is not None and live < _ws_live.get(key, s_pad):
+        prev = _ws_live.get(key, s_pad)
+        w[0][:, :, live:prev].zero_()
+        w[1][:, :, live:prev].zero_()
+        w[2][:, :, :, live:prev].zero_()
+    if live is not None:
+        _ws_live[key] = live
     return w
 
 
-def _workspace_vt_perm(B: int, Hl: int, n_pad: int, device) -> torch.Tensor:
-    """V^T in scan order for the sliding-window pass, zero-initialised once (columns behind the sequence must be finite)."""
+def _workspace_vt_perm(B: int, Hl: int, n_pad: int, device, live: int = None) -> torch.Tensor:
+    """V^T in scan order for the sliding-window pass, zero-initialised once (columns behind the sequence must be finite); columns
+    >= `live` (the caller's N) are zeroed again when a shorter sequence reuses the same padded workspace."""
     key = ("vtp", B, Hl, n_pad, str(device))
     w = _ws.get(key)
     if w is None:
         for k in [k for k in _ws if k[0] == "vtp"]:
             del _ws[k]
+            _ws_live.pop(k, None)
         w = torch.zeros(B, Hl, 64, n_pad, dtype=torch.bfloat16, device=device)
         _ws[key] = w
+    elif live is not None and live < _ws_live.get(key, n_pad):
+        w[:, :, :, live:_ws_live.get(key, n_pad)].zero_()
+    if live is not None:
+        _ws_live[key] = live
     return w
 
 
@@ -137,7 +155,7 @@ class EasyAnimateAttnProcessor2_0:
             send[:, 2].view(P, B, Hl, 64, nl)[..., n_own:].zero_()
         recv = sp.all_to_all(send)                                   # [source rank, 3, B, Hl, nl * 64]
         s_pad = ops.round_up(T + Nt, 256)
-        qf, kf, vf = _workspace_heads(B, Hl, s_pad, dev, dt)         # zero-initialised once; rows >= T + Nt are never written
+        qf, kf, vf = _workspace_heads(B, Hl, s_pad, dev, dt, live=T + Nt)   # rows >= T + Nt are zero
         hsl = slice(head0, head0 + Hl)
         qf[:, :, :T], kf[:, :, :T], vf[:, :, :, :T] = q[:, hsl, :T], k[:, hsl, :T], vt[:, hsl, :, :T]
         for g in range(P):
@@ -161,7 +179,11 @@ class EasyAnimateAttnProcessor2_0:
 
     def _heads_mode(self, lay, sp, H) -> bool:
         """EA_SP_MODE=heads (sequence_parallel.SequenceParallel.mode): the full-attention blocks exchange heads, not keys."""
-        return lay is not None and sp.size > 1 and getattr(sp, "mode", "keys") == "heads" and H % sp.size == 0
+        if lay is None or sp.size <= 1 or getattr(sp, "mode", "keys") != "heads":
+            return False
+        if H % sp.size:     # the user asked for the head exchange: no silent switch to the key all-gather (the SWA blocks raise too)
+            raise NotImplementedError(f"EA_SP_MODE=heads needs heads ({H}) % sequence ranks ({sp.size}) == 0; use EA_SP_MODE=keys")
+        return True
 
     def _attend(self, ws, B, H, T, N, S, v_off, d, dev, lay, sp, grid, pending=None):
         """softmax(QK^T)V over the rows staged in ws -> bf16 [B, S, d]."""
@@ -375,7 +397,7 @@ class EasyAnimateSWAttnProcessor2_0(EasyAnimateAttnProcessor2_0):
             back = win.transpose(1, 2)[:, hh, inv].transpose(1, 2)        # [B, N, Hl, 64] in (f h w) order again
             o[:, T:] = ops.bf16_add_(back.reshape(B, N, Hl * 64).contiguous(), cross[:, T:].contiguous())
         else:
-            vtp = _workspace_vt_perm(B, Hl, ops.round_up(N, 64), dev)            # zero-initialised once: columns >= N stay zero
+            vtp = _workspace_vt_perm(B, Hl, ops.round_up(N, 64), dev, live=N)    # columns >= N are zero
             ops.permute_cols(vt, vtp, order, (F_, Hh, Ww), T)
             ops.attention_window_mapped(q, k, vtp, cross, o, N, T, hmap32, Hh * Ww, ops.FOLDED_ATTN_SCALE)
         # ---- text rows: cross + cross; video rows: window + cross (added in the kernel's store)

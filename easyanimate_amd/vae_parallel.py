@@ -54,8 +54,13 @@ def _subgroups(rank_lists: List[List[int]], parent: Optional[dist.ProcessGroup])
       world-collective call cannot be made; the groups are created member-locally (`use_local_synchronization=True`) -- possible
       only when the default group has no eagerly bound communicator to split from; otherwise the caller has to create the groups
       up front, world-collectively."""
-    # (keyed by the default group too: a process that tears its world down and builds another must not meet the old one's groups)
-    key = (id(dist.distributed_c10d._get_default_group()),) + tuple(tuple(r) for r in rank_lists)
+    # (keyed by the default group's NAME -- c10d numbers its groups with a per-process counter, so a world built after
+    # destroy_process_group() never has the name of the old one, while id() of the new object may repeat; entries of a world that
+    # is gone are evicted)
+    world_name = dist.distributed_c10d._get_default_group().group_name
+    for k in [k for k in _SUBGROUPS if k[0] != world_name]:
+        del _SUBGROUPS[k]
+    key = (world_name,) + tuple(tuple(r) for r in rank_lists)
     me = dist.get_rank()
     if key not in _SUBGROUPS:
         world = dist.get_world_size()

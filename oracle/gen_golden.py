@@ -379,6 +379,60 @@ def gen_vae_dec_wide(ns, shim):
     print("  bf16 pass", time.time() - t0, "dec std", out["dec_std"], "shape", out["dec_shape"], "floor", out["dec_floor_mse"], flush=True)
 
 
+
+def vae_config4_inputs(seed=15, frames=49, size=1024):
+    """Seeded inputs of BASELINE config 4: U(-1, 1) RGB [1, 3, 49, 1024, 1024] and the latents the pipeline hands to
+    vae.decode, randn[1, 16, 13, 128, 128] / scaling_factor (pipeline_easyanimate.py decode_latents)."""
+    g = _g(seed)
+    z = torch.randn(1, 16, (frames - 1) // 4 + 1, size // 8, size // 8, generator=g) / 0.1825
+    video = torch.rand(1, 3, frames, size, size, generator=g) * 2 - 1
+    return video, z
+
+
+C4_PIX_STRIDE = 7      # coprime with every tile / sub-pixel period of the decoder: the samples visit all phases of 2, 4, 8, 16, 512
+C4_LAT_STRIDE = 3
+
+
+@section("vae_config4")
+def gen_vae_config4(ns, shim):
+    # ---- round 5 (VERDICT r4 next #2a): BASELINE config 4 AT THE SHAPE IT IS QUOTED ON -- 49 x 1024^2 through the unchanged
+    # reference (fp32, its chunked / cached mode: omnigen_enc_dec.py:279-337, 617-677; autoencoder_magvit.py:229-317), decode
+    # and encode.  ~1 h on 8 cores.  Stored: every 7th pixel (fp16) of the decode, every 3rd latent site (fp32) of the moments.
+    # EA_GOLDEN_C4_PART = "dec" | "enc" restricts the run to one half (each half writes its own file).
+    import time
+    part = os.environ.get("EA_GOLDEN_C4_PART", "dec,enc").split(",")
+    vkw = dict(FULL_VAE)
+    vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**vkw).eval()
+    shapes = _load_sd(vae, 2, "default")
+    video, zlat = vae_config4_inputs()
+    base = dict(cfg=vkw, shapes=shapes, seed=2, style="default", input_seed=15, frames=49, size=1024)
+    if "dec" in part:
+        t0 = time.time()
+        with torch.no_grad():
+            dec = vae.decode(zlat)[0]
+        dt = time.time() - t0
+        print("  decode fp32 49x1024^2", dt, tuple(dec.shape), flush=True)
+        s = C4_PIX_STRIDE
+        out = dict(base, z_sum=zlat.double().sum().item(), dec_shape=tuple(dec.shape), dec_std=dec.std().item(), stride=s,
+                   dec_sub_f16=dec[..., ::s, ::s].to(torch.float16).contiguous(), ref_cpu_seconds=dt,
+                   dec_frame_means=dec.double().mean(dim=(0, 1, 3, 4)))
+        torch.save(out, os.path.join(OUT, "vae_config4_dec_49x1024.pt"))
+        print("  dec std", out["dec_std"], flush=True)
+        del dec
+    if "enc" in part:
+        t0 = time.time()
+        with torch.no_grad():
+            moments = vae.encode(video)[0].parameters
+        dt = time.time() - t0
+        print("  encode fp32 49x1024^2", dt, tuple(moments.shape), flush=True)
+        s = C4_LAT_STRIDE
+        out = dict(base, video_sum=video.double().sum().item(), moments_shape=tuple(moments.shape), moments_std=moments.std().item(),
+                   stride=s, moments_sub=moments[..., ::s, ::s].contiguous(), ref_cpu_seconds=dt,
+                   moments_frame_means=moments.double().mean(dim=(0, 1, 3, 4)))
+        torch.save(out, os.path.join(OUT, "vae_config4_enc_49x1024.pt"))
+        print("  moments std", out["moments_std"], flush=True)
+
+
 def _ref_loop(ns, shim, m, latents, enc, rope, steps, guidance, dt, keep=None):
     """The reference's sampling loop (pipeline_easyanimate.py:1069-1111) over the shim-hosted reference transformer."""
     mm = copy.deepcopy(m).to(dt)

@@ -1084,3 +1084,31 @@ def test_feed_forward_kblocked_path_equals_row_major():
         finally:
             attention.KBLOCKED_FFN = True
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+
+
+def test_feed_forward_kblocked_copy_observes_data_writes():
+    """fc2 of the K-blocked pair is read through a derived copy; a `weight.data += delta` LoRA merge
+    (utils/lora_utils.py:369-433) between two forwards changes neither data_ptr nor _version.  Outside weights_frozen() the copy is
+    re-derived on every call, so forward -> .data merge -> forward equals a module that was loaded with the merged weight; inside
+    a frozen region (the pipelines' loops) the copy is kept, and the pipelines drop it once per call."""
+    from easyanimate_amd import _lib, _params, attention
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ff = attention.FeedForward(512, activation_fn="gelu-approximate", final_dropout=True).to(torch.bfloat16).to(DEV).eval()
+    x = _bf(torch.randn(2, 70000, 512, generator=g)).to(DEV)
+    delta = _bf(0.05 * torch.randn(512, 4, generator=g) @ torch.randn(4, 2048, generator=g)).to(DEV)
+    with torch.no_grad():
+        _lib.reset_counters()
+        y0 = ff(x)
+        assert _lib.counters() == {"gemm_256_mi16": 2}, _lib.counters()       # the K-blocked pair is the path under test
+        ff.net[2].weight.data += delta
+        y1 = ff(x)
+        ref = attention.FeedForward(512, activation_fn="gelu-approximate", final_dropout=True).to(torch.bfloat16).to(DEV).eval()
+        ref.load_state_dict(ff.state_dict())
+        y_ref = ref(x)
+        assert torch.equal(y1, y_ref) and not torch.equal(y1, y0)
+        with _params.weights_frozen():
+            ff.net[2].weight.data -= delta          # a write the frozen region promises not to do: the copy is NOT refreshed ...
+            assert torch.equal(ff(x), y1)
+        _params.drop_tag("kblock")                  # ... until the next pipeline call drops it (pipeline.denoise / __call__)
+        with _params.weights_frozen():
+            assert torch.equal(ff(x), y0)
