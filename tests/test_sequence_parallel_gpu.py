@@ -325,7 +325,7 @@ def test_sp_sliding_window_blocks_equal_single_rank(world, cfg_parallel):
         assert n_win == 1 and err <= 2e-2 * max(1.0, scale) and mse < 1e-4
 
 
-def _worker_full_width(rank, world, port, ret, mode="keys"):
+def _worker_full_width(rank, world, port, ret, mode="keys", golden="transformer_full_ragged.pt"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -333,7 +333,7 @@ def _worker_full_width(rank, world, port, ret, mode="keys"):
         from easyanimate_amd.embeddings import get_3d_rotary_pos_embed
         from easyanimate_amd.synthetic import synth_state_dict
         from oracle.gen_golden import dit_full_inputs
-        g = torch.load(os.path.join(GOLD, "transformer_full_ragged.pt"), weights_only=False)
+        g = torch.load(os.path.join(GOLD, golden), weights_only=False)
         B, Fr, H, W, T = g["dims"]
         lat, extra, enc = dit_full_inputs(g["cfg"], g["input_seed"], *g["dims"])
         rope = get_3d_rotary_pos_embed(64, g["crops"], grid_size=(H // 2, W // 2), temporal_size=Fr, use_real=True)
@@ -344,7 +344,7 @@ def _worker_full_width(rank, world, port, ret, mode="keys"):
         _lib.reset_counters()
         with torch.no_grad():
             out = m(lat.to("cuda:0").bfloat16(), g["t"].to("cuda:0").bfloat16(), encoder_hidden_states=enc.to("cuda:0").bfloat16(),
-                    image_rotary_emb=rope, return_dict=False)[0]
+                    image_rotary_emb=rope, inpaint_latents=None if extra is None else extra.to("cuda:0").bfloat16(), return_dict=False)[0]
         torch.cuda.synchronize()
         cnt = _lib.counters()
         mse = ((out.float().cpu().double() - g["out"].double()) ** 2).mean().item()
@@ -376,3 +376,26 @@ def test_sp_full_width_forward_vs_reference_golden(mode):
             assert cnt.get("gemm_qkv_fused_kv_part", 0) == 2 and cnt.get("gemm_qkv_fused_q_part", 0) == 2 and cnt.get("gemm_qkv_fused", 0) == 6, cnt
         else:
             assert cnt.get("attention_v3", 0) == 2 and "attention_v3_segments" not in cnt and cnt.get("gemm_qkv_fused", 0) == 4, cnt
+
+
+@pytest.mark.parametrize("mode", ["keys", "heads"])
+def test_sp_full_width_inpaint_forward_vs_reference_golden(mode):
+    """BASELINE config 5 in its multi-GPU form (I2V: `inpaint_latents` = mask + masked-video latents concatenated on the channel
+    axis inside the transformer, 33 input channels -- transformer3d.py:1523-1531; pipeline_easyanimate_inpaint.py:1500-1590) under
+    CFG 2 x sequence 2 at full width, against the REFERENCE's golden (transformer_full_inp.pt: 3 x 32 x 48 latents, N = 1152 video
+    tokens in shards of 576, T = 77 text tokens -- an unaligned text length, so the slot layout pads it): the CFG half's batch cut of
+    the 17 conditioning channels and the token-shard cut of the patchified 33-channel input both have to be right."""
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_full_width, args=(world, _free_port(), ret, mode, "transformer_full_inp.pt"), nprocs=world, join=True)
+    assert len(ret) == world
+    print(f"[parity] full-width InP transformer (33 channels) under CFG 2 x sequence 2 ({mode}) vs the reference golden:", dict(ret))
+    for r in range(world):
+        mse, size, rng, cnt = ret[r]
+        assert size == 2 and rng == ((0, 576) if r % 2 == 0 else (576, 1152))
+        assert mse < 1e-4
+        if mode == "keys":
+            assert cnt.get("attention_v3_segments", 0) == 2, cnt
+        else:
+            assert cnt.get("attention_v3", 0) == 2 and "attention_v3_segments" not in cnt, cnt
