@@ -73,6 +73,7 @@ extern "C" int ea_version(void) { return 112; }   // 112: ea_attention_window_ma
 #define EA_OPTION(n) int ea_##n##_set(int v); int ea_##n##_get();
 EA_OPTION(gemm_tile)      // ea_gemm.hip:      0 (auto) | 128 | 256
 EA_OPTION(gemm_mfma)      // ea_gemm.hip:      16 | 32
+EA_OPTION(gemm_w4a)       // ea_gemm.hip:      0 | 1 (four-wave 256 x 256 kernel, hand-placed main loop)
 EA_OPTION(conv_mfma)      // ea_conv.hip:      16 | 32
 EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
 EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1
@@ -84,7 +85,7 @@ int ea_build_variants_set(int v) { return v == EA_BUILD_VARIANTS ? 0 : -1; }
 namespace {
 struct Option { const char* name; int (*set)(int); int (*get)(); };
 #define EA_OPTION(n) {#n, ea_##n##_set, ea_##n##_get}
-const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(conv_mfma),
+const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(gemm_w4a), EA_OPTION(conv_mfma),
                             EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(attn_variant), EA_OPTION(build_variants)};
 #undef EA_OPTION
 const Option* find_option(const char* name) {

@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
 // The row-slab kernel for the C_out = 128 layers at full resolution (42 % of a 49 x 1024^2 decode): 512 voxels x 128
 // channels per workgroup.  The 256-voxel version above gives each wave a 64 x 64 tile: 8 fragment reads (8 KiB) per 16
 // MFMAs, and with eight waves that is 64 KiB of LDS reads per phase = 512 LDS cycles against 512 MFMA cycles per SIMD -- the
-// LDS read port is exactly saturated and the MFMA pipe ends at 55 % (profiles/r02k_conv_row16_sq_counters.txt: it is not
+// LDS read port is exactly saturated and the MFMA pipe ends at 55 % (profiles/history/r02k_conv_row16_sq_counters.txt: it is not
 // power-limited, 1.96 GHz).  A 128 x 64 wave tile needs 12 reads per 32 MFMAs (what the 256-channel tiles get), but its
 // 514-row slab does not fit beside the weights at 64 channels per stage (164 KiB).  So this kernel stages HALF the
 // channels: LDS rows are 64 bytes = 32 channels = exactly one k32 step,
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
 // Zero padding is the descriptor's range check: lanes on padding voxels carry an offset beyond the row, a row of padding
 // has extent 0 -- out-of-range buffer loads write zeros to the LDS.
 //
-// Measured (13 x 1024^2, in-session A/B, profiles/r02l_conv_m512_ab.txt): 128 -> 128 with residual + GroupNorm partials
+// Measured (13 x 1024^2, in-session A/B, profiles/history/r02l_conv_m512_ab.txt): 128 -> 128 with residual + GroupNorm partials
 // 11.81 -> 9.61 ms (1021 -> 1255 TFLOP/s), 256 -> 128 19.8 -> 17.5 ms (1217 -> 1376); of which 512-voxel tiles +4 %, one
 // phase per tile +9 %, buffer addressing +1.5 %, the residual prefetch in the epilogue +5 % on residual layers.
 //
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
 
 // ea_set_option("conv_m512", bit 0: the 512-voxel x 128-channel kernel, bit 1: the 256 x 256 kernel over 32-channel stages).
 // Bit 1 is off by default: for the 256-channel tiles the four-phase kernel over 64-channel stages is 1.5-3 % faster
-// (profiles/r02p_conv_k32_256_ab.txt) -- their W tile is 16 pieces of half cache lines per 32-MFMA phase.
+// (profiles/history/r02p_conv_k32_256_ab.txt) -- their W tile is 16 pieces of half cache lines per 32-MFMA phase.
 int g_conv_m512 = 1;
 int g_conv_mfma = 16;  // ea_set_option("conv_mfma", 16 | 32): MFMA shape of the row-slab kernel
 int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles;

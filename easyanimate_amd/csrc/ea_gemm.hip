@@ -818,6 +818,89 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
 }
 
 // =================================================================================================
+// 256 x 256 x 64 tiles with FOUR waves, one per SIMD, 128 x 128 wave tiles (8 x 8 MFMA tiles of 16x16x32 = 256 accumulator
+// registers = the whole AGPR file), main loop placed by hand as ONE inline-asm block (round 5; generated by
+// tools/gen_gemm_w4_asm.py into ea_gemm_w4_loop.inc -- the schedule is documented there).  Rounds 3 / 4 measured this wave
+// shape twice in fenced C++ (-3..-8 % against the eight-wave kernel) while the vendor's kernel of the same shape is 13-15 %
+// ahead; the compiled loops carried eight conditional branches per K tile around the DMA requests and compiler-placed waits.
+// Here: no branch inside a K tile (requests past the last tile go through an empty buffer resource), exactly one non-MFMA
+// instruction between two MFMAs, one barrier per operand hand-over (4 per K tile), 0.25 ds_read_b128 per MFMA.
+// Same LDS layout / swizzle / DMA source addressing / C^T orientation / epilogue image as gemm256_mi16_kernel: the same
+// products in another summation order over k (fp32 accumulation per 32 k, as there).
+#include "ea_gemm_w4_loop.inc"
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256_w4a_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm, tn;
+    if (!tile_of_block(p, tm, tn)) return;
+    const int b = blockIdx.y;
+    const int row0 = tm * 256, col0 = tn * 256;
+    const unsigned short* Ab = p.A + b * p.abs_;
+    const int nk = p.K / BK;
+
+    // DMA pieces: a K tile of an operand is 256 rows x 128 bytes = 32 pieces of 1 KiB; wave w stages pieces 8w .. 8w+7.  Buffer
+    // addressing: per-lane byte offsets relative to the tile's first row (fixed for the kernel), the K tile is the scalar offset.
+    int aoff[8], woff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ (r & 7);
+        const int ra = (row0 + r < p.M ? row0 + r : p.M - 1) - row0;
+        const int rw = (col0 + r < p.N ? col0 + r : p.N - 1) - col0;
+        aoff[i] = (int)((int64_t)ra * p.lda * 2) + cs * 16;
+        woff[i] = (int)((int64_t)rw * p.ldw * 2) + cs * 16;
+    }
+    const unsigned short* Abase = Ab + (int64_t)row0 * p.lda;
+    const unsigned short* Wbase = p.W + (int64_t)col0 * p.ldw;
+    const int a_rows = p.M - row0 < 256 ? p.M - row0 : 256, w_rows = p.N - col0 < 256 ? p.N - col0 : 256;
+    // bytes reachable from Abase / Wbase (host-checked to fit 32 bits)
+    const unsigned a_ext = (unsigned)((((int64_t)nk - 1) * p.a_kstep + ((int64_t)a_rows - 1) * p.lda + BK) * 2);
+    const unsigned w_ext = (unsigned)((((int64_t)nk - 1) * p.w_kstep + ((int64_t)w_rows - 1) * p.ldw + BK) * 2);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // fragment byte addresses of k-step 0: row * 128 + ((chunk ^ (row & 7)) << 4), chunk = lq; + 2048 per 16-row MFMA tile
+    const unsigned ak0 = lds0 + (wr * 128 + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+    const unsigned wk0 = lds0 + 2 * OPER2 + (wc * 128 + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+    const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + 2 * OPER2 + wave * 8192);
+    const unsigned a_lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Abase);
+    const unsigned a_hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)Abase >> 32));
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Wbase);
+    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)Wbase >> 32));
+    const unsigned a_kst = __builtin_amdgcn_readfirstlane((unsigned)(p.a_kstep * 2));
+    const unsigned w_kst = __builtin_amdgcn_readfirstlane((unsigned)(p.w_kstep * 2));
+    const unsigned a_ext_s = __builtin_amdgcn_readfirstlane(a_ext), w_ext_s = __builtin_amdgcn_readfirstlane(w_ext);
+    const unsigned nk_s = __builtin_amdgcn_readfirstlane((unsigned)nk);
+
+    asm volatile(EA_W4A_MAINLOOP_ASM
+                 :
+                 : [wk0] "v"(wk0), [ak0] "v"(ak0),
+                   [aoff0] "v"(aoff[0]), [aoff1] "v"(aoff[1]), [aoff2] "v"(aoff[2]), [aoff3] "v"(aoff[3]),
+                   [aoff4] "v"(aoff[4]), [aoff5] "v"(aoff[5]), [aoff6] "v"(aoff[6]), [aoff7] "v"(aoff[7]),
+                   [woff0] "v"(woff[0]), [woff1] "v"(woff[1]), [woff2] "v"(woff[2]), [woff3] "v"(woff[3]),
+                   [woff4] "v"(woff[4]), [woff5] "v"(woff[5]), [woff6] "v"(woff[6]), [woff7] "v"(woff[7]),
+                   [a_lo] "s"(a_lo), [a_hi] "s"(a_hi), [a_ext] "s"(a_ext_s), [w_lo] "s"(w_lo), [w_hi] "s"(w_hi), [w_ext] "s"(w_ext_s),
+                   [a_kst] "s"(a_kst), [w_kst] "s"(w_kst), [nk] "s"(nk_s), [lds_w] "s"(lds_w), [lds_a] "s"(lds_a)
+                 : EA_W4A_CLOBBERS);
+    __builtin_amdgcn_s_barrier();   // every wave's requests have landed and its fragment reads are done: the LDS becomes the epilogue images
+
+    // ---- epilogue: the wave's 128 x 128 tile as two 128 x 64 halves through its private 16 KiB image, gemm256_mi16_kernel's code
+    char* const img = smem + wave * 16384;
+    const int mrow0 = row0 + wr * 128;
+    f32x4_t acc[8][4];
+    EA_W4A_READ_HALF0(acc)
+    gemm_wave_epilogue<EPI>(p, b, acc, img, mrow0, col0 + wc * 128, lane);
+    EA_W4A_READ_HALF1(acc)
+    gemm_wave_epilogue<EPI>(p, b, acc, img, mrow0, col0 + wc * 128 + 64, lane);
+}
+
+// =================================================================================================
 // Fused QKV projection: ONE launch computes q, k, v = Linear_{q,k,v}(x) for a token stream and finishes each
 // (128 tokens x one head) wave tile in its epilogue -- bias, qk-LayerNorm(64), interleaved RoPE, softmax scale on q,
 // head-major scatter of q / k rows, transposed scatter of v -- i.e. processor.py:244-285 without the [B,n,3d] QKV
@@ -1052,6 +1135,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     }
 }
 
+int g_gemm_w4a = 0;     // ea_set_option("gemm_w4a", 0 | 1): the four-wave kernel with the hand-placed main loop instead of gemm256_mi16_kernel
 int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of the 256^2 kernel (32: the first version, kept as cross-check)
 
 template <int EPI, bool W8>
@@ -1076,6 +1160,22 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             if (!attr16_done) {
                 hipFuncSetAttribute((const void*)gemm256_mi16_kernel<EPI, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 attr16_done = true;
+            }
+            // the four-wave hand-placed kernel addresses its operands through 32-bit buffer offsets
+            const int64_t nk64 = p.K / BK;
+            const bool w4a_ok = !W8 && g_gemm_w4a && ((nk64 - 1) * p.a_kstep + 255 * p.lda + BK) * 2 < (int64_t)0xFFFFFFFF &&
+                                ((nk64 - 1) * p.w_kstep + 255 * p.ldw + BK) * 2 < (int64_t)0xFFFFFFFF;
+            if (w4a_ok) {
+                if constexpr (!W8) {
+                    static bool attrw4_done = false;
+                    if (!attrw4_done) {
+                        hipFuncSetAttribute((const void*)gemm256_w4a_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                        attrw4_done = true;
+                    }
+                    ea_count("gemm_256_w4a");
+                    hipLaunchKernelGGL((gemm256_w4a_kernel<EPI>), grid, dim3(256), lds, st, p);
+                }
+                return EA_OK;
             }
             ea_count(W8 ? "gemm_256_mi16_w8" : "gemm_256_mi16");
             hipLaunchKernelGGL((gemm256_mi16_kernel<EPI, W8>), grid, dim3(threads), lds, st, p);
@@ -1256,6 +1356,12 @@ int ea_gemm_tile_get() { return g_gemm_tile; }
 int ea_gemm_tile_set(int v) {
     if (v != 0 && v != 128 && v != 256) return -1;
     g_gemm_tile = v;
+    return 0;
+}
+int ea_gemm_w4a_get() { return g_gemm_w4a; }
+int ea_gemm_w4a_set(int v) {
+    if (v != 0 && v != 1) return -1;
+    g_gemm_w4a = v;
     return 0;
 }
 int ea_gemm_mfma_get() { return g_gemm_mfma; }

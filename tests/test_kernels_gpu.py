@@ -1112,3 +1112,81 @@ def test_feed_forward_kblocked_copy_observes_data_writes():
         _params.drop_tag("kblock")                  # ... until the next pipeline call drops it (pipeline.denoise / __call__)
         with _params.weights_frozen():
             assert torch.equal(ff(x), y0)
+
+
+# ---- round 5: the four-wave 256 x 256 kernel with the hand-placed main loop (gemm256_w4a_kernel) ----------------------------------------
+W4A_SHAPES = [
+    # B, M, N, K     nk = 1 / 2 / 3 (prologue-only, no in-loop request, first in-loop request), tails in M and N, batches, long K
+    (1, 256, 256, 64), (1, 256, 256, 128), (1, 512, 512, 192), (2, 700, 768, 3072), (1, 16500, 320, 320), (2, 1000, 3072, 1024),
+    (1, 2048, 12288, 256), (1, 1283, 3072, 12288),
+]
+
+
+@pytest.mark.parametrize("B,M,N,K", W4A_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_w4a_bit_identical_to_the_eight_wave_kernel(B, M, N, K, epi):
+    """ea_set_option("gemm_w4a", 1): same LDS image, same fragments, the same MFMAs accumulating the same k32 steps in the same
+    order per accumulator -> bit-identical to gemm256_mi16_kernel (which is pinned to fp64 by test_gemm_tile256); strided A
+    (row stride K + 8, batch gap), ragged last tiles, the gated-residual epilogue in place."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(41)
+    Abuf = _bf(torch.randn(B, M + 3, K + 8, generator=g)).to(DEV)
+    A = Abuf[:, 1:M + 1, :K]
+    W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = _bf(torch.randn(B, M, N, generator=g)).to(DEV)
+    gate = torch.randn(B, N, generator=g).to(DEV)
+    outs = []
+    _lib.set_option("gemm_tile", 256)
+    try:
+        for w4a in (0, 1, 1):
+            _lib.set_option("gemm_w4a", w4a)
+            _lib.reset_counters()
+            if epi == 2:
+                out = res.clone()
+                y = ops.gemm(A, W, bias, epi, out=out, res=out, gate=gate)
+            else:
+                y = ops.gemm(A, W, bias, epi)
+            torch.cuda.synchronize()
+            assert _lib.counters() == ({"gemm_256_w4a": 1} if w4a else {"gemm_256_mi16": 1}), _lib.counters()
+            outs.append(y.clone())
+    finally:
+        _lib.set_option("gemm_tile", 0)
+        _lib.set_option("gemm_w4a", 0)
+    assert torch.isfinite(outs[1].float()).all()
+    if not torch.equal(outs[1], outs[0]):
+        d = (outs[1].float() - outs[0].float()).abs()
+        bad = (d > 0).nonzero()
+        raise AssertionError(f"w4a differs from mi16: {bad.shape[0]} of {d.numel()} elements, max {d.max().item():.3e}, first {bad[:5].tolist()}, "
+                             f"last {bad[-3:].tolist()}; rows with a difference {bad[:, 1].unique()[:20].tolist()}; cols {bad[:, 2].unique()[:20].tolist()}")
+    assert torch.equal(outs[2], outs[1])          # repeated launches agree (race screen)
+
+
+@pytest.mark.parametrize("B,M,dim,inner", [(2, 70000, 512, 2048), (1, 66000 + 77, 1024, 1536)])
+def test_gemm_w4a_kblocked_pair_bit_identical(B, M, dim, inner):
+    """The K-blocked feed-forward pair (K-blocked C out of the first GEMM, K-blocked A / W into the second) through the four-wave
+    kernel: the buffer-addressed requests with their K step as the scalar offset."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(43)
+    x = _bf(torch.randn(B, M, dim, generator=g)).to(DEV)
+    w1 = _bf(torch.randn(inner, dim, generator=g) / math.sqrt(dim)).to(DEV)
+    w2 = _bf(torch.randn(dim, inner, generator=g) / math.sqrt(inner)).to(DEV)
+    b1, b2 = torch.randn(inner, generator=g).to(DEV), torch.randn(dim, generator=g).to(DEV)
+    res = _bf(torch.randn(B, M, dim, generator=g)).to(DEV)
+    gate = torch.randn(B, dim, generator=g).to(DEV)
+    w2b = ops.to_kblocked(w2)
+    outs = {}
+    try:
+        for w4a in (0, 1):
+            _lib.set_option("gemm_w4a", w4a)
+            _lib.reset_counters()
+            h = ops.gemm_kblocked(x, w1, b1, ops.EPI_BIAS_GELU_TANH, ops.LAYOUT_C)
+            y = ops.gemm_kblocked(h, w2b, b2, ops.EPI_BIAS_GATE_RES, ops.LAYOUT_A | ops.LAYOUT_W, res=res, gate=gate)
+            torch.cuda.synchronize()
+            assert _lib.counters() == ({"gemm_256_w4a": 2} if w4a else {"gemm_256_mi16": 2}), _lib.counters()
+            outs[w4a] = (h, y)
+    finally:
+        _lib.set_option("gemm_w4a", 0)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])

@@ -1,0 +1,254 @@
+"""Generates easyanimate_amd/csrc/ea_gemm_w4_loop.inc: the hand-placed main loop of gemm256_w4a_kernel (ea_gemm.hip) as ONE
+inline-asm block, plus the accumulator read-out statements.
+
+    python tools/gen_gemm_w4_asm.py            (rewrites the .inc; the build hashes it like every source file)
+
+Why generated: the loop is 128 MFMAs per K tile with exactly one other instruction between two MFMAs, on fixed registers
+(accumulators a0..a255, fragment double buffer v0..v127) -- placing ~330 lines by hand once per schedule experiment is what
+this script is for.  The SCHEDULE table below is the whole design; everything else is bookkeeping.
+
+Structure (one wave per SIMD, 128 x 128 wave tile = 8 x 8 MFMA tiles of 16x16x32, K tile = 2 k-steps of 64 MFMAs):
+  slot n = "in front of MFMA n" of the K tile.  k-step 0 (slots 0..63) computes on fragment buffer 0, k-step 1 on buffer 1.
+  W = weight operand, A = activation operand; stage s holds tile t, tile t+1 is landing in stage s^1, tile t+2 is requested
+  into stage s as soon as ALL waves have the corresponding operand of tile t in registers (one barrier per operand):
+     1..15   ds_read W k-step-1 fragments of tile t           -> buffer 1
+     20      lgkmcnt(0) + barrier: W(t) is in registers everywhere -> W region of stage s is free
+     23..59  8 x LDS-DMA W(t+2) -> stage s, interleaved with ds_read A k-step-1 fragments (25..43)
+     51      lgkmcnt(0) + barrier: A(t) is in registers everywhere -> A region of stage s is free
+     62..125 8 x LDS-DMA A(t+2) -> stage s
+     68      vmcnt(18) + barrier: W(t+1) has landed (own pieces by count, the others' by the barrier)
+     70..84  ds_read W k-step-0 fragments of tile t+1          -> buffer 0 (its last reader was MFMA 63)
+     105     vmcnt(15) + barrier: A(t+1) has landed
+     107..121 ds_read A k-step-0 fragments of tile t+1         -> buffer 0
+  No branch inside the tile: the requests of tiles >= nk go through a buffer resource with num_records = 0 (no traffic, the
+  vmcnt bookkeeping stays uniform)."""
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "easyanimate_amd", "csrc", "ea_gemm_w4_loop.inc")
+
+# fixed registers
+FW = [0, 64]      # first VGPR of W fragment buffer b (8 fragments x 4 registers)
+FA = [32, 96]     # first VGPR of A fragment buffer b
+V_WK0, V_WK1, V_AK0, V_AK1 = 128, 129, 130, 131   # LDS byte addresses of the fragment reads (current stage), toggled by xor 0x8000
+ADDR = {"wk0": V_WK0, "wk1": V_WK1, "ak0": V_AK0, "ak1": V_AK1}
+S_RA, S_RW = 80, 84              # buffer resources (4 SGPRs each)
+S_KA, S_KW = 88, 89              # scalar byte offset of the tile being requested
+S_MW, S_MA = 90, 91              # LDS byte address of this wave's first W / A piece in the stage being filled
+S_LEFT = 92                      # K tiles left, including the current one
+S_NRA, S_NRW = 93, 94            # real num_records
+S_KSTA, S_KSTW = 95, 96          # bytes to the next K tile
+
+
+def acc(i, j):
+    """First AGPR of accumulator tile (row block i, column block j)."""
+    return 4 * (j * 8 + i)
+
+
+def mfma(b, n):
+    j, i = n >> 3, n & 7
+    a = acc(i, j)
+    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], v[{FW[b] + 4 * j}:{FW[b] + 4 * j + 3}], v[{FA[b] + 4 * i}:{FA[b] + 4 * i + 3}], a[{a}:{a + 3}]"
+
+
+def rd(oper, b, x, addr):
+    base = (FW if oper == "w" else FA)[b] + 4 * x
+    off = f" offset:{x * 2048}" if x else ""
+    return f"ds_read_b128 v[{base}:{base + 3}], v{ADDR[addr]}{off}"
+
+
+def dma(oper, x):
+    rs, k = (S_RW, S_KW) if oper == "w" else (S_RA, S_KA)
+    return f"buffer_load_dwordx4 %[{oper}off{x}], s[{rs}:{rs + 3}], s{k} offen lds"
+
+
+def m0_first(oper):
+    return f"s_mov_b32 m0, s{S_MW if oper == 'w' else S_MA}"
+
+
+M0_NEXT = "s_add_u32 m0, m0, 0x400"
+
+
+def schedule():
+    """slot -> instructions placed in front of MFMA `slot` of the K tile."""
+    s = {n: [] for n in range(129)}
+    for x in range(8):                                   # W k-step 1 of tile t
+        s[1 + 2 * x].append(rd("w", 1, x, "wk1"))
+    s[17].append(f"v_xor_b32 v{ADDR['wk1']}, 0x8000, v{ADDR['wk1']}")     # -> the other stage, for the next tile
+    s[20] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    s[21].append(m0_first("w"))
+    w_slots = [23, 26, 29, 32, 35, 53, 56, 59]
+    for x, n in enumerate(w_slots):                       # W(t+2)
+        s[n].append(dma("w", x))
+        if x < 7:
+            s[n + 1].append(M0_NEXT)
+    a1_slots = [25, 28, 31, 34, 37, 39, 41, 43]
+    for x, n in enumerate(a1_slots):                      # A k-step 1 of tile t
+        s[n].append(rd("a", 1, x, "ak1"))
+    s[45].append(f"v_xor_b32 v{ADDR['ak1']}, 0x8000, v{ADDR['ak1']}")
+    s[47].append(f"v_xor_b32 v{ADDR['wk0']}, 0x8000, v{ADDR['wk0']}")
+    s[49].append(f"v_xor_b32 v{ADDR['ak0']}, 0x8000, v{ADDR['ak0']}")
+    s[51] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    s[60].append(m0_first("a"))
+    a_slots = [62, 65, 86, 88, 90, 97, 101, 125]
+    for x, n in enumerate(a_slots):                       # A(t+2)
+        s[n].append(dma("a", x))
+        if x < 7:
+            s[n + 1].append(M0_NEXT)
+    s[68] += ["s_waitcnt vmcnt(18)", "s_barrier"]
+    for x in range(8):                                    # W k-step 0 of tile t+1
+        s[70 + 2 * x].append(rd("w", 0, x, "wk0"))
+    s[105] += ["s_waitcnt vmcnt(15)", "s_barrier"]
+    for x in range(8):                                    # A k-step 0 of tile t+1
+        s[107 + 2 * x].append(rd("a", 0, x, "ak0"))
+    # scalar bookkeeping of the next tile, behind the last request
+    s[126] += [f"s_add_u32 s{S_KA}, s{S_KA}, s{S_KSTA}", f"s_add_u32 s{S_KW}, s{S_KW}, s{S_KSTW}"]
+    s[127] += [f"s_xor_b32 s{S_MW}, s{S_MW}, 0x8000", f"s_xor_b32 s{S_MA}, s{S_MA}, 0x8000", f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1"]
+    return s
+
+
+def check(s):
+    """The counts the waits rely on."""
+    order = []
+    for n in range(129):
+        for ins in s[n]:
+            order.append((n, ins))
+    dmas = [(n, i) for n, i in order if i.startswith("buffer_load")]
+    assert len(dmas) == 16 and all("woff" in i for _, i in dmas[:8]) and all("aoff" in i for _, i in dmas[8:])
+    before68 = sum(1 for n, _ in dmas if n < 68)
+    before105 = sum(1 for n, _ in dmas if n < 105)
+    assert before68 == 10 and before105 == 15, (before68, before105)     # vmcnt(8 + 10) / vmcnt(15)
+    reads = [(n, i) for n, i in order if i.startswith("ds_read")]
+    assert len(reads) == 32
+    # a register written by a read must not be read by an MFMA that is still to come in the same role
+    for n, i in reads:
+        b = 1 if (f"v{V_WK1}" in i.split("],")[1] or f"v{V_AK1}" in i.split("],")[1]) else 0
+        first_use, last_use_prev = (64, 128) if b == 1 else (128, 64)   # buffer 0 is next used by the NEXT tile's MFMA 0
+        if b == 1:
+            assert n < 64
+        else:
+            assert n >= 64
+    # m0 is written at least one instruction before each DMA and never between the DMA and its own m0
+    return True
+
+
+def emit():
+    s = schedule()
+    check(s)
+    L = []
+    A = L.append
+    A("// GENERATED by tools/gen_gemm_w4_asm.py -- do not edit; see that file for the schedule.")
+    A("#define EA_W4A_MAINLOOP_ASM \\")
+    body = []
+    B = body.append
+    # ---- prologue: resources, tile 0 and tile 1 requests, accumulators := 0, first fragments
+    B(f"s_mov_b32 s{S_RA}, %[a_lo]")
+    B(f"s_mov_b32 s{S_RA + 1}, %[a_hi]")
+    B(f"s_mov_b32 s{S_RA + 2}, %[a_ext]")
+    B(f"s_mov_b32 s{S_RA + 3}, 0x00020000")
+    B(f"s_mov_b32 s{S_RW}, %[w_lo]")
+    B(f"s_mov_b32 s{S_RW + 1}, %[w_hi]")
+    B(f"s_mov_b32 s{S_RW + 2}, %[w_ext]")
+    B(f"s_mov_b32 s{S_RW + 3}, 0x00020000")
+    B(f"s_mov_b32 s{S_NRA}, %[a_ext]")
+    B(f"s_mov_b32 s{S_NRW}, %[w_ext]")
+    B(f"s_mov_b32 s{S_KSTA}, %[a_kst]")
+    B(f"s_mov_b32 s{S_KSTW}, %[w_kst]")
+    B(f"s_mov_b32 s{S_LEFT}, %[nk]")
+    B(f"s_mov_b32 s{S_MW}, %[lds_w]")
+    B(f"s_mov_b32 s{S_MA}, %[lds_a]")
+    B(f"s_mov_b32 s{S_KA}, 0")
+    B(f"s_mov_b32 s{S_KW}, 0")
+    B(f"v_mov_b32 v{V_WK0}, %[wk0]")
+    B(f"v_mov_b32 v{V_AK0}, %[ak0]")
+    B(f"v_xor_b32 v{V_WK1}, 64, v{V_WK0}")        # k-step 1 = 16-byte chunk index + 4 under the XOR swizzle
+    B(f"v_xor_b32 v{V_AK1}, 64, v{V_AK0}")
+    # tile 0 -> stage 0
+    B(m0_first("w"))
+    for x in range(8):
+        B("s_nop 0")
+        B(dma("w", x))
+        if x < 7:
+            B(M0_NEXT)
+    B(m0_first("a"))
+    for x in range(8):
+        B("s_nop 0")
+        B(dma("a", x))
+        if x < 7:
+            B(M0_NEXT)
+    # tile 1 -> stage 1 (nk == 1: through an empty resource)
+    B(f"s_cmp_gt_u32 s{S_LEFT}, 1")
+    B(f"s_cselect_b32 s{S_RA + 2}, s{S_NRA}, 0")
+    B(f"s_cselect_b32 s{S_RW + 2}, s{S_NRW}, 0")
+    B(f"s_mov_b32 s{S_KA}, s{S_KSTA}")
+    B(f"s_mov_b32 s{S_KW}, s{S_KSTW}")
+    B(f"s_xor_b32 s{S_MW}, s{S_MW}, 0x8000")
+    B(f"s_xor_b32 s{S_MA}, s{S_MA}, 0x8000")
+    B(m0_first("w"))
+    for x in range(8):
+        B("s_nop 0")
+        B(dma("w", x))
+        if x < 7:
+            B(M0_NEXT)
+    B(m0_first("a"))
+    for x in range(8):
+        B("s_nop 0")
+        B(dma("a", x))
+        if x < 7:
+            B(M0_NEXT)
+    B(f"s_xor_b32 s{S_MW}, s{S_MW}, 0x8000")          # the loop's first requests (tile 2) go to stage 0 again
+    B(f"s_xor_b32 s{S_MA}, s{S_MA}, 0x8000")
+    B(f"s_add_u32 s{S_KA}, s{S_KA}, s{S_KSTA}")
+    B(f"s_add_u32 s{S_KW}, s{S_KW}, s{S_KSTW}")
+    for r in range(256):                               # accumulators := 0 while tile 0 is on its way
+        B(f"v_accvgpr_write_b32 a{r}, 0")
+    B("s_waitcnt vmcnt(16)")                           # tile 0 (this wave's pieces) has landed; tile 1 stays in flight
+    B("s_barrier")
+    for x in range(8):
+        B(rd("w", 0, x, "wk0"))
+    for x in range(8):
+        B(rd("a", 0, x, "ak0"))
+    # ---- the K loop
+    B("1:")
+    B(f"s_cmp_gt_u32 s{S_LEFT}, 2")                    # tile t + 2 exists?
+    B(f"s_cselect_b32 s{S_RA + 2}, s{S_NRA}, 0")
+    B(f"s_cselect_b32 s{S_RW + 2}, s{S_NRW}, 0")
+    B("s_waitcnt lgkmcnt(0)")                          # buffer 0 = k-step 0 of this tile
+    for n in range(128):
+        for ins in s[n]:
+            B(ins)
+        B(mfma(0 if n < 64 else 1, n & 63))
+    for ins in s[128]:
+        B(ins)
+    B(f"s_cmp_lg_u32 s{S_LEFT}, 0")
+    B("s_cbranch_scc1 1b")
+    # ---- everything this wave requested has landed (the empty requests of the last two tiles too), the last MFMAs have left the pipe
+    B("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    B("s_nop 15")
+    B("s_nop 15")
+    for ins in body:
+        A(f'    "{ins}\\n\\t" \\')
+    L[-1] = L[-1][:-2]      # no continuation behind the last line
+    A("")
+    clob = [f'"v{r}"' for r in range(132)] + [f'"a{r}"' for r in range(256)] + [f'"s{r}"' for r in range(80, 97)] + ['"m0"', '"scc"', '"memory"']
+    A("#define EA_W4A_CLOBBERS \\")
+    for k in range(0, len(clob), 16):
+        A("    " + ", ".join(clob[k:k + 16]) + (", \\" if k + 16 < len(clob) else ""))
+    A("")
+    # ---- accumulator read-out: column half h (j = 4h .. 4h + 3) into f32x4_t dst[8][4]
+    for h in range(2):
+        A(f"#define EA_W4A_READ_HALF{h}(dst) \\")
+        lines = []
+        for jj in range(4):
+            for i in range(8):
+                a = acc(i, 4 * h + jj)
+                for e in range(4):
+                    lines.append(f'    asm volatile("v_accvgpr_read_b32 %0, a{a + e}" : "=v"(dst[{i}][{jj}][{e}]));')
+        for k, ln in enumerate(lines):
+            A(ln + (" \\" if k + 1 < len(lines) else ""))
+        A("")
+    open(OUT, "w").write("\n".join(L))
+    print(OUT, len(body), "asm lines")
+
+
+if __name__ == "__main__":
+    emit()
