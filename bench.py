@@ -339,8 +339,10 @@ def main():
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "attention_hbm_bytes_per_launch.json")
     if os.path.exists(pmc) and world == 1 and args.config == "c3":
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        try:   # HBM bytes per attention launch from the PMC passes -- only if they were taken on THIS build (tools/update_traffic_json.py)
+            rec = json.load(open(pmc))
+            sha = open(os.path.join(ROOT, "easyanimate_amd", "lib", "build.sha256")).read().strip()
+            traffic = rec.get("hbm_bytes_per_launch") if rec.get("build_sha256") == sha else None
         except Exception:
             traffic = None
 

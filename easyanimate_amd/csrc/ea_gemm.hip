@@ -1136,6 +1136,215 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
 }
 
 int g_gemm_w4a = 0;     // ea_set_option("gemm_w4a", 0 | 1): the four-wave kernel with the hand-placed main loop instead of gemm256_mi16_kernel
+// ---- the fused QKV projection on the four-wave hand-placed main loop (gemm256_w4a_kernel's; EA_W4A_MAINLOOP_ASM_SWAP for the V tiles).
+// A wave tile is 128 tokens x 128 features = TWO heads: the epilogues below are gemm256_qkv_kernel's, per head (same roundings at the
+// same points: bit-identical to that kernel), called once per accumulator half.
+__device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[8][4], char* const img, const float* biasb, const int feat0,
+                                               const int tok0, const int64_t bh, const int Mv, const int lane) {
+    const int lr = lane & 15, lq = lane >> 4;
+    // lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = j * 16 + lr;
+        const float bv = biasb ? biasb[feat0 + n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(acc[i][j][e] + bv);
+            const int ch = i * 2 + (lq >> 1);
+            *reinterpret_cast<u16x4*>(img + n * 256 + ((ch ^ (n & 15)) << 4) + (lq & 1) * 8) = o;
+        }
+    }
+    const int r4 = lane >> 4, c16 = lane & 15;
+    unsigned short* dst = q.vt_out + (bh * 64) * (int64_t)q.kv_rows + q.kv_off + tok0 + c16 * 8;
+    const int nv = Mv - (tok0 + c16 * 8);       // valid tokens among this lane's eight (ragged last M tile: < 8)
+    if (nv >= 8) {
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const int n = qq * 4 + r4;
+            const u16x8 o = *reinterpret_cast<const u16x8*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
+            *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.kv_rows) = o;
+        }
+    } else if (nv > 0) {   // the one straddling group of a row: element stores, nothing past column kv_off + M is written
+        for (int qq = 0; qq < 16; ++qq) {
+            const int n = qq * 4 + r4;
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
+            for (int e = 0; e < nv; ++e) dst[(int64_t)n * q.kv_rows + e] = src[e];
+        }
+    }
+}
+
+__device__ __forceinline__ void qkv_epilogue_qk(const QkvArgs& q, f32x4_t (&acc)[8][4], char* const img, const float* biasb, const int feat0,
+                                                const int tok0, const int64_t bh, const int which, const int Mv, const int lane_e) {
+    const int lr_e = lane_e & 15, lq_e = lane_e >> 4;
+    // lane_e holds features j*16 + lq_e*4 + 0..3 of token i*16 + lr_e
+    const float* gw = q.nw[which];
+    const float* gb = q.nb[which];
+    f32x4_t bias4[4], gw4[4], gb4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = j * 16 + lq_e * 4;
+        f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        bias4[j] = biasb ? *reinterpret_cast<const f32x4_t*>(biasb + feat0 + n) : z;
+        gw4[j] = *reinterpret_cast<const f32x4_t*>(gw + n);
+        gb4[j] = *reinterpret_cast<const f32x4_t*>(gb + n);
+    }
+    const float osc = which == 0 ? q.q_scale : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + lr_e;
+        f32x4_t c4[4], s4[4];
+        if (q.cosT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t tr = (int64_t)(tok0 + r < Mv ? tok0 + r : Mv - 1) * 64 + j * 16 + lq_e * 4;
+                c4[j] = *reinterpret_cast<const f32x4_t*>(q.cosT + tr);
+                s4[j] = *reinterpret_cast<const f32x4_t*>(q.sinT + tr);
+            }
+        }
+        float v[4][4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] = bf16_bits_to_f32(f32_to_bf16_bits(acc[i][j][e] + bias4[j][e]));   // the stored QKV value
+                s += v[j][e];
+            }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / 64.0f);
+        float qd = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[j][e] - mean;
+                qd += d * d;
+            }
+        qd += __shfl_xor(qd, 16, 64);
+        qd += __shfl_xor(qd, 32, 64);
+        const float rstd = rsqrtf(qd * (1.0f / 64.0f) + q.eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[j][e] = bf16_bits_to_f32(f32_to_bf16_bits((v[j][e] - mean) * rstd * gw4[j][e] + gb4[j][e]));
+            u16x4 o;
+            if (q.cosT) {
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float x0 = v[j][e], x1 = v[j][e + 1];
+                    o[e] = f32_to_bf16_bits((x0 * c4[j][e] - x1 * s4[j][e]) * osc);
+                    o[e + 1] = f32_to_bf16_bits((x1 * c4[j][e + 1] + x0 * s4[j][e + 1]) * osc);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[j][e] * osc);
+            }
+            const int ch = j * 2 + (lq_e >> 1);
+            *reinterpret_cast<u16x4*>(img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq_e & 1) * 8) = o;
+        }
+    }
+    const int r8 = lane_e >> 3, c8 = lane_e & 7;
+    unsigned short* dst = (which ? q.k_out + (bh * q.kv_rows + q.kv_off + tok0) * 64
+                                 : q.q_out + (bh * q.s_pad + q.seq_off + tok0) * 64) + c8 * 8;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+        const int r = qq * 8 + r8;
+        const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
+        if (tok0 + r < Mv) *reinterpret_cast<u16x8*>(dst + (int64_t)r * 64) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm256_qkv_w4a_kernel(QkvArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm, tn;
+    {
+        GemmArgs g;
+        g.tiles_m = q.tiles_m; g.tiles_n = q.tiles_n; g.rows_per_xcd = q.rows_per_xcd;
+        if (!tile_of_block(g, tm, tn)) return;
+    }
+    const int b = blockIdx.y;
+    const int row0 = tm * 256;
+    const int tiles_per_w = q.inner >> 8;
+    const int part = __builtin_amdgcn_readfirstlane(tn / tiles_per_w);
+    const int which = q.first_part + part;                                 // 0 = q, 1 = k, 2 = v
+    const int col0 = (tn - part * tiles_per_w) * 256;                      // first output feature inside that weight
+    const unsigned short* Ab = q.A + b * q.abs_;
+    const unsigned short* Wb = which == 0 ? q.W[0] : (which == 1 ? q.W[1] : q.W[2]);
+    const float* biasb = which == 0 ? q.bias[0] : (which == 1 ? q.bias[1] : q.bias[2]);
+    const int nk = q.K / BK;
+
+    int aoff[8], woff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ (r & 7);
+        const int ra = (row0 + r < q.M ? row0 + r : q.M - 1) - row0;       // ragged last M tile: rows past M re-read row M - 1
+        aoff[i] = (int)((int64_t)ra * q.lda * 2) + cs * 16;
+        woff[i] = r * q.K * 2 + cs * 16;
+    }
+    const unsigned short* Abase = Ab + (int64_t)row0 * q.lda;
+    const unsigned short* Wbase = Wb + (int64_t)col0 * q.K;
+    const int a_rows = q.M - row0 < 256 ? q.M - row0 : 256;
+    const unsigned a_ext = (unsigned)((((int64_t)a_rows - 1) * q.lda + q.K) * 2);
+    const unsigned w_ext = (unsigned)((int64_t)256 * q.K * 2);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ak0 = lds0 + (wr * 128 + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+    const unsigned wk0 = lds0 + 2 * OPER2 + (wc * 128 + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+    const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + 2 * OPER2 + wave * 8192);
+    const unsigned a_lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Abase);
+    const unsigned a_hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)Abase >> 32));
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Wbase);
+    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)Wbase >> 32));
+    const unsigned kst = BK * 2;
+    const unsigned a_ext_s = __builtin_amdgcn_readfirstlane(a_ext), w_ext_s = __builtin_amdgcn_readfirstlane(w_ext);
+    const unsigned nk_s = __builtin_amdgcn_readfirstlane((unsigned)nk);
+#define EA_W4A_OPERANDS                                                                                                         \
+    [wk0] "v"(wk0), [ak0] "v"(ak0), [aoff0] "v"(aoff[0]), [aoff1] "v"(aoff[1]), [aoff2] "v"(aoff[2]), [aoff3] "v"(aoff[3]),       \
+        [aoff4] "v"(aoff[4]), [aoff5] "v"(aoff[5]), [aoff6] "v"(aoff[6]), [aoff7] "v"(aoff[7]), [woff0] "v"(woff[0]),              \
+        [woff1] "v"(woff[1]), [woff2] "v"(woff[2]), [woff3] "v"(woff[3]), [woff4] "v"(woff[4]), [woff5] "v"(woff[5]),              \
+        [woff6] "v"(woff[6]), [woff7] "v"(woff[7]), [a_lo] "s"(a_lo), [a_hi] "s"(a_hi), [a_ext] "s"(a_ext_s), [w_lo] "s"(w_lo),    \
+        [w_hi] "s"(w_hi), [w_ext] "s"(w_ext_s), [a_kst] "s"(kst), [w_kst] "s"(kst), [nk] "s"(nk_s), [lds_w] "s"(lds_w),            \
+        [lds_a] "s"(lds_a)
+    if (which == 2) {
+        asm volatile(EA_W4A_MAINLOOP_ASM_SWAP : : EA_W4A_OPERANDS : EA_W4A_CLOBBERS);
+    } else {
+        asm volatile(EA_W4A_MAINLOOP_ASM : : EA_W4A_OPERANDS : EA_W4A_CLOBBERS);
+    }
+#undef EA_W4A_OPERANDS
+    __builtin_amdgcn_s_barrier();
+
+    char* const img = smem + wave * 16384;
+    const int tok0 = row0 + wr * 128;                 // first token (row of A) of this wave tile
+    const int head0 = (col0 >> 6) + wc * 2;           // the wave tile's two heads
+    int Mv = q.M;
+    asm volatile("" : "+s"(Mv));
+    int lane_e;                                       // the lane id again: no lane-derived value has to stay live across the main loop
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    f32x4_t acc[8][4];
+    if (which == 2) {
+        EA_W4A_READ_HALF0(acc)
+        qkv_epilogue_v(q, acc, img, biasb, head0 * 64, tok0, (int64_t)b * q.heads + head0, Mv, lane_e);
+        EA_W4A_READ_HALF1(acc)
+        qkv_epilogue_v(q, acc, img, biasb, head0 * 64 + 64, tok0, (int64_t)b * q.heads + head0 + 1, Mv, lane_e);
+    } else {
+        EA_W4A_READ_HALF0(acc)
+        qkv_epilogue_qk(q, acc, img, biasb, head0 * 64, tok0, (int64_t)b * q.heads + head0, which, Mv, lane_e);
+        EA_W4A_READ_HALF1(acc)
+        qkv_epilogue_qk(q, acc, img, biasb, head0 * 64 + 64, tok0, (int64_t)b * q.heads + head0 + 1, which, Mv, lane_e);
+    }
+}
+
 int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of the 256^2 kernel (32: the first version, kept as cross-check)
 
 template <int EPI, bool W8>
@@ -1319,6 +1528,17 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
     }
     ea_count(W8 ? "gemm_qkv_fused_w8" : "gemm_qkv_fused");
     if (parts != 7) ea_count(parts == 6 ? "gemm_qkv_fused_kv_part" : "gemm_qkv_fused_q_part");
+    // the four-wave hand-placed main loop (32-bit buffer offsets: a 256-row tile of A / W must be reachable within 4 GiB)
+    if (!W8 && g_gemm_w4a && (255 * lda + K) * 2 < (int64_t)0xFFFFFFFF && (int64_t)256 * K * 2 < (int64_t)0xFFFFFFFF) {
+        static bool attrw4_done = false;
+        if (!attrw4_done) {
+            hipFuncSetAttribute((const void*)gemm256_qkv_w4a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
+            attrw4_done = true;
+        }
+        ea_count("gemm_qkv_fused_w4a");
+        hipLaunchKernelGGL(gemm256_qkv_w4a_kernel, grid, dim3(256), GEMM2_LDS, (hipStream_t)stream, q);
+        return ea_check_launch("ea_qkv_gemm_norm_rope_bf16");
+    }
     hipLaunchKernelGGL(gemm256_qkv_kernel<W8>, grid, dim3(512), GEMM2_LDS, (hipStream_t)stream, q);
     return ea_check_launch(W8 ? "ea_qkv_gemm_norm_rope_bf16_w8" : "ea_qkv_gemm_norm_rope_bf16");
 }

@@ -3,7 +3,10 @@ state-dict name, so the product model, the oracle restatement and the shim-hoste
 bit-identical values independent of construction order (SURVEY.md 8d "value distributions / seeds")."""
 from __future__ import annotations
 
+import concurrent.futures as cf
+import contextlib
 import math
+import os
 import zlib
 from typing import Dict, Iterable, Tuple
 
@@ -45,15 +48,51 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, style: str = 
     return w
 
 
+_POOL = None
+
+
+def _pool() -> cf.ThreadPoolExecutor:
+    """Every tensor has its own generator (keyed by name), so tensors can be generated concurrently with identical results;
+    torch.rand / randn release the GIL.  (A 7B state dict: 35 s on one core, a few seconds on eight.)"""
+    global _POOL
+    if _POOL is None:
+        _POOL = cf.ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1)))
+    return _POOL
+
+
 def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, style: str = "default") -> Dict[str, torch.Tensor]:
-    return {k: synth_tensor(k, tuple(v), seed, style) for k, v in shapes.items()}
+    keys = list(shapes)
+    vals = list(_pool().map(lambda k: synth_tensor(k, tuple(shapes[k]), seed, style), keys))
+    return dict(zip(keys, vals))
 
 
 @torch.no_grad()
 def fill_module_(module: torch.nn.Module, seed: int = 0, style: str = "default", chunk_device=None) -> None:
-    """In-place synthetic init of every parameter/buffer of `module` (on whatever device it lives)."""
-    for name, p in list(module.named_parameters()) + list(module.named_buffers()):
-        if not p.dtype.is_floating_point:
-            continue
-        t = synth_tensor(name, tuple(p.shape), seed, style)
+    """In-place synthetic init of every parameter/buffer of `module` (on whatever device it lives); generation runs a few tensors
+    ahead of the copies in a thread pool, at most 16 tensors in flight."""
+    items = [(n, p) for n, p in list(module.named_parameters()) + list(module.named_buffers()) if p.dtype.is_floating_point]
+    window = 16
+    futs = {}
+    for i in range(min(window, len(items))):
+        futs[i] = _pool().submit(synth_tensor, items[i][0], tuple(items[i][1].shape), seed, style)
+    for i, (name, p) in enumerate(items):
+        t = futs.pop(i).result()
+        if i + window < len(items):
+            n2, p2 = items[i + window]
+            futs[i + window] = _pool().submit(synth_tensor, n2, tuple(p2.shape), seed, style)
         p.copy_(t.to(device=p.device, dtype=p.dtype))
+
+
+@contextlib.contextmanager
+def skip_init():
+    """Construct nn.Linear / Conv / LayerNorm modules WITHOUT their default random initialisation (the synthetic fill overwrites
+    every value anyway): `with skip_init(): m = Model.from_config(cfg)` -- seconds instead of half a minute at 7B."""
+    saved = {}
+    for cls in (torch.nn.Linear, torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.LayerNorm, torch.nn.GroupNorm, torch.nn.Embedding):
+        saved[cls] = cls.reset_parameters
+        cls.reset_parameters = lambda self: None
+    try:
+        yield
+    finally:
+        for cls, fn in saved.items():
+            cls.reset_parameters = fn

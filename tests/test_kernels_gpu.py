@@ -1100,6 +1100,7 @@ def test_feed_forward_kblocked_copy_observes_data_writes():
         _lib.reset_counters()
         y0 = ff(x)
         assert _lib.counters() == {"gemm_256_mi16": 2}, _lib.counters()       # the K-blocked pair is the path under test
+        w_orig = ff.net[2].weight.data.clone()
         ff.net[2].weight.data += delta
         y1 = ff(x)
         ref = attention.FeedForward(512, activation_fn="gelu-approximate", final_dropout=True).to(torch.bfloat16).to(DEV).eval()
@@ -1107,7 +1108,7 @@ def test_feed_forward_kblocked_copy_observes_data_writes():
         y_ref = ref(x)
         assert torch.equal(y1, y_ref) and not torch.equal(y1, y0)
         with _params.weights_frozen():
-            ff.net[2].weight.data -= delta          # a write the frozen region promises not to do: the copy is NOT refreshed ...
+            ff.net[2].weight.data.copy_(w_orig)     # a write the frozen region promises not to do: the copy is NOT refreshed ...
             assert torch.equal(ff(x), y1)
         _params.drop_tag("kblock")                  # ... until the next pipeline call drops it (pipeline.denoise / __call__)
         with _params.weights_frozen():
@@ -1190,3 +1191,56 @@ def test_gemm_w4a_kblocked_pair_bit_identical(B, M, dim, inner):
     finally:
         _lib.set_option("gemm_w4a", 0)
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+
+
+@pytest.mark.parametrize("B,H,M,K,seq_off,use_rope", [(2, 4, 512, 128, 8, True), (1, 4, 256, 64, 0, False), (2, 48, 768, 3072, 256, True),
+                                                      (1, 48, 2016, 3072, 256, True), (2, 8, 1283, 256, 64, True), (1, 4, 13104, 256, 64, True)])
+def test_qkv_fused_w4a_bit_identical_to_the_eight_wave_kernel(B, H, M, K, seq_off, use_rope):
+    """gemm256_qkv_w4a_kernel (four waves, hand-placed main loop, two heads per wave tile, V tiles on the operand-swapped loop)
+    against gemm256_qkv_kernel: the same MFMAs on the same fragments and the same epilogue code per head -> q, k and V^T
+    bit-identical, including ragged last tiles (M = 1283 / 13104 / 2016), K | V written into an exchange slot of another geometry
+    (kv_off / kv_rows) and the split launch (K | V thirds, then the Q third); nothing outside the addressed rows is written."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(29)
+    d = H * 64
+    x = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+    ws = [_bf(torch.randn(d, K, generator=g) / K ** 0.5).to(DEV) for _ in range(3)]
+    bs = [(0.3 * torch.randn(d, generator=g)).to(DEV) for _ in range(3)]
+    nq_w, nk_w = [(1 + 0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    nq_b, nk_b = [(0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(2)]
+    ang = torch.rand(M, 32, generator=g) * 6.28
+    cos = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV) if use_rope else None
+    sin = ang.sin().repeat_interleave(2, 1).contiguous().to(DEV) if use_rope else None
+    kv_off = seq_off + 64
+    s_pad, kv_rows = ops.round_up(seq_off + M, 256), ops.round_up(kv_off + M + 64, 256)
+    full = lambda *shape: torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
+    outs = {}
+    try:
+        for w4a in (0, 1):
+            _lib.set_option("gemm_w4a", w4a)
+            res = []
+            for split in (False, True):
+                q, k, vt = full(B, H, s_pad, 64), full(B, H, kv_rows, 64), full(B, H, 64, kv_rows)
+                _lib.reset_counters()
+                for parts in ((ops.QKV_KV, ops.QKV_Q) if split else (None,)):
+                    kw = {} if parts is None else {"parts": parts}
+                    ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q, k, vt, nq_w, nq_b, nk_w, nk_b, cos, sin, seq_off, 1e-6,
+                                           q_scale=ops.FOLDED_Q_SCALE, kv_off=kv_off, **kw)
+                torch.cuda.synchronize()
+                c = _lib.counters()
+                assert c.get("gemm_qkv_fused_w4a", 0) == ((2 if split else 1) if w4a else 0), c
+                res.append((q, k, vt))
+            assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))      # split launch == single launch
+            outs[w4a] = res[0]
+    finally:
+        _lib.set_option("gemm_w4a", 0)
+    for name, a, b in zip("q k vt".split(), outs[1], outs[0]):
+        if not torch.equal(a, b):
+            dd = (a.float() - b.float()).abs()
+            bad = (dd > 0).nonzero()
+            raise AssertionError(f"{name}: {bad.shape[0]} of {dd.numel()} elements differ, max {dd.max().item():.3e}, first {bad[:5].tolist()}")
+    q, k, vt = outs[1]
+    assert torch.isfinite(q[:, :, seq_off:seq_off + M].float()).all()
+    assert (q[:, :, :seq_off] == 7).all() and (q[:, :, seq_off + M:] == 7).all()
+    assert (k[:, :, :kv_off] == 7).all() and (k[:, :, kv_off + M:] == 7).all() and (vt[:, :, :, :kv_off] == 7).all() and (vt[:, :, :, kv_off + M:] == 7).all()

@@ -36,3 +36,35 @@ for what, B, M, N, K, epi in SHAPES:
             print(json.dumps({"what": what, "kernel": name, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}), flush=True)
     _lib.set_option("gemm_w4a", 0)
     del x, w, y, res
+
+# ---- the fused QKV projection (config-3 video stream, one rank of four, config 2)
+for what, B, M in (("fused QKV c3 video", 2, 53248), ("fused QKV one rank of 4", 1, 13312), ("fused QKV c2 video", 2, 13312)):
+    H, K = 48, 3072
+    dd = H * 64
+    x = torch.randn(B, M, K, device="cuda").to(torch.bfloat16)
+    ws = [(torch.randn(dd, K, device="cuda") / math.sqrt(K)).to(torch.bfloat16) for _ in range(3)]
+    bs = [torch.randn(dd, device="cuda") * 0.1 for _ in range(3)]
+    n1 = [torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")]
+    ang = torch.rand(M, 32, device="cuda") * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous()
+    s_pad = ops.round_up(256 + M, 256)
+    q = torch.zeros(B, H, s_pad, 64, dtype=torch.bfloat16, device="cuda")
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device="cuda")
+    fn = lambda: ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q, k, vt, n1[0], n1[1], n1[2], n1[3], cos, sin, 256, 1e-6,
+                                        q_scale=ops.FOLDED_Q_SCALE)
+    outs = {}
+    for v in (0, 1):
+        _lib.set_option("gemm_w4a", v)
+        fn()
+        torch.cuda.synchronize()
+        outs[v] = (q.clone(), k.clone(), vt.clone())
+    print(json.dumps({"what": what, "bit_identical": bool(all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])))}), flush=True)
+    fl = 2.0 * B * M * 3 * dd * K
+    for rep in range(reps):
+        for v, name in ((0, "eight-wave (product)"), (1, "four-wave hand-placed")):
+            _lib.set_option("gemm_w4a", v)
+            ms = timeit(fn, warm=2, iters=7)
+            print(json.dumps({"what": what, "kernel": name, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}), flush=True)
+    _lib.set_option("gemm_w4a", 0)
+    del x, ws, q, k, vt

@@ -44,10 +44,14 @@ def acc(i, j):
     return 4 * (j * 8 + i)
 
 
-def mfma(b, n):
+def mfma(b, n, swap=False):
+    """swap = False: the weight fragment is the MFMA's A operand (C^T orientation: a lane ends with 4 consecutive output columns of
+    one row); swap = True: the activation fragment is (a lane ends with 4 consecutive ROWS of one column -- the V^T tiles of the
+    fused QKV kernel)."""
     j, i = n >> 3, n & 7
     a = acc(i, j)
-    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], v[{FW[b] + 4 * j}:{FW[b] + 4 * j + 3}], v[{FA[b] + 4 * i}:{FA[b] + 4 * i + 3}], a[{a}:{a + 3}]"
+    w, x = f"v[{FW[b] + 4 * j}:{FW[b] + 4 * j + 3}]", f"v[{FA[b] + 4 * i}:{FA[b] + 4 * i + 3}]"
+    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {x}, {w}, a[{a}:{a + 3}]" if swap else f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {w}, {x}, a[{a}:{a + 3}]"
 
 
 def rd(oper, b, x, addr):
@@ -131,13 +135,8 @@ def check(s):
     return True
 
 
-def emit():
-    s = schedule()
-    check(s)
-    L = []
-    A = L.append
-    A("// GENERATED by tools/gen_gemm_w4_asm.py -- do not edit; see that file for the schedule.")
-    A("#define EA_W4A_MAINLOOP_ASM \\")
+def loop_body(s, swap):
+    """The whole asm block (prologue, K loop, drain) as a list of instructions."""
     body = []
     B = body.append
     # ---- prologue: resources, tile 0 and tile 1 requests, accumulators := 0, first fragments
@@ -162,19 +161,16 @@ def emit():
     B(f"v_mov_b32 v{V_AK0}, %[ak0]")
     B(f"v_xor_b32 v{V_WK1}, 64, v{V_WK0}")        # k-step 1 = 16-byte chunk index + 4 under the XOR swizzle
     B(f"v_xor_b32 v{V_AK1}, 64, v{V_AK0}")
-    # tile 0 -> stage 0
-    B(m0_first("w"))
-    for x in range(8):
-        B("s_nop 0")
-        B(dma("w", x))
-        if x < 7:
-            B(M0_NEXT)
-    B(m0_first("a"))
-    for x in range(8):
-        B("s_nop 0")
-        B(dma("a", x))
-        if x < 7:
-            B(M0_NEXT)
+
+    def request_tile():
+        for oper in ("w", "a"):
+            B(m0_first(oper))
+            for x in range(8):
+                B("s_nop 0")
+                B(dma(oper, x))
+                if x < 7:
+                    B(M0_NEXT)
+    request_tile()                                     # tile 0 -> stage 0
     # tile 1 -> stage 1 (nk == 1: through an empty resource)
     B(f"s_cmp_gt_u32 s{S_LEFT}, 1")
     B(f"s_cselect_b32 s{S_RA + 2}, s{S_NRA}, 0")
@@ -183,18 +179,7 @@ def emit():
     B(f"s_mov_b32 s{S_KW}, s{S_KSTW}")
     B(f"s_xor_b32 s{S_MW}, s{S_MW}, 0x8000")
     B(f"s_xor_b32 s{S_MA}, s{S_MA}, 0x8000")
-    B(m0_first("w"))
-    for x in range(8):
-        B("s_nop 0")
-        B(dma("w", x))
-        if x < 7:
-            B(M0_NEXT)
-    B(m0_first("a"))
-    for x in range(8):
-        B("s_nop 0")
-        B(dma("a", x))
-        if x < 7:
-            B(M0_NEXT)
+    request_tile()
     B(f"s_xor_b32 s{S_MW}, s{S_MW}, 0x8000")          # the loop's first requests (tile 2) go to stage 0 again
     B(f"s_xor_b32 s{S_MA}, s{S_MA}, 0x8000")
     B(f"s_add_u32 s{S_KA}, s{S_KA}, s{S_KSTA}")
@@ -216,7 +201,7 @@ def emit():
     for n in range(128):
         for ins in s[n]:
             B(ins)
-        B(mfma(0 if n < 64 else 1, n & 63))
+        B(mfma(0 if n < 64 else 1, n & 63, swap))
     for ins in s[128]:
         B(ins)
     B(f"s_cmp_lg_u32 s{S_LEFT}, 0")
@@ -225,10 +210,24 @@ def emit():
     B("s_waitcnt vmcnt(0) lgkmcnt(0)")
     B("s_nop 15")
     B("s_nop 15")
-    for ins in body:
-        A(f'    "{ins}\\n\\t" \\')
-    L[-1] = L[-1][:-2]      # no continuation behind the last line
-    A("")
+    return body
+
+
+def emit():
+    s = schedule()
+    check(s)
+    L = []
+    A = L.append
+    A("// GENERATED by tools/gen_gemm_w4_asm.py -- do not edit; see that file for the schedule.")
+    n_lines = 0
+    for swap in (False, True):
+        A("#define EA_W4A_MAINLOOP_ASM_SWAP \\" if swap else "#define EA_W4A_MAINLOOP_ASM \\")
+        body = loop_body(s, swap)
+        n_lines = len(body)
+        for ins in body:
+            A(f'    "{ins}\\n\\t" \\')
+        L[-1] = L[-1][:-2]      # no continuation behind the last line
+        A("")
     clob = [f'"v{r}"' for r in range(132)] + [f'"a{r}"' for r in range(256)] + [f'"s{r}"' for r in range(80, 97)] + ['"m0"', '"scc"', '"memory"']
     A("#define EA_W4A_CLOBBERS \\")
     for k in range(0, len(clob), 16):
@@ -247,7 +246,7 @@ def emit():
             A(ln + (" \\" if k + 1 < len(lines) else ""))
         A("")
     open(OUT, "w").write("\n".join(L))
-    print(OUT, len(body), "asm lines")
+    print(OUT, n_lines, "asm lines per variant")
 
 
 if __name__ == "__main__":

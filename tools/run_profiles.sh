@@ -23,6 +23,7 @@ if [ -z "$SKIP_PMC" ]; then
   python tools/rocprof_summary.py pmc $(find $OUT/pmc_fetch -name "*.db" | head -1) > $OUT/pmc_FETCH_SIZE.csv
   python tools/rocprof_summary.py pmc $(find $OUT/pmc_write -name "*.db" | head -1) > $OUT/pmc_WRITE_SIZE.csv
 fi
+[ -z "$SKIP_PMC" ] && python tools/update_traffic_json.py $OUT $TAG > $OUT/traffic_json.log 2>&1 || true
 grep '"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprofv3.json || true
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write   # the sqlite databases are large; the summaries are what is kept
 head -12 $OUT/kernel_stats.csv; [ -z "$SKIP_PMC" ] && { head -8 $OUT/pmc_FETCH_SIZE.csv; head -8 $OUT/pmc_WRITE_SIZE.csv; } || true
