@@ -73,7 +73,7 @@ extern "C" int ea_version(void) { return 112; }   // 112: ea_attention_window_ma
 #define EA_OPTION(n) int ea_##n##_set(int v); int ea_##n##_get();
 EA_OPTION(gemm_tile)      // ea_gemm.hip:      0 (auto) | 128 | 256
 EA_OPTION(gemm_mfma)      // ea_gemm.hip:      16 | 32
-EA_OPTION(gemm_w4a)       // ea_gemm.hip:      0 | 1 (four-wave 256 x 256 kernel, hand-placed main loop)
+EA_OPTION(gemm_w4a)       // ea_gemm.hip:      bits 1 (GEMM) | 2 (fused QKV): four-wave 256 x 256 kernels with the hand-placed main loop; default 3
 EA_OPTION(conv_mfma)      // ea_conv.hip:      16 | 32
 EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
 EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1

@@ -1135,7 +1135,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     }
 }
 
-int g_gemm_w4a = 0;     // ea_set_option("gemm_w4a", 0 | 1): the four-wave kernel with the hand-placed main loop instead of gemm256_mi16_kernel
+int g_gemm_w4a = 3;     // ea_set_option("gemm_w4a", bits): 1 = ea_gemm_bf16 / _kblocked, 2 = the fused QKV projection run on the four-wave kernels with the
+                        // hand-placed main loop (default 3); 0 = the eight-wave kernels (kept: fp8 weights, cross-check)
 // ---- the fused QKV projection on the four-wave hand-placed main loop (gemm256_w4a_kernel's; EA_W4A_MAINLOOP_ASM_SWAP for the V tiles).
 // A wave tile is 128 tokens x 128 features = TWO heads: the epilogues below are gemm256_qkv_kernel's, per head (same roundings at the
 // same points: bit-identical to that kernel), called once per accumulator half.
@@ -1372,7 +1373,7 @@ int launch_gemm(const GemmArgs& p0, int batch, int tile, hipStream_t st) {
             }
             // the four-wave hand-placed kernel addresses its operands through 32-bit buffer offsets
             const int64_t nk64 = p.K / BK;
-            const bool w4a_ok = !W8 && g_gemm_w4a && ((nk64 - 1) * p.a_kstep + 255 * p.lda + BK) * 2 < (int64_t)0xFFFFFFFF &&
+            const bool w4a_ok = !W8 && (g_gemm_w4a & 1) && ((nk64 - 1) * p.a_kstep + 255 * p.lda + BK) * 2 < (int64_t)0xFFFFFFFF &&
                                 ((nk64 - 1) * p.w_kstep + 255 * p.ldw + BK) * 2 < (int64_t)0xFFFFFFFF;
             if (w4a_ok) {
                 if constexpr (!W8) {
@@ -1529,7 +1530,7 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
     ea_count(W8 ? "gemm_qkv_fused_w8" : "gemm_qkv_fused");
     if (parts != 7) ea_count(parts == 6 ? "gemm_qkv_fused_kv_part" : "gemm_qkv_fused_q_part");
     // the four-wave hand-placed main loop (32-bit buffer offsets: a 256-row tile of A / W must be reachable within 4 GiB)
-    if (!W8 && g_gemm_w4a && (255 * lda + K) * 2 < (int64_t)0xFFFFFFFF && (int64_t)256 * K * 2 < (int64_t)0xFFFFFFFF) {
+    if (!W8 && (g_gemm_w4a & 2) && (255 * lda + K) * 2 < (int64_t)0xFFFFFFFF && (int64_t)256 * K * 2 < (int64_t)0xFFFFFFFF) {
         static bool attrw4_done = false;
         if (!attrw4_done) {
             hipFuncSetAttribute((const void*)gemm256_qkv_w4a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
@@ -1580,7 +1581,7 @@ int ea_gemm_tile_set(int v) {
 }
 int ea_gemm_w4a_get() { return g_gemm_w4a; }
 int ea_gemm_w4a_set(int v) {
-    if (v != 0 && v != 1) return -1;
+    if (v < 0 || v > 3) return -1;
     g_gemm_w4a = v;
     return 0;
 }

@@ -46,4 +46,4 @@ def test_config2_full_depth_forward_vs_reference_golden():
     assert v.shape == (2, 16, 13, 64, 64) and torch.isfinite(v.float()).all()
     assert mse < 1e-4
     # one contiguous attention launch per block over both batch elements; text and video streams both on the fused QKV launch
-    assert cnt.get("attention_v3", 0) == 28 and cnt.get("gemm_qkv_fused", 0) == 56 and cnt.get("gemm_256_mi16", 0) >= 28 * 3, cnt
+    assert cnt.get("attention_v3", 0) == 28 and cnt.get("gemm_qkv_fused", 0) == 56 and cnt.get("gemm_256_w4a", 0) >= 28 * 3 and cnt.get("gemm_qkv_fused_w4a", 0) == 56, cnt

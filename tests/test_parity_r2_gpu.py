@@ -189,7 +189,7 @@ def test_transformer_full_width_vs_golden(name):
     assert mse < BAR
     assert cnt.get("attention_v3", 0) == 2                             # the product attention kernel, once per block
     if name.endswith("t2v"):
-        assert cnt.get("gemm_256_mi16", 0) > 0                          # M = 2 x 5120 rows: the large-tile GEMM path
+        assert cnt.get("gemm_256_w4a", 0) > 0                           # M = 2 x 5120 rows: the large-tile GEMM path
 
 
 def test_transformer_full_length_s53504_vs_golden():
@@ -222,7 +222,7 @@ def test_transformer_full_length_s53504_vs_golden():
     print(f"[parity] full-width 2-layer transformer at S = 53504 (49f x 1024^2): new-bf16 vs ref-fp32 MSE={mse:.3e} rel_l2={rel:.3e} "
           f"ref std {g['out_std']:.3f} | kernels {cnt}")
     assert mse < BAR and torch.isfinite(out.float()).all()
-    assert cnt.get("attention_v3", 0) == 2 and cnt.get("gemm_qkv_fused", 0) == 4 and cnt.get("gemm_256_mi16", 0) >= 6, cnt
+    assert cnt.get("attention_v3", 0) == 2 and cnt.get("gemm_qkv_fused", 0) == 4 and cnt.get("gemm_256_w4a", 0) >= 6, cnt
 
 
 def test_vae_full_width_ragged_shape_vs_golden():
@@ -384,5 +384,5 @@ def test_denoise_loop_full_width_meets_the_bar(name):
           f"{g['guidance']:g}): latent MSE by step new vs ref-fp32 " + ", ".join(f"{k}: {v:.3e}" for k, v in res.items())
           + " | ref-bf16 vs ref-fp32 (floor) " + ", ".join(f"{k}: {v:.3e}" for k, v in floor.items())
           + f" | final latent std {ref[g['steps']].std().item():.3f} | kernels {cnt}")
-    assert cnt.get("attention_v3", 0) >= 2 * g["steps"] and cnt.get("gemm_256_mi16", 0) > 0 and cnt.get("gemm_qkv_fused", 0) > 0
+    assert cnt.get("attention_v3", 0) >= 2 * g["steps"] and cnt.get("gemm_256_w4a", 0) > 0 and cnt.get("gemm_qkv_fused", 0) > 0
     assert all(v < BAR for v in res.values()), res

@@ -6,7 +6,9 @@ import json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from easyanimate_amd import ops
+from easyanimate_amd import _lib, ops
+if len(sys.argv) > 1:      # python tools/ab_ffn_kblocked.py 1  -> the four-wave hand-placed kernel (ea_set_option("gemm_w4a", 1))
+    _lib.set_option("gemm_w4a", int(sys.argv[1]))
 from microbench_vae_common import timeit
 
 d, inner = 3072, 12288
