@@ -77,6 +77,7 @@ EA_OPTION(gemm_w4a)       // ea_gemm.hip:      bits 1 (GEMM) | 2 (fused QKV): fo
 EA_OPTION(conv_mfma)      // ea_conv.hip:      16 | 32
 EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
 EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1
+EA_OPTION(conv_w4a)       // ea_conv.hip:      bits 1 (512 x 128 tiles) | 2 (256 x 256 tiles): four-wave row-slab kernels, hand-placed main loop
 EA_OPTION(attn_variant)   // ea_attention.hip: 3 (EA_BUILD_VARIANTS=1 libraries: also 1 | 2)
 #undef EA_OPTION
 // read-only: was this library built with EA_BUILD_VARIANTS=1 (the cross-check kernel generations are present)?
@@ -86,7 +87,7 @@ namespace {
 struct Option { const char* name; int (*set)(int); int (*get)(); };
 #define EA_OPTION(n) {#n, ea_##n##_set, ea_##n##_get}
 const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(gemm_w4a), EA_OPTION(conv_mfma),
-                            EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(attn_variant), EA_OPTION(build_variants)};
+                            EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(conv_w4a), EA_OPTION(attn_variant), EA_OPTION(build_variants)};
 #undef EA_OPTION
 const Option* find_option(const char* name) {
     for (const Option& o : g_options)

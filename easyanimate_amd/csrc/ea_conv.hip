@@ -1406,9 +1406,220 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
     }
 }
 
+// =================================================================================================================
+// The same row-slab implicit GEMM over 32-channel stages on FOUR waves, one per SIMD, 128 voxels x 128 channels per wave, with the
+// main loop placed by hand as one inline-asm block (round 5; tools/gen_conv_w4_asm.py -> ea_conv_w4_loop.inc, where the schedule
+// is documented; the GEMM got +7..16 % from the same move, ea_gemm.hip gemm256_w4a_kernel).  Same products in the same order per
+// accumulator as conv3d_cl_row16_k32_kernel (slabs in (dt, dh, channel block) order, dw inside): bit-identical results, and the
+// same GroupNorm partial-sum layout (waves along M: 4 at 512 x 128, 2 at 256 x 256).
+//   LDS: A stage = PPW * 4 pieces of 1 KiB (16 rows of 64 B; rows >= TM + 2 are zero-filled by out-of-range requests), stage 1 at
+//   stage 0 ^ A_XOR; three W stages of BN x 64 B.  512 x 128: A0 [0, 36 K) | W [36 K, 60 K) | A1 [64 K, 100 K);  256 x 256: A0 [0, 20 K)
+//   | A1 [32 K, 52 K) | W [64 K, 112 K).
+#include "ea_conv_w4_loop.inc"
+#include "ea_gemm_w4_loop.inc"     // EA_W4A_READ_HALF0 / 1: the accumulator read-out (acc(i, j) = a[4 * (8 j + i)] in both loops)
+
+// epilogue of one 128-voxel x 64-channel accumulator half (conv3d_cl_row16_k32_kernel's, per half): bias, residual (prefetched one
+// M tile ahead), one bf16 rounding, store, GroupNorm partial sums of the rounded values
+template <int WM>
+__device__ __forceinline__ void conv_w4a_epilogue(const ConvArgs& p, f32x4 (&acc)[8][4], const int col_w, const int wr, const int orow,
+                                                  const int w0, const int h_out, const int t_out, const int tiles_w, const int tm,
+                                                  const int lane) {
+    const int lr = lane & 15, lq = lane >> 4;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool has_res = p.res != nullptr, has_gn = p.gn_partial != nullptr;
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n0 = col_w + j * 16 + lq * 4;
+        if (p.bias) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
+        else b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t m_base = (int64_t)orow * p.W_out + w0 + wr * 128 + lr;
+    const int64_t e_base = m_base * p.C_out + col_w + lq * 4;   // + i * 16 * C_out + j * 16
+    const int64_t e_step = (int64_t)16 * p.C_out;
+    const unsigned short* const resp =
+        p.res ? p.res - (p.vres ? (int64_t)(t_out - ((t_out + 1) >> 1)) * p.H_out * p.W_out * p.C_out : 0) : nullptr;
+    bf16x4 rr[2][4];
+    if (has_res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[0][j] = *reinterpret_cast<const bf16x4*>(resp + e_base + j * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (has_res && i + 1 < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[(i + 1) & 1][j] = *reinterpret_cast<const bf16x4*>(resp + e_base + (i + 1) * e_step + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rr[i & 1][j][e];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16) = o;
+            if (has_gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = (float)o[e];
+                    gs[j] += r;
+                    gq[j] += r * r;
+                }
+            }
+        }
+    }
+    if (p.gn_partial) {
+        const int64_t in_frame = ((int64_t)h_out * tiles_w + (tm % tiles_w)) * WM + wr;
+        const int64_t blk = (int64_t)t_out * p.gn_nblk + in_frame;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s_ = gs[j], q_ = gq[j];
+#pragma unroll
+            for (int o_ = 1; o_ < 16; o_ <<= 1) {
+                s_ += __shfl_xor(s_, o_, 64);
+                q_ += __shfl_xor(q_, o_, 64);
+            }
+            const int n0 = col_w + j * 16 + lq * 4;
+            if (lr == 0) {
+                float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
+                dst[0] = s_;
+                dst[1] = q_;
+            }
+        }
+    }
+}
+
+template <int BN, int TM>   // 128 x 512 or 256 x 256: (channels, voxels) per workgroup
+__global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
+    static_assert((BN == 128 && TM == 512) || (BN == 256 && TM == 256), "wave tile 128 voxels x 128 channels, four waves");
+    constexpr int RB = 64, KC = 32;
+    constexpr int NROW = TM + 2;
+    constexpr int PPW = TM == 512 ? EA_CONV_W4A_PPW_M512 : EA_CONV_W4A_PPW_N256;
+    constexpr int WP = TM == 512 ? EA_CONV_W4A_WP_M512 : EA_CONV_W4A_WP_N256;
+    constexpr int A_XOR = TM == 512 ? EA_CONV_W4A_AXOR_M512 : EA_CONV_W4A_AXOR_N256;
+    constexpr int W_BASE = TM == 512 ? 36 * 1024 : 64 * 1024;
+    constexpr int WN = BN / 128, WM = 4 / WN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm, tn;
+    {
+        const int rpx = (p.tiles_m + 7) / 8;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int m_lo = xcd * rpx;
+        int rows = p.tiles_m - m_lo;
+        rows = rows < rpx ? rows : rpx;
+        if (rows <= 0 || idx >= rows * p.tiles_n) return;
+        tm = m_lo + idx / p.tiles_n;
+        tn = idx % p.tiles_n;
+    }
+    const int col0 = tn * BN;
+    const int tiles_w = p.W_out / TM;
+    const int w0 = (tm % tiles_w) * TM;
+    const int orow = tm / tiles_w;                 // t_out * H_out + h_out
+    const int h_out = orow % p.H_out, t_out = orow / p.H_out;
+
+    // this lane's slab rows: piece q = wave * PPW + i, LDS row r = 16 q + lane / 4  <->  input voxel w0 - 1 + r; padding and the rows
+    // behind the slab point far beyond the input row (the request writes zeros)
+    int a_voff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int r = q * 16 + (lane >> 2), c = lane & 3;
+        const int w = w0 - 1 + r;
+        a_voff[i] = (r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ ((r >> 1) & 3)) * 8) * 2 : 0x40000000;
+    }
+    const int wk = (p.tmerge ? 18 : 27) * p.C_in;
+    int w_voff[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = (wave * WP + i) * 16 + (lane >> 2), c = lane & 3;
+        w_voff[i] = (r * wk + (c ^ ((r >> 1) & 3)) * 8) * 2;
+    }
+    const unsigned short* const w_tile = p.w + (p.tmerge ? (int64_t)(t_out & 1) * p.C_out * wk : 0) + (int64_t)col0 * wk;
+    const unsigned w_bytes = (unsigned)(BN * wk * 2);
+    const int row_bytes = p.W_in * p.C_in * 2;
+
+    // the (dt, dh) -> input row table: lane l < ntab holds the row of dtdh = l (base address, extent; extent 0 = zero padding)
+    const int ntab = p.tmerge ? 6 : 9;
+    unsigned t_lo = 0, t_hi = 0, t_ext = 0;
+    {
+        const int dtdh = lane < ntab ? lane : 0;
+        const int dt = dtdh / 3, dh = dtdh - dt * 3;
+        int ti = t_out + dt - 2;
+        ti = ti < 0 ? 0 : ti;                                  // causal replicate padding
+        ti = p.vin ? (ti + 1) >> 1 : ti;                       // virtual temporal x2
+        if (p.tmerge) {                                        // two physical frames (p - 1, p), p = (t_out + 1) >> 1
+            ti = ((t_out + 1) >> 1) - 1 + dt;
+            ti = ti < 0 ? 0 : ti;
+        }
+        const int hu = h_out + dh - 1;
+        const bool ok = hu >= 0 && hu < p.H_in;
+        const unsigned short* row = p.x + ((int64_t)ti * p.H_in + (ok ? hu : 0)) * p.W_in * p.C_in;
+        t_lo = (unsigned)(uintptr_t)row;
+        t_hi = (unsigned)((uintptr_t)row >> 32);
+        t_ext = ok ? (unsigned)row_bytes : 0u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // fragment addresses: row * 64 + ((lq ^ ((row >> 1) & 3)) << 4); A row = wr * 128 + i * 16 + lr + dw, W row = wc * 128 + j * 16 + lr
+    unsigned ak[3];
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+        const int row = wr * 128 + lr + dw;
+        ak[dw] = lds0 + row * RB + ((lq ^ ((row >> 1) & 3)) << 4);
+    }
+    const unsigned wkf = lds0 + W_BASE + (wc * 128 + lr) * RB + ((lq ^ ((lr >> 1) & 3)) << 4);
+    const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds0 + wave * (PPW * 1024));
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + W_BASE + wave * (WP * 1024));
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)w_tile);
+    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)w_tile >> 32));
+    const unsigned w_ext = __builtin_amdgcn_readfirstlane(w_bytes);
+    const unsigned cblocks = __builtin_amdgcn_readfirstlane((unsigned)(p.C_in / KC));
+    const unsigned nslabs = __builtin_amdgcn_readfirstlane((unsigned)(ntab * (p.C_in / KC)));
+    const unsigned cin2 = __builtin_amdgcn_readfirstlane((unsigned)(p.C_in * 2));
+#define EA_CW4_COMMON                                                                                                             \
+    [t_lo] "v"(t_lo), [t_hi] "v"(t_hi), [t_ext] "v"(t_ext), [ak0] "v"(ak[0]), [ak1] "v"(ak[1]), [ak2] "v"(ak[2]), [wk] "v"(wkf),   \
+        [w_lo] "s"(w_lo), [w_hi] "s"(w_hi), [w_ext] "s"(w_ext), [cblocks] "s"(cblocks), [nslabs] "s"(nslabs), [cin2] "s"(cin2),     \
+        [lds_w] "s"(lds_w), [lds_a] "s"(lds_a)
+    if constexpr (TM == 512) {
+        asm volatile(EA_CONV_W4A_ASM_M512
+                     :
+                     : EA_CW4_COMMON, [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]),
+                       [aoff4] "v"(a_voff[4]), [aoff5] "v"(a_voff[5]), [aoff6] "v"(a_voff[6]), [aoff7] "v"(a_voff[7]), [aoff8] "v"(a_voff[8]),
+                       [woff0] "v"(w_voff[0]), [woff1] "v"(w_voff[1])
+                     : EA_CONV_W4A_CLOBBERS);
+    } else {
+        asm volatile(EA_CONV_W4A_ASM_N256
+                     :
+                     : EA_CW4_COMMON, [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]),
+                       [aoff4] "v"(a_voff[4]), [woff0] "v"(w_voff[0]), [woff1] "v"(w_voff[1]), [woff2] "v"(w_voff[2]), [woff3] "v"(w_voff[3])
+                     : EA_CONV_W4A_CLOBBERS);
+    }
+#undef EA_CW4_COMMON
+
+    // ---- epilogue: the wave's 128 channels as two halves of 64 (accumulator column blocks 0..3, then 4..7)
+    int lane_e;                                       // the lane id again: nothing lane-derived has to stay live across the main loop
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    f32x4 acc[8][4];
+    EA_W4A_READ_HALF0(acc)
+    conv_w4a_epilogue<WM>(p, acc, col0 + wc * 128, wr, orow, w0, h_out, t_out, tiles_w, tm, lane_e);
+    EA_W4A_READ_HALF1(acc)
+    conv_w4a_epilogue<WM>(p, acc, col0 + wc * 128 + 64, wr, orow, w0, h_out, t_out, tiles_w, tm, lane_e);
+}
+
 // ea_set_option("conv_m512", bit 0: the 512-voxel x 128-channel kernel, bit 1: the 256 x 256 kernel over 32-channel stages).
 // Bit 1 is off by default: for the 256-channel tiles the four-phase kernel over 64-channel stages is 1.5-3 % faster
 // (profiles/history/r02p_conv_k32_256_ab.txt) -- their W tile is 16 pieces of half cache lines per 32-MFMA phase.
+int g_conv_w4a = 3;    // ea_set_option("conv_w4a", bits): 1 = the 512 x 128 tiles, 2 = the 256 x 256 tiles on conv3d_cl_row16_w4a_kernel (default 3; 0 = the eight-wave kernels)
 int g_conv_m512 = 1;
 int g_conv_mfma = 16;  // ea_set_option("conv_mfma", 16 | 32): MFMA shape of the row-slab kernel
 int g_conv_tile = 0;   // 0 = auto; 128: force the 128^2 kernel; 256 / 512: force the ping-pong kernels with 256- / 512-row tiles;
@@ -1444,6 +1655,12 @@ int ea_conv_mfma_get() { return g_conv_mfma; }
 int ea_conv_mfma_set(int v) {
     if (v != 16 && !(v == 32 && EA_BUILD_VARIANTS)) return -1;   // the 32x32x16 row-slab kernel: EA_BUILD_VARIANTS=1 libraries only
     g_conv_mfma = v;
+    return 0;
+}
+int ea_conv_w4a_get() { return g_conv_w4a; }
+int ea_conv_w4a_set(int v) {
+    if (v < 0 || v > 3) return -1;
+    g_conv_w4a = v;
     return 0;
 }
 int ea_conv_m512_get() { return g_conv_m512; }
@@ -1587,7 +1804,7 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
         // no folded up-sampling / temporal duplication: the one-phase-per-tile kernels over 32-channel stages -- 512 voxels x
         // 128 channels for C_out == 128 with rows a multiple of 512 voxels, 256 x 256 for the 256-channel tiles
         const bool k32_128 = C_out == 128 && p.W_out % 512 == 0 && (g_conv_m512 & 1);
-        const bool k32_256 = bn == 256 && (g_conv_m512 & 2);
+        const bool k32_256 = bn == 256 && ((g_conv_m512 & 2) || (g_conv_w4a & 2));
         if (g_conv_mfma == 16 && !ups && !tdup && (k32_128 || k32_256)) {
             const int tmv = k32_128 ? 512 : 256, wm = k32_128 ? 4 : 2;
             const int tiles5 = (int)(p.M / tmv);
@@ -1611,6 +1828,25 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
                 (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<128, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024 + 3 * 128 * 64);
                 (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_k32_kernel<256, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 18 * 1024 + 3 * 256 * 64);
                 attr5_done = true;
+            }
+            // the four-wave kernels with the hand-placed main loop (ea_set_option("conv_w4a", bit 0: 512 x 128, bit 1: 256 x 256)
+            if ((k32_128 && (g_conv_w4a & 1)) || (!k32_128 && (g_conv_w4a & 2))) {
+                static bool attr6_done = false;
+                if (!attr6_done) {
+                    (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                    (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+                    attr6_done = true;
+                }
+                if (k32_128) {
+                    ea_count("conv_row16_m512");
+                    ea_count("conv_w4a");
+                    hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<128, 512>), dim3((unsigned)grid5), dim3(256), 100 * 1024, (hipStream_t)stream, p);
+                } else {
+                    ea_count("conv_row16_256_k32");
+                    ea_count("conv_w4a");
+                    hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<256, 256>), dim3((unsigned)grid5), dim3(256), 112 * 1024, (hipStream_t)stream, p);
+                }
+                return ea_check_launch("ea_conv3d_cl_bf16");
             }
             if (k32_128) {
                 ea_count("conv_row16_m512");

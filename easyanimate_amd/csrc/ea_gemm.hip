@@ -938,210 +938,11 @@ struct QkvArgs {
     int tiles_m, tiles_n, rows_per_xcd;
 };
 
-template <bool W8>
-__global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int lr = lane & 15, lq = lane >> 4;
-
-    int tm, tn;
-    {
-        GemmArgs g;
-        g.tiles_m = q.tiles_m; g.tiles_n = q.tiles_n; g.rows_per_xcd = q.rows_per_xcd;
-        if (!tile_of_block(g, tm, tn)) return;
-    }
-    const int b = blockIdx.y;
-    const int row0 = tm * 256;
-    const int tiles_per_w = q.inner >> 8;
-    const int part = __builtin_amdgcn_readfirstlane(tn / tiles_per_w);
-    const int which = q.first_part + part;                                 // 0 = q, 1 = k, 2 = v
-    const int col0 = (tn - part * tiles_per_w) * 256;                      // first output feature inside that weight
-    const unsigned short* Ab = q.A + b * q.abs_;
-    const unsigned short* Wb = which == 0 ? q.W[0] : (which == 1 ? q.W[1] : q.W[2]);
-    const float* biasb = which == 0 ? q.bias[0] : (which == 1 ? q.bias[1] : q.bias[2]);
-
-    const unsigned short* asrc[4];
-    const unsigned short* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
-        const int cs = c ^ (r & 7);
-        const int ra = row0 + r < q.M ? row0 + r : q.M - 1;       // ragged last M tile: rows past M re-read row M - 1
-        asrc[i] = Ab + (int64_t)ra * q.lda + cs * 8;
-        wsrc[i] = Wb + (int64_t)(col0 + r) * q.K + cs * 8;
-    }
-    constexpr int64_t a_kst = BK, w_kst = BK;                     // row-major operands: the next K tile is 64 elements on
-    char* const dma_a = smem + wave * 4096;
-    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-    unsigned a_k[2], w_k[2];
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-        w_k[ks2] = 2 * OPER2 + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
-    }
-    const int nk = q.K / BK;
-    bf16x8 wf[4];
-    W8Lane w8;
-    if (W8) {   // fp8-stored weights (q.W point at bytes): thread (row tid / 2, k half tid % 2), 32 weights per K tile
-        const int r = tid >> 1, h = tid & 1;
-        w8.src = reinterpret_cast<const unsigned char*>(Wb) + (int64_t)(col0 + r) * q.K + h * 32;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w8.lds[c] = r * 128 + (((h * 4 + c) ^ (r & 7)) << 4);
-    }
-
-    char* const img = smem + wave * 16384;
-    const int tok0 = row0 + wr * 128;                 // first token (row of A) of this wave tile
-    const int head = (col0 >> 6) + wc;
-    const int64_t bh = (int64_t)b * q.heads + head;
-
-    if (which == 2) {
-        EA_G3_MAINLOOP(1, W8)
-        int Mv = q.M;                       // laundered: nothing of the ragged-tile bookkeeping is hoisted above the main loop
-        asm volatile("" : "+s"(Mv));
-        int lane_e;                         // the lane id again, so that no lane-derived value stays live across the main loop
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-        const int lr = lane_e & 15, lq = lane_e >> 4, lane = lane_e;
-        // ---- v: lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = j * 16 + lr;
-            const float bv = biasb ? biasb[col0 + wc * 64 + n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(acc[i][j][e] + bv);
-                const int ch = i * 2 + (lq >> 1);
-                *reinterpret_cast<u16x4*>(img + n * 256 + ((ch ^ (n & 15)) << 4) + (lq & 1) * 8) = o;
-            }
-        }
-        // wave-private image: the LDS writes above are ordered before the reads below by the waitcnt the compiler inserts
-        const int r4 = lane >> 4, c16 = lane & 15;
-        unsigned short* dst = q.vt_out + (bh * 64) * (int64_t)q.kv_rows + q.kv_off + tok0 + c16 * 8;
-        const int nv = Mv - (tok0 + c16 * 8);       // valid tokens among this lane's eight (ragged last M tile: < 8)
-        if (nv >= 8) {
-#pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {
-                const int n = qq * 4 + r4;
-                const u16x8 o = *reinterpret_cast<const u16x8*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
-                *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.kv_rows) = o;
-            }
-        } else if (nv > 0) {   // the one straddling group of a row: element stores, nothing past column kv_off + M is written
-            for (int qq = 0; qq < 16; ++qq) {
-                const int n = qq * 4 + r4;
-                const unsigned short* src = reinterpret_cast<const unsigned short*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
-                for (int e = 0; e < nv; ++e) dst[(int64_t)n * q.kv_rows + e] = src[e];
-            }
-        }
-        return;
-    }
-
-    EA_G3_MAINLOOP(0, W8)
-    int Mv = q.M;
-    asm volatile("" : "+s"(Mv));
-    int lane_e;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-    const int lr_e = lane_e & 15, lq_e = lane_e >> 4;
-    // ---- q / k: lane_e holds features j*16 + lq_e*4 + 0..3 of token i*16 + lr_e
-    const float* gw = q.nw[which];
-    const float* gb = q.nb[which];
-    f32x4_t bias4[4], gw4[4], gb4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = j * 16 + lq_e * 4;
-        f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-        bias4[j] = biasb ? *reinterpret_cast<const f32x4_t*>(biasb + col0 + wc * 64 + n) : z;
-        gw4[j] = *reinterpret_cast<const f32x4_t*>(gw + n);
-        gb4[j] = *reinterpret_cast<const f32x4_t*>(gb + n);
-    }
-    const float osc = which == 0 ? q.q_scale : 1.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = i * 16 + lr_e;
-        // the token's cos / sin rows first: their latency is covered by the LayerNorm arithmetic below
-        f32x4_t c4[4], s4[4];
-        if (q.cosT) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t tr = (int64_t)(tok0 + r < Mv ? tok0 + r : Mv - 1) * 64 + j * 16 + lq_e * 4;
-                c4[j] = *reinterpret_cast<const f32x4_t*>(q.cosT + tr);
-                s4[j] = *reinterpret_cast<const f32x4_t*>(q.sinT + tr);
-            }
-        }
-        float v[4][4];
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[j][e] = bf16_bits_to_f32(f32_to_bf16_bits(acc[i][j][e] + bias4[j][e]));   // the stored QKV value
-                s += v[j][e];
-            }
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const float mean = s * (1.0f / 64.0f);
-        float qd = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[j][e] - mean;
-                qd += d * d;
-            }
-        qd += __shfl_xor(qd, 16, 64);
-        qd += __shfl_xor(qd, 32, 64);
-        const float rstd = rsqrtf(qd * (1.0f / 64.0f) + q.eps);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[j][e] = bf16_bits_to_f32(f32_to_bf16_bits((v[j][e] - mean) * rstd * gw4[j][e] + gb4[j][e]));
-            u16x4 o;
-            if (q.cosT) {
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const float x0 = v[j][e], x1 = v[j][e + 1];
-                    o[e] = f32_to_bf16_bits((x0 * c4[j][e] - x1 * s4[j][e]) * osc);
-                    o[e + 1] = f32_to_bf16_bits((x1 * c4[j][e + 1] + x0 * s4[j][e + 1]) * osc);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[j][e] * osc);
-            }
-            const int ch = j * 2 + (lq_e >> 1);
-            *reinterpret_cast<u16x4*>(img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq_e & 1) * 8) = o;
-        }
-    }
-    const int r8 = lane_e >> 3, c8 = lane_e & 7;
-    unsigned short* dst = (which ? q.k_out + (bh * q.kv_rows + q.kv_off + tok0) * 64
-                                 : q.q_out + (bh * q.s_pad + q.seq_off + tok0) * 64) + c8 * 8;
-#pragma unroll
-    for (int qq = 0; qq < 16; ++qq) {
-        const int r = qq * 8 + r8;
-        const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
-        if (tok0 + r < Mv) *reinterpret_cast<u16x8*>(dst + (int64_t)r * 64) = o;
-    }
-}
-
-int g_gemm_w4a = 3;     // ea_set_option("gemm_w4a", bits): 1 = ea_gemm_bf16 / _kblocked, 2 = the fused QKV projection run on the four-wave kernels with the
-                        // hand-placed main loop (default 3); 0 = the eight-wave kernels (kept: fp8 weights, cross-check)
-// ---- the fused QKV projection on the four-wave hand-placed main loop (gemm256_w4a_kernel's; EA_W4A_MAINLOOP_ASM_SWAP for the V tiles).
-// A wave tile is 128 tokens x 128 features = TWO heads: the epilogues below are gemm256_qkv_kernel's, per head (same roundings at the
-// same points: bit-identical to that kernel), called once per accumulator half.
+// ---- the per-head epilogues of the fused QKV projection (one 128-token x 64-feature accumulator tile = one head), shared by
+// gemm256_qkv_kernel (eight waves: one head per wave tile) and gemm256_qkv_w4a_kernel (four waves: two heads per wave tile)
 __device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[8][4], char* const img, const float* biasb, const int feat0,
                                                const int tok0, const int64_t bh, const int Mv, const int lane) {
+#pragma clang fp contract(off)
     const int lr = lane & 15, lq = lane >> 4;
     // lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
 #pragma unroll
@@ -1178,6 +979,10 @@ __device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[
 
 __device__ __forceinline__ void qkv_epilogue_qk(const QkvArgs& q, f32x4_t (&acc)[8][4], char* const img, const float* biasb, const int feat0,
                                                 const int tok0, const int64_t bh, const int which, const int Mv, const int lane_e) {
+    // no FMA contraction in here: three kernels (eight-wave bf16 / fp8 weights, four-wave) inline this body, and the LayerNorm / RoPE
+    // arithmetic has to round identically in all of them (with contraction left to the compiler a handful of q / k values per
+    // million landed on neighbouring bf16 numbers -- first GPU run of the four-wave kernel)
+#pragma clang fp contract(off)
     const int lr_e = lane_e & 15, lq_e = lane_e >> 4;
     // lane_e holds features j*16 + lq_e*4 + 0..3 of token i*16 + lr_e
     const float* gw = q.nw[which];
@@ -1259,6 +1064,95 @@ __device__ __forceinline__ void qkv_epilogue_qk(const QkvArgs& q, f32x4_t (&acc)
     }
 }
 
+template <bool W8>
+__global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    int tm, tn;
+    {
+        GemmArgs g;
+        g.tiles_m = q.tiles_m; g.tiles_n = q.tiles_n; g.rows_per_xcd = q.rows_per_xcd;
+        if (!tile_of_block(g, tm, tn)) return;
+    }
+    const int b = blockIdx.y;
+    const int row0 = tm * 256;
+    const int tiles_per_w = q.inner >> 8;
+    const int part = __builtin_amdgcn_readfirstlane(tn / tiles_per_w);
+    const int which = q.first_part + part;                                 // 0 = q, 1 = k, 2 = v
+    const int col0 = (tn - part * tiles_per_w) * 256;                      // first output feature inside that weight
+    const unsigned short* Ab = q.A + b * q.abs_;
+    const unsigned short* Wb = which == 0 ? q.W[0] : (which == 1 ? q.W[1] : q.W[2]);
+    const float* biasb = which == 0 ? q.bias[0] : (which == 1 ? q.bias[1] : q.bias[2]);
+
+    const unsigned short* asrc[4];
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3), c = lane & 7;
+        const int cs = c ^ (r & 7);
+        const int ra = row0 + r < q.M ? row0 + r : q.M - 1;       // ragged last M tile: rows past M re-read row M - 1
+        asrc[i] = Ab + (int64_t)ra * q.lda + cs * 8;
+        wsrc[i] = Wb + (int64_t)(col0 + r) * q.K + cs * 8;
+    }
+    constexpr int64_t a_kst = BK, w_kst = BK;                     // row-major operands: the next K tile is 64 elements on
+    char* const dma_a = smem + wave * 4096;
+    char* const dma_w = smem + 2 * OPER2 + wave * 4096;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    unsigned a_k[2], w_k[2];
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+        a_k[ks2] = (wr * 128 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+        w_k[ks2] = 2 * OPER2 + (wc * 64 + lr) * 128 + (((ks2 * 4 + lq) ^ (lr & 7)) << 4);
+    }
+    const int nk = q.K / BK;
+    bf16x8 wf[4];
+    W8Lane w8;
+    if (W8) {   // fp8-stored weights (q.W point at bytes): thread (row tid / 2, k half tid % 2), 32 weights per K tile
+        const int r = tid >> 1, h = tid & 1;
+        w8.src = reinterpret_cast<const unsigned char*>(Wb) + (int64_t)(col0 + r) * q.K + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w8.lds[c] = r * 128 + (((h * 4 + c) ^ (r & 7)) << 4);
+    }
+
+    char* const img = smem + wave * 16384;
+    const int tok0 = row0 + wr * 128;                 // first token (row of A) of this wave tile
+    const int head = (col0 >> 6) + wc;
+    const int64_t bh = (int64_t)b * q.heads + head;
+
+    if (which == 2) {
+        EA_G3_MAINLOOP(1, W8)
+        int Mv = q.M;                       // laundered: nothing of the ragged-tile bookkeeping is hoisted above the main loop
+        asm volatile("" : "+s"(Mv));
+        int lane_e;                         // the lane id again, so that no lane-derived value stays live across the main loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        qkv_epilogue_v(q, acc, img, biasb, col0 + wc * 64, tok0, bh, Mv, lane_e);
+        return;
+    }
+
+    EA_G3_MAINLOOP(0, W8)
+    int Mv = q.M;
+    asm volatile("" : "+s"(Mv));
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    qkv_epilogue_qk(q, acc, img, biasb, col0 + wc * 64, tok0, bh, which, Mv, lane_e);
+}
+
+// ---- the fused QKV projection on the four-wave hand-placed main loop (gemm256_w4a_kernel's; EA_W4A_MAINLOOP_ASM_SWAP for the V tiles).
+// A wave tile is 128 tokens x 128 features = TWO heads: the shared per-head epilogues (qkv_epilogue_qk / _v above, contraction-free:
+// bit-identical to gemm256_qkv_kernel) are called once per accumulator half.
 __global__ __launch_bounds__(256) void gemm256_qkv_w4a_kernel(QkvArgs q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1346,6 +1240,8 @@ __global__ __launch_bounds__(256) void gemm256_qkv_w4a_kernel(QkvArgs q) {
     }
 }
 
+int g_gemm_w4a = 3;     // ea_set_option("gemm_w4a", bits): 1 = ea_gemm_bf16 / _kblocked, 2 = the fused QKV projection run on the four-wave kernels with the
+                        // hand-placed main loop (default 3); 0 = the eight-wave kernels (kept: fp8 weights, cross-check)
 int g_gemm_mfma = 16;   // ea_set_option("gemm_mfma", 16 | 32): MFMA shape of the 256^2 kernel (32: the first version, kept as cross-check)
 
 template <int EPI, bool W8>

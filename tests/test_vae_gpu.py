@@ -7,6 +7,19 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _eight_wave_conv_dispatch():
+    """The kernel-level tests of this file pin the dispatch and the arithmetic of the EIGHT-wave convolution kernels (exact launch
+    counters, forced tile options): they run with conv_w4a = 0.  The four-wave hand-placed kernels -- the default since round 5
+    for the 512 x 128 and 256 x 256 row-slab tiles -- are covered by test_conv_w4a_bit_identical_to_the_eight_wave_kernels below
+    (which sets the option itself) and by every model-level golden (tests/test_parity_r2_gpu.py, test_config4_gpu.py)."""
+    from easyanimate_amd import _lib
+    prev = _lib.get_option("conv_w4a")
+    _lib.set_option("conv_w4a", 0)
+    yield
+    _lib.set_option("conv_w4a", prev)
 DEV = "cuda"
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -794,3 +807,56 @@ def test_conv3d_merged_temporal_taps(T, H, W, Ci, Co, kern):
     rel27 = ((y.float() - y27.float()).norm() / y27.float().norm()).item()
     print(f"[parity] merged-tap vs 27-tap kernel: rel_l2 {rel27:.3e}")
     assert rel < 5e-3 and rel27 < 5e-3
+
+
+# ---- round 5: the row-slab kernels on four waves with the hand-placed main loop (conv3d_cl_row16_w4a_kernel) -------------------------
+@pytest.mark.parametrize("T,H,W,Ci,Co,res,tmerge", [
+    (3, 3, 512, 128, 128, True, False),       # 512 x 128 tiles: the kernel that carries 42 % of a 49 x 1024^2 decode
+    (2, 2, 1024, 256, 128, True, False),      # two tiles per row, 8 channel blocks
+    (2, 5, 512, 64, 128, False, False),       # 2 channel blocks: the (dt, dh) cursor moves every second slab; rows of padding top and bottom
+    (3, 3, 512, 256, 128, True, True),        # merged temporal taps (6 table rows), virtual input and residual
+    (2, 2, 512, 64, 128, False, True),
+    (4, 4, 256, 128, 256, True, False),       # 256 x 256 tiles
+    (2, 3, 512, 256, 256, False, False),
+    (3, 2, 256, 512, 512, True, False),       # two N tiles
+])
+def test_conv_w4a_bit_identical_to_the_eight_wave_kernels(T, H, W, Ci, Co, res, tmerge):
+    """ea_set_option("conv_w4a", 3): same slabs, same fragments, the same MFMAs accumulating the same taps in the same order per
+    accumulator -> the output and the GroupNorm partial sums are bit-identical to conv3d_cl_row16_k32_kernel (which is pinned to the
+    fp64 convolution by test_conv3d_cl_row_slab / test_conv3d_merged_temporal_taps)."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight, _pack_tmerge_weight
+    g = torch.Generator().manual_seed(77 + W + Ci + Co)
+    x = _bf(torch.randn(T, H, W, Ci, generator=g)).to(DEV)
+    w = _bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)
+    b = torch.randn(Co, generator=g).to(DEV)
+    wp = (_pack_tmerge_weight(w, Co) if tmerge else _pack_conv_weight(w)).to(DEV)
+    Tl = 2 * T - 1 if tmerge else T
+    r = _bf(torch.randn(T if tmerge else Tl, H, W, Co, generator=g)).to(DEV) if res else None
+    kw = dict(vin=True, vres=res, tmerge=True) if tmerge else {}
+    outs = {}
+    _lib.set_option("conv_tile", 1024)
+    _lib.set_option("conv_m512", 3)            # the eight-wave reference for the 256 x 256 tiles is the k32 kernel too
+    try:
+        for v in (0, 3, 3):
+            _lib.set_option("conv_w4a", v)
+            _lib.reset_counters()
+            y = ops.conv3d_cl(x, wp, b, 3, 1, 1, 1, res=r, **kw)
+            torch.cuda.synchronize()
+            c = _lib.counters()
+            assert c.get("conv_w4a", 0) == (1 if v else 0) and (c.get("conv_row16_m512", 0) + c.get("conv_row16_256_k32", 0)) == 1, c
+            part, nblk = y.gn_partial
+            outs.setdefault(v, []).append((y.clone(), part[:y.shape[0] * nblk * (Co // 4) * 2].clone(), nblk))
+    finally:
+        _lib.set_option("conv_tile", 0)
+        _lib.set_option("conv_m512", 1)
+        _lib.set_option("conv_w4a", 0)         # (the module fixture restores the default)
+    (y0, p0, n0), (y1, p1, n1), (y2, p2, n2) = outs[0][0], outs[3][0], outs[3][1]
+    assert torch.isfinite(y1.float()).all() and n0 == n1
+    if not torch.equal(y1, y0):
+        d = (y1.float() - y0.float()).abs()
+        bad = (d > 0).nonzero()
+        raise AssertionError(f"w4a conv differs: {bad.shape[0]} of {d.numel()} elements, max {d.max().item():.3e}; first {bad[:4].tolist()} last {bad[-2:].tolist()}; "
+                             f"frames {bad[:, 0].unique().tolist()} rows {bad[:, 1].unique().tolist()[:8]} voxels {bad[:, 2].unique().tolist()[:16]} channels {bad[:, 3].unique().tolist()[:16]}")
+    assert torch.equal(p1, p0)
+    assert torch.equal(y2, y1) and torch.equal(p2, p1)       # repeated launches agree (race screen)

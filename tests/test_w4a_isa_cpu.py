@@ -13,17 +13,24 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "easyanimate_amd", "csrc", "ea_gemm.hip")
-KERNELS = ["gemm256_w4a_kernelILi0E", "gemm256_w4a_kernelILi1E", "gemm256_w4a_kernelILi2E", "gemm256_qkv_w4a_kernel"]
+CSRC = os.path.join(ROOT, "easyanimate_amd", "csrc")
+# (source file, kernel symbol fragment, MFMAs inside each hand-placed loop body)
+KERNELS = [("ea_gemm.hip", "gemm256_w4a_kernelILi0E", [128]), ("ea_gemm.hip", "gemm256_w4a_kernelILi1E", [128]),
+           ("ea_gemm.hip", "gemm256_w4a_kernelILi2E", [128]), ("ea_gemm.hip", "gemm256_qkv_w4a_kernel", [128, 128]),
+           ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi128ELi512E", [384]), ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi256ELi256E", [384])]
 
 
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("isa") / "ea_gemm.s")
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-inline-asm",
-                        "-x", "hip", "-S", "--cuda-device-only", SRC, "-o", out], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return open(out).read().split("\n")
+    d = tmp_path_factory.mktemp("isa")
+    out = {}
+    for src in sorted({k[0] for k in KERNELS}):
+        o = str(d / (src + ".s"))
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-inline-asm",
+                            "-x", "hip", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[src] = open(o).read().split("\n")
+    return out
 
 
 def _regs(text):
@@ -143,14 +150,15 @@ def _analyse(name, body):
     return errors, n_w, n_r, n_loop_mfma, loops_ok
 
 
-@pytest.mark.parametrize("name", KERNELS)
-def test_compiler_leaves_the_accumulators_alone(isa, name):
-    st = [i for i, l in enumerate(isa) if re.match(rf"_ZN\w*{name}\w*:", l)][0]
-    en = [i for i in range(st, len(isa)) if ".end_amdhsa_kernel" in isa[i]][0]
-    body = isa[st:en]
+@pytest.mark.parametrize("src,name,loop_mfmas", KERNELS)
+def test_compiler_leaves_the_accumulators_alone(isa, src, name, loop_mfmas):
+    text = isa[src]
+    st = [i for i, l in enumerate(text) if re.match(rf"_ZN\w*{name}\w*:", l)][0]
+    en = [i for i in range(st, len(text)) if ".end_amdhsa_kernel" in text[i]][0]
+    body = text[st:en]
     meta = {k: int([l.split()[-1] for l in body if k in l][0]) for k in (".amdhsa_private_segment_fixed_size", ".amdhsa_accum_offset")}
     assert meta[".amdhsa_private_segment_fixed_size"] == 0 and not any("scratch_" in l for l in body)
     errors, n_w, n_r, n_loop_mfma, loops_ok = _analyse(name, body)
-    assert n_loop_mfma == ([128, 128] if "qkv" in name else [128]) and loops_ok
+    assert n_loop_mfma == loop_mfmas and loops_ok
     print(f"[isa] {name}: arch VGPRs {meta['.amdhsa_accum_offset']}, compiler AGPR spill writes / reads behind the main loop: {n_w} / {n_r}")
     assert not errors, "\n".join(errors[:10])
