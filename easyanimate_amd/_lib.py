@@ -33,9 +33,12 @@ PROTOTYPES = {
     "ea_gemm_bf16_w8": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _I, _P],
     "ea_qknorm_rope_bf16": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ea_qkv_gemm_norm_rope_bf16": [_P] * 16 + [_I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P],
+    "ea_qkv_gemm_norm_rope_grouped_bf16": [_P] * 16 + [_I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _I, _L, _F, _F, _P],
     "ea_qkv_gemm_norm_rope_bf16_w8": [_P] * 16 + [_I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P],
     "ea_attention_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P],
     "ea_attention_fwd_segments_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _F, _P, _I, _P],
+    "ea_attention_fwd_segments_heads_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _F, _P, _I, _I, _I, _L, _P],
+    "ea_attention_fwd_range_heads_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _I, _L, _P],
     "ea_attention_d512_fwd_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _F, _P],
     "ea_attention_window_fwd_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "ea_attention_window_mapped_fwd_bf16": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P],

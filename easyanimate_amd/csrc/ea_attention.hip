@@ -456,7 +456,10 @@ extern "C" int ea_qknorm_rope_bf16(const ea_bf16* qkv, int64_t qkv_batch_stride,
 
 static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
                             int64_t out_batch_stride, int batch, int heads, int s_pad, int q_begin, int q_end,
-                            int kv_begin, int kv_end, float scale, float* state, int flags, void* stream) {
+                            int kv_begin, int kv_end, float scale, float* state, int flags, void* stream,
+                            int q_head0 = 0, int q_heads = 0, int64_t kv_bstride = 0) {
+    EA_REQUIRE(q_head0 >= 0 && (q_heads == 0 ? q_head0 == 0 : q_head0 + heads <= q_heads) && kv_bstride >= 0 && kv_bstride % 8 == 0,
+               "ea_attention_fwd: the head window [q_head0, q_head0 + heads) must lie inside q_heads");
     EA_REQUIRE(q && k && vt && (out || (flags & 2)), "ea_attention_fwd: null tensor");
     EA_REQUIRE(batch > 0 && heads > 0 && kv_end > kv_begin && kv_begin >= 0, "ea_attention_fwd: bad sizes");
     EA_REQUIRE(s_pad % ATT_QB == 0 && s_pad >= kv_end, "ea_attention_fwd: s_pad must be a multiple of 256 and >= the key range");
@@ -481,6 +484,7 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     unsigned short* o16 = (unsigned short*)out;
     f32x4* st4 = reinterpret_cast<f32x4*>(state);
 #if EA_BUILD_VARIANTS
+    EA_REQUIRE(q_heads == 0 || g_attn_variant >= 3, "ea_attention_fwd: a head window needs the v3 kernel");
     const int variant = plain ? g_attn_variant : (g_attn_variant >= 3 ? 3 : 2);   // key ranges / resumable state: v2 / v3 only
     if (variant == 1) {
         ea_count("attention_v1");
@@ -510,9 +514,11 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     (void)plain;
     ea_count("attention_v3");
     const dim3 grid3((unsigned)att3_grid_blocks(bh, nqb));
+    AttSegments hw = AttSegments();          // not a segment launch: only the head window fields are read
+    hw.q_head0 = q_head0; hw.q_heads = q_heads; hw.kv_bstride = kv_bstride;
 #define EA_ATT_LAUNCH(MODE)                                                                                               \
     hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid3, blk, ATT_LDS, st, q, k, vt, o16,                            \
-                       out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4)
+                       out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4, hw)
     switch (flags) {
         case 0: EA_ATT_LAUNCH(0); break;
         case 1: EA_ATT_LAUNCH(1); break;
@@ -531,12 +537,14 @@ extern "C" int ea_attention_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const e
                             stream);
 }
 
-extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
-                                              int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin,
-                                              int q_end, int seg_rows, int n_seg, int skip_seg, int64_t seg_stride,
-                                              int seg_first_row, int seg_used_rows, int kv_valid, float scale, float* state,
-                                              int flags, void* stream) {
+static int attention_segments_launch(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
+                                     int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin,
+                                     int q_end, int seg_rows, int n_seg, int skip_seg, int64_t seg_stride,
+                                     int seg_first_row, int seg_used_rows, int kv_valid, float scale, float* state,
+                                     int flags, void* stream, int q_head0, int q_heads, int64_t kv_bstride) {
     EA_REQUIRE(q && k_seg0 && vt_seg0 && (out || (flags & 2)), "ea_attention_fwd_segments_bf16: null tensor");
+    EA_REQUIRE(q_head0 >= 0 && (q_heads == 0 ? q_head0 == 0 : q_head0 + heads <= q_heads) && kv_bstride >= 0 && kv_bstride % 8 == 0,
+               "ea_attention_fwd_segments_bf16: the head window [q_head0, q_head0 + heads) must lie inside q_heads");
     EA_REQUIRE(batch > 0 && heads > 0 && q_pad % ATT_QB == 0 && q_begin >= 0 && q_begin <= q_end && q_end <= q_pad,
                "ea_attention_fwd_segments_bf16: bad query range");
     EA_REQUIRE(seg_rows > 0 && seg_rows % ATT_KV == 0 && n_seg >= 1 && seg_stride >= 0,
@@ -561,6 +569,7 @@ extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k
     AttSegments sg;
     sg.rows = seg_rows; sg.tiles = seg_used_rows / ATT_KV; sg.skip = (skip_seg >= 0 && skip_seg < n_seg) ? skip_seg : n_seg;
     sg.total_tiles = used * sg.tiles; sg.stride = seg_stride; sg.first = seg_first_row / ATT_KV;
+    sg.q_head0 = q_head0; sg.q_heads = q_heads; sg.kv_bstride = kv_bstride;
     const dim3 grid((unsigned)att3_grid_blocks(bh, nqb)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     unsigned short* o16 = (unsigned short*)out;
@@ -576,6 +585,25 @@ extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k
     }
 #undef EA_ATT_SEG
     return ea_check_launch("ea_attention_fwd_segments_bf16");
+}
+
+extern "C" int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
+                                              int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin,
+                                              int q_end, int seg_rows, int n_seg, int skip_seg, int64_t seg_stride,
+                                              int seg_first_row, int seg_used_rows, int kv_valid, float scale, float* state,
+                                              int flags, void* stream) {
+    return attention_segments_launch(q, k_seg0, vt_seg0, out, out_batch_stride, batch, heads, q_pad, q_begin, q_end, seg_rows, n_seg,
+                                     skip_seg, seg_stride, seg_first_row, seg_used_rows, kv_valid, scale, state, flags, stream, 0, 0, 0);
+}
+
+extern "C" int ea_attention_fwd_segments_heads_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
+                                                    int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin,
+                                                    int q_end, int seg_rows, int n_seg, int skip_seg, int64_t seg_stride,
+                                                    int seg_first_row, int seg_used_rows, int kv_valid, float scale, float* state,
+                                                    int flags, int q_head0, int q_heads, int64_t kv_batch_stride, void* stream) {
+    return attention_segments_launch(q, k_seg0, vt_seg0, out, out_batch_stride, batch, heads, q_pad, q_begin, q_end, seg_rows, n_seg,
+                                     skip_seg, seg_stride, seg_first_row, seg_used_rows, kv_valid, scale, state, flags, stream, q_head0,
+                                     q_heads, kv_batch_stride);
 }
 
 extern "C" int ea_attention_window_fwd_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
@@ -627,4 +655,12 @@ extern "C" int ea_attention_fwd_range_bf16(const ea_bf16* q, const ea_bf16* k, c
                                            void* stream) {
     return attention_launch(q, k, vt, out, out_batch_stride, batch, heads, s_pad, q_begin, q_end, kv_begin, kv_end, scale,
                             state, flags, stream);
+}
+
+extern "C" int ea_attention_fwd_range_heads_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                                 int64_t out_batch_stride, int batch, int heads, int s_pad, int q_begin,
+                                                 int q_end, int kv_begin, int kv_end, float scale, float* state, int flags,
+                                                 int q_head0, int q_heads, int64_t kv_batch_stride, void* stream) {
+    return attention_launch(q, k, vt, out, out_batch_stride, batch, heads, s_pad, q_begin, q_end, kv_begin, kv_end, scale,
+                            state, flags, stream, q_head0, q_heads, kv_batch_stride);
 }

@@ -933,6 +933,9 @@ struct QkvArgs {
     int kv_off, kv_rows;   // geometry of k_out / vt_out (rows per head, first row): equal to (seq_off, s_pad) unless the caller
                            // lets K / V^T land in another buffer (sequence parallelism: the rank's slot of the exchange buffer)
     int first_part;        // the launch's N axis starts at this third (0 = q | k | v, 1 = k | v): which = first_part + tn / tiles_per_w
+    int kv_gheads;         // K / V^T destination in head GROUPS (sequence parallelism exchanging one head group at a time): head h of batch b
+    int64_t kv_gstride;    // lands in group h / kv_gheads at k_out + group * kv_gstride + ((b * kv_gheads + h % kv_gheads) * kv_rows ..) * 64
+                           // (kv_gheads == heads, kv_gstride == 0: one [batch, heads, kv_rows, 64] buffer)
     int64_t lda, abs_;
     float eps, q_scale;
     int tiles_m, tiles_n, rows_per_xcd;
@@ -940,8 +943,14 @@ struct QkvArgs {
 
 // ---- the per-head epilogues of the fused QKV projection (one 128-token x 64-feature accumulator tile = one head), shared by
 // gemm256_qkv_kernel (eight waves: one head per wave tile) and gemm256_qkv_w4a_kernel (four waves: two heads per wave tile)
+// element offset of (batch b, head) inside the K / V^T destination (see QkvArgs::kv_gheads)
+__device__ __forceinline__ int64_t qkv_kv_base(const QkvArgs& q, const int b, const int head) {
+    const int g = head / q.kv_gheads;
+    return (int64_t)g * q.kv_gstride + ((int64_t)b * q.kv_gheads + (head - g * q.kv_gheads)) * q.kv_rows * 64;
+}
+
 __device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[8][4], char* const img, const float* biasb, const int feat0,
-                                               const int tok0, const int64_t bh, const int Mv, const int lane) {
+                                               const int tok0, const int64_t kvbase, const int Mv, const int lane) {
 #pragma clang fp contract(off)
     const int lr = lane & 15, lq = lane >> 4;
     // lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
@@ -959,7 +968,7 @@ __device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[
         }
     }
     const int r4 = lane >> 4, c16 = lane & 15;
-    unsigned short* dst = q.vt_out + (bh * 64) * (int64_t)q.kv_rows + q.kv_off + tok0 + c16 * 8;
+    unsigned short* dst = q.vt_out + kvbase + q.kv_off + tok0 + c16 * 8;
     const int nv = Mv - (tok0 + c16 * 8);       // valid tokens among this lane's eight (ragged last M tile: < 8)
     if (nv >= 8) {
 #pragma unroll
@@ -978,7 +987,8 @@ __device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[
 }
 
 __device__ __forceinline__ void qkv_epilogue_qk(const QkvArgs& q, f32x4_t (&acc)[8][4], char* const img, const float* biasb, const int feat0,
-                                                const int tok0, const int64_t bh, const int which, const int Mv, const int lane_e) {
+                                                const int tok0, const int64_t bh, const int64_t kvbase, const int which, const int Mv,
+                                                const int lane_e) {
     // no FMA contraction in here: three kernels (eight-wave bf16 / fp8 weights, four-wave) inline this body, and the LayerNorm / RoPE
     // arithmetic has to round identically in all of them (with contraction left to the compiler a handful of q / k values per
     // million landed on neighbouring bf16 numbers -- first GPU run of the four-wave kernel)
@@ -1054,7 +1064,7 @@ __device__ __forceinline__ void qkv_epilogue_qk(const QkvArgs& q, f32x4_t (&acc)
         }
     }
     const int r8 = lane_e >> 3, c8 = lane_e & 7;
-    unsigned short* dst = (which ? q.k_out + (bh * q.kv_rows + q.kv_off + tok0) * 64
+    unsigned short* dst = (which ? q.k_out + kvbase + (int64_t)(q.kv_off + tok0) * 64
                                  : q.q_out + (bh * q.s_pad + q.seq_off + tok0) * 64) + c8 * 8;
 #pragma unroll
     for (int qq = 0; qq < 16; ++qq) {
@@ -1138,7 +1148,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
         asm volatile("" : "+s"(Mv));
         int lane_e;                         // the lane id again, so that no lane-derived value stays live across the main loop
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-        qkv_epilogue_v(q, acc, img, biasb, col0 + wc * 64, tok0, bh, Mv, lane_e);
+        qkv_epilogue_v(q, acc, img, biasb, col0 + wc * 64, tok0, qkv_kv_base(q, b, head), Mv, lane_e);
         return;
     }
 
@@ -1147,7 +1157,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_qkv_kernel(QkvArgs q) {
     asm volatile("" : "+s"(Mv));
     int lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-    qkv_epilogue_qk(q, acc, img, biasb, col0 + wc * 64, tok0, bh, which, Mv, lane_e);
+    qkv_epilogue_qk(q, acc, img, biasb, col0 + wc * 64, tok0, bh, qkv_kv_base(q, b, head), which, Mv, lane_e);
 }
 
 // ---- the fused QKV projection on the four-wave hand-placed main loop (gemm256_w4a_kernel's; EA_W4A_MAINLOOP_ASM_SWAP for the V tiles).
@@ -1229,14 +1239,15 @@ __global__ __launch_bounds__(256) void gemm256_qkv_w4a_kernel(QkvArgs q) {
     f32x4_t acc[8][4];
     if (which == 2) {
         EA_W4A_READ_HALF0(acc)
-        qkv_epilogue_v(q, acc, img, biasb, head0 * 64, tok0, (int64_t)b * q.heads + head0, Mv, lane_e);
+        qkv_epilogue_v(q, acc, img, biasb, head0 * 64, tok0, qkv_kv_base(q, b, head0), Mv, lane_e);
         EA_W4A_READ_HALF1(acc)
-        qkv_epilogue_v(q, acc, img, biasb, head0 * 64 + 64, tok0, (int64_t)b * q.heads + head0 + 1, Mv, lane_e);
+        qkv_epilogue_v(q, acc, img, biasb, head0 * 64 + 64, tok0, qkv_kv_base(q, b, head0 + 1), Mv, lane_e);
     } else {
         EA_W4A_READ_HALF0(acc)
-        qkv_epilogue_qk(q, acc, img, biasb, head0 * 64, tok0, (int64_t)b * q.heads + head0, which, Mv, lane_e);
+        qkv_epilogue_qk(q, acc, img, biasb, head0 * 64, tok0, (int64_t)b * q.heads + head0, qkv_kv_base(q, b, head0), which, Mv, lane_e);
         EA_W4A_READ_HALF1(acc)
-        qkv_epilogue_qk(q, acc, img, biasb, head0 * 64 + 64, tok0, (int64_t)b * q.heads + head0 + 1, which, Mv, lane_e);
+        qkv_epilogue_qk(q, acc, img, biasb, head0 * 64 + 64, tok0, (int64_t)b * q.heads + head0 + 1, qkv_kv_base(q, b, head0 + 1), which, Mv,
+                        lane_e);
     }
 }
 
@@ -1386,9 +1397,12 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
                                           const float* nk_w, const float* nk_b, const float* cos, const float* sin,
                                           int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
                                           int seq_off, int s_pad, int kv_off, int kv_rows, int parts, float ln_eps, float q_scale,
-                                          void* stream) {
+                                          void* stream, int kv_group_heads = 0, int64_t kv_group_stride = 0) {
     EA_REQUIRE(A && Wq && Wk && Wv && q_out && k_out && vt_out && nq_w && nq_b && nk_w && nk_b,
                "ea_qkv_gemm_norm_rope_bf16: null tensor");
+    if (kv_group_heads <= 0) { kv_group_heads = heads; kv_group_stride = 0; }
+    EA_REQUIRE(heads % kv_group_heads == 0 && kv_group_stride >= 0 && kv_group_stride % 8 == 0,
+               "ea_qkv_gemm_norm_rope_bf16: kv_group_heads must divide heads, kv_group_stride must be a multiple of 8 elements");
     if (kv_rows <= 0) { kv_rows = s_pad; kv_off = seq_off; }
     if (parts == 0) parts = 7;
     EA_REQUIRE(parts == 7 || parts == 1 || parts == 6, "ea_qkv_gemm_norm_rope_bf16: parts must be 7 (q|k|v), 1 (q) or 6 (k|v)");
@@ -1413,6 +1427,7 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
     q.nw[0] = nq_w; q.nb[0] = nq_b; q.nw[1] = nk_w; q.nb[1] = nk_b; q.cosT = cos; q.sinT = sin;
     q.M = M; q.K = K; q.inner = heads * 64; q.heads = heads; q.seq_off = seq_off; q.s_pad = s_pad;
     q.kv_off = kv_off; q.kv_rows = kv_rows; q.first_part = parts == 6 ? 1 : 0;
+    q.kv_gheads = kv_group_heads; q.kv_gstride = kv_group_stride;
     q.lda = lda; q.abs_ = a_batch_stride; q.eps = ln_eps; q.q_scale = q_scale;
     q.tiles_m = (M + 255) / 256;      // a ragged last tile re-reads row M - 1 and stores rows < M only
     q.tiles_n = (parts == 7 ? 3 : (parts == 6 ? 2 : 1)) * q.inner / 256;
@@ -1450,6 +1465,18 @@ extern "C" int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, c
                                           float q_scale, void* stream) {
     return qkv_entry<false>(A, Wq, Wk, Wv, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, batch, M, heads, K, lda,
                             a_batch_stride, seq_off, s_pad, kv_off, kv_rows, parts, ln_eps, q_scale, stream);
+}
+
+// K / V^T written in head groups (see QkvArgs::kv_gheads): the sequence-parallel exchange by head groups
+extern "C" int ea_qkv_gemm_norm_rope_grouped_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
+                                                  const float* bq, const float* bk, const float* bv, ea_bf16* q_out,
+                                                  ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
+                                                  const float* nk_w, const float* nk_b, const float* cos, const float* sin,
+                                                  int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
+                                                  int seq_off, int s_pad, int kv_off, int kv_rows, int parts, int kv_group_heads,
+                                                  int64_t kv_group_stride, float ln_eps, float q_scale, void* stream) {
+    return qkv_entry<false>(A, Wq, Wk, Wv, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin, batch, M, heads, K, lda,
+                            a_batch_stride, seq_off, s_pad, kv_off, kv_rows, parts, ln_eps, q_scale, stream, kv_group_heads, kv_group_stride);
 }
 
 extern "C" int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq_fp8, const uint8_t* Wk_fp8, const uint8_t* Wv_fp8,

@@ -284,10 +284,12 @@ QKV_ALL, QKV_Q, QKV_KV = 7, 1, 6   # `parts` of qkv_gemm_norm_rope: which thirds
 def qkv_gemm_norm_rope(x: torch.Tensor, wq, wk, wv, bq, bk, bv, q_out: torch.Tensor, k_out: torch.Tensor,
                        vt_out: torch.Tensor, nq_w, nq_b, nk_w, nk_b, cos: Optional[torch.Tensor],
                        sin: Optional[torch.Tensor], seq_off: int, eps: float, q_scale: float = 1.0,
-                       kv_off: Optional[int] = None, parts: int = QKV_ALL) -> None:
+                       kv_off: Optional[int] = None, parts: int = QKV_ALL, kv_group_stride: int = 0) -> None:
     """x bf16 [B, n_tok, K] -> rows [seq_off, seq_off+n_tok) of q_out [B,H,S_pad,64], rows [kv_off, kv_off+n_tok) of k_out
     [B,H,R,64] and columns of vt_out [B,H,64,R] (R, kv_off default to q_out's geometry): the three projections +
-    qk-LayerNorm + RoPE + scatter in one launch (parts = QKV_KV / QKV_Q: two launches, K | V first)."""
+    qk-LayerNorm + RoPE + scatter in one launch (parts = QKV_KV / QKV_Q: two launches, K | V first).
+    kv_group_stride > 0 (ea_qkv_gemm_norm_rope_grouped_bf16): k_out / vt_out are the buffers of head GROUP 0, [B, Hg, R, 64] /
+    [B, Hg, 64, R] with Hg dividing H; group g lives kv_group_stride elements further on (the caller owns that memory)."""
     _dev(x, wq, wk, wv, bq, bk, bv, q_out, k_out, vt_out, nq_w, nq_b, nk_w, nk_b, cos, sin)
     _chk(x, _BF16, "x")
     B, n_tok, K = x.shape
@@ -295,7 +297,8 @@ def qkv_gemm_norm_rope(x: torch.Tensor, wq, wk, wv, bq, bk, bv, q_out: torch.Ten
     assert dh == 64 and x.stride(2) == 1 and q_out.is_contiguous() and k_out.is_contiguous() and vt_out.is_contiguous()
     kv_rows = k_out.shape[2]
     kv_off = seq_off if kv_off is None else kv_off
-    assert k_out.shape == (B, H, kv_rows, 64) and vt_out.shape == (B, H, 64, kv_rows) and kv_off + n_tok <= kv_rows
+    Hg = k_out.shape[1] if kv_group_stride else H
+    assert H % Hg == 0 and k_out.shape == (B, Hg, kv_rows, 64) and vt_out.shape == (B, Hg, 64, kv_rows) and kv_off + n_tok <= kv_rows
     w8 = wq.dtype == _FP8          # fp8 weight storage: all three or none
     for w in (wq, wk, wv):
         _chk(w, _FP8 if w8 else _BF16, "W")
@@ -303,6 +306,13 @@ def qkv_gemm_norm_rope(x: torch.Tensor, wq, wk, wv, bq, bk, bv, q_out: torch.Ten
     if cos is not None:
         _chk(cos, _F32, "cos"); _chk(sin, _F32, "sin")
         assert cos.shape == (n_tok, 64) and cos.is_contiguous() and sin.is_contiguous()
+    if kv_group_stride:
+        assert not w8, "grouped K / V^T destination: bf16 weights only"
+        _timed("gemm", lambda: _lib.call("ea_qkv_gemm_norm_rope_grouped_bf16", _p(x), _p(wq), _p(wk), _p(wv), _p(bq), _p(bk), _p(bv),
+                                         _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b), _p(nk_w), _p(nk_b), _p(cos),
+                                         _p(sin), B, n_tok, H, K, x.stride(1), x.stride(0), seq_off, s_pad, kv_off, kv_rows,
+                                         int(parts), Hg, int(kv_group_stride), float(eps), float(q_scale), _stream()))
+        return
     _timed("gemm", lambda: _lib.call("ea_qkv_gemm_norm_rope_bf16_w8" if w8 else "ea_qkv_gemm_norm_rope_bf16", _p(x), _p(wq), _p(wk), _p(wv), _p(bq), _p(bk), _p(bv),
                                      _p(q_out), _p(k_out), _p(vt_out), _p(nq_w), _p(nq_b), _p(nk_w), _p(nk_b), _p(cos),
                                      _p(sin), B, n_tok, H, K, x.stride(1), x.stride(0), seq_off, s_pad, kv_off, kv_rows,
@@ -328,22 +338,31 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scal
 def attention_segments(q: torch.Tensor, gathered: torch.Tensor, n_seg: int, skip_seg: int, seg_rows: int, kv_valid: int,
                        q_begin: int, q_end: int, state: Optional[torch.Tensor] = None, load_state: bool = False,
                        store_state: bool = False, out: Optional[torch.Tensor] = None, first_row: int = 0,
-                       used_rows: Optional[int] = None) -> Optional[torch.Tensor]:
+                       used_rows: Optional[int] = None, head0: int = 0, group_heads: int = 0) -> Optional[torch.Tensor]:
     """Attention of query rows [q_begin, q_end) over the key segments of an exchange buffer `gathered`
     [n_seg, 2, B, H, seg_rows*64] (per rank: K rows [B,H,seg_rows,64], then V^T [B,H,64,seg_rows]), skipping segment
-    skip_seg; of every segment the rows [first_row, first_row + used_rows) are keys; softmax scale folded into Q."""
+    skip_seg; of every segment the rows [first_row, first_row + used_rows) are keys; softmax scale folded into Q.
+    group_heads > 0: a HEAD WINDOW -- `gathered` holds group_heads heads ([n_seg, 2, B, group_heads, seg_rows*64]) and the launch
+    serves heads [head0, head0 + group_heads) of q / out / state (which keep all H heads)."""
     _dev(q, gathered, out, state)
     B, H, q_pad, dh = q.shape
+    Hl = group_heads or H
     assert dh == 64 and q.is_contiguous() and gathered.is_contiguous() and gathered.dtype == _BF16
-    assert gathered.numel() == n_seg * 2 * B * H * seg_rows * 64
+    assert gathered.numel() == n_seg * 2 * B * Hl * seg_rows * 64 and head0 + Hl <= H
     used_rows = seg_rows - first_row if used_rows is None else used_rows
     flags = (1 if load_state else 0) | (2 if store_state else 0)
     if flags:
         assert state is not None and state.dtype == _F32 and state.numel() * 4 >= _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)
     if not store_state:
         assert out is not None and out.stride(2) == 1 and out.stride(1) == H * 64 and out.shape[1] >= q_end
-    half = B * H * seg_rows * 64
+    half = B * Hl * seg_rows * 64
     base = gathered.data_ptr()
+    if group_heads:
+        _timed("attention", lambda: _lib.call("ea_attention_fwd_segments_heads_bf16", _p(q), ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * half),
+                                              _p(out), out.stride(0) if out is not None else 0, B, Hl, q_pad, q_begin, q_end, seg_rows,
+                                              n_seg, skip_seg, 2 * half, first_row, used_rows, kv_valid, FOLDED_ATTN_SCALE, _p(state),
+                                              flags, head0, H, 0, _stream()))
+        return out
     _timed("attention", lambda: _lib.call("ea_attention_fwd_segments_bf16", _p(q), ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * half),
                                           _p(out), out.stride(0) if out is not None else 0, B, H, q_pad, q_begin, q_end, seg_rows,
                                           n_seg, skip_seg, 2 * half, first_row, used_rows, kv_valid, FOLDED_ATTN_SCALE, _p(state),
@@ -423,18 +442,26 @@ def attention_state(B: int, H: int, q_begin: int, q_end: int, device) -> torch.T
 
 def attention_range(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float, q_begin: int, q_end: int,
                     kv_begin: int, kv_end: int, state: Optional[torch.Tensor] = None, load_state: bool = False,
-                    store_state: bool = False, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                    store_state: bool = False, out: Optional[torch.Tensor] = None, head0: int = 0) -> Optional[torch.Tensor]:
     """Attention over the key range [kv_begin, kv_end) for query rows [q_begin, q_end); `state` carries the
-    online-softmax state between calls.  out: bf16 [B, >= q_end, H*64] (written unless store_state)."""
+    online-softmax state between calls.  out: bf16 [B, >= q_end, H*64] (written unless store_state).
+    k / vt with fewer heads than q ([B, Hg, s_pad, 64] / [B, Hg, 64, s_pad]): a HEAD WINDOW -- the launch serves heads
+    [head0, head0 + Hg) of q / out / state (ea_attention_fwd_range_heads_bf16)."""
     _dev(q, k, vt, out, state)
     B, H, s_pad, dh = q.shape
-    assert dh == 64 and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    Hl = k.shape[1]
+    assert dh == 64 and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and head0 + Hl <= H and vt.shape[1] == Hl
     flags = (1 if load_state else 0) | (2 if store_state else 0)
     if flags:
         assert state is not None and state.dtype == _F32 and state.is_contiguous()
         assert state.numel() * 4 >= _lib.load().ea_attention_state_bytes(B, H, q_begin, q_end)
     if not store_state:
         assert out is not None and out.stride(2) == 1 and out.stride(1) == H * 64 and out.shape[1] >= q_end
+    if Hl != H:
+        _timed("attention", lambda: _lib.call("ea_attention_fwd_range_heads_bf16", _p(q), _p(k), _p(vt), _p(out),
+                                              out.stride(0) if out is not None else 0, B, Hl, s_pad, q_begin, q_end, kv_begin,
+                                              kv_end, float(scale), _p(state), flags, head0, H, 0, _stream()))
+        return out
     _timed("attention", lambda: _lib.call("ea_attention_fwd_range_bf16", _p(q), _p(k), _p(vt), _p(out),
                                           out.stride(0) if out is not None else 0, B, H, s_pad, q_begin, q_end, kv_begin,
                                           kv_end, float(scale), _p(state), flags, _stream()))

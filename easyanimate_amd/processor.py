@@ -194,6 +194,24 @@ class EasyAnimateAttnProcessor2_0:
                 return ops.attention(qf, kf, vf, T + Nt, ops.FOLDED_ATTN_SCALE)
             return self._head_parallel(ws, B, H, T, S, d, dev, lay, sp, full)
         o = torch.empty(B, S, d, dtype=torch.bfloat16, device=dev)
+        if lay is not None and sp.exchanges(lay) and ws.get("groups", 1) > 1:
+            # the exchange pipelined by head groups: own-slot pass of every group (its K / V^T are the group buffer's own slot), then
+            # per group: wait for ITS all-gather only, resume the state over the other ranks' slots of that group -- group g + 1 is
+            # still on the links while group g's remote pass runs
+            G, kvb = ws["groups"], ws["kv"]
+            Hg = H // G
+            state = _attention_state(B, H, S, dev)
+            for g in range(G):
+                k_g, vt_g = sp.slot_views(kvb[g])
+                for i, (lo, hi) in enumerate(lay.own_ranges):
+                    ops.attention_range(ws["q"], k_g, vt_g, ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
+                                        store_state=True, head0=g * Hg)
+            for g in range(G):
+                other = sp.exchange_finish(pending[g])
+                buf = other if other is not None else kvb[g]
+                ops.attention_segments(ws["q"], buf, sp.size, sp.rank, lay.rows, lay.remote_valid, 0, S, state=state, load_state=True,
+                                       out=o, first_row=lay.t_pad, used_rows=lay.n_loc, head0=g * Hg, group_heads=Hg)
+            return o
         if lay is not None and sp.exchanges(lay):
             # sequence-parallel: attend the OWN slot (text + own shard) while the in-place K / V^T all-gather is in flight,
             # then resume the online-softmax state over the other ranks' slots where the all-gather left them
@@ -263,9 +281,16 @@ class EasyAnimateAttnProcessor2_0:
             # per-rank rows: [text | gap | own shard]; K / V^T live in the rank's slot of the exchange buffer
             lay = sp.layout(T, N)
             S, v_off = lay.q_end, lay.t_pad
-            kvb = sp.kv_buffer(B, H, lay, dev)
-            k_own, vt_own = sp.slot_views(kvb)
-            ws = dict(q=_workspace_q(B, H, lay.q_pad, dev), k=k_own, vt=vt_own, kv=kvb)
+            # head groups of the pipelined K / V^T exchange (sequence_parallel.SequenceParallel.groups): the projections must be able to
+            # write K / V^T group-wise, which the fused QKV launch does (bf16 weights, both streams on it); otherwise one group
+            G = 1
+            if (sp.exchanges(lay) and lay.bringup_ranges is None and self.exchange_in_attend is False and not self._heads_mode(lay, sp, H)
+                    and self.fuse_qkv and ops.qkv_fused_ok(T, d, d, 0) and ops.qkv_fused_ok(N, d, d, lay.t_pad)
+                    and all(gemm_weight(m.weight).dtype == torch.bfloat16 for a_ in (attn, tattn) for m in (a_.to_q, a_.to_k, a_.to_v))):
+                G = sp.head_groups(H)
+            kvb = sp.kv_buffer(B, H, lay, dev, groups=G) if G > 1 else sp.kv_buffer(B, H, lay, dev)
+            k_own, vt_own = sp.slot_views(kvb[0] if G > 1 else kvb)      # (G > 1: group 0's own slot; group g is kvb.stride(0) * g further on)
+            ws = dict(q=_workspace_q(B, H, lay.q_pad, dev), k=k_own, vt=vt_own, kv=kvb, groups=G, gstride=kvb.stride(0) if G > 1 else 0)
         else:
             S = T + N
             s_pad, v_off = ops.round_up(S, 256), T
@@ -280,6 +305,11 @@ class EasyAnimateAttnProcessor2_0:
         exchange = lay is not None and sp.exchanges(lay)
         pending = None
 
+        def start_exchange_now():
+            # one all-gather per head group, posted back to back (one group: the single all-gather of the whole buffer)
+            G_ = ws.get("groups", 1)
+            return [sp.exchange_start(ws["kv"][g]) for g in range(G_)] if G_ > 1 else sp.exchange_start(ws["kv"])
+
         def qkv_stream(inp, mod, n_tok, seq_off, c, s_, start_exchange=False):
             """rows [seq_off, seq_off + n_tok) of q (workspace) and of K / V^T (workspace, or the rank's exchange slot: the
             row numbering is the same).  start_exchange: the K / V^T all-gather starts as soon as K | V exist."""
@@ -293,12 +323,13 @@ class EasyAnimateAttnProcessor2_0:
                 args = (inp, gemm_weight(lq.weight), gemm_weight(lk.weight), gemm_weight(lv.weight),
                         f32(lq.bias), f32(lk.bias), f32(lv.bias), ws["q"], ws["k"], ws["vt"],
                         f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias), c, s_, seq_off, nq.eps)
+                gs = ws.get("gstride", 0)
                 if start_exchange and self.kv_first:
-                    ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE, parts=ops.QKV_KV)
-                    pending = sp.exchange_start(ws["kv"])
-                    ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE, parts=ops.QKV_Q)
+                    ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE, parts=ops.QKV_KV, kv_group_stride=gs)
+                    pending = start_exchange_now()
+                    ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE, parts=ops.QKV_Q, kv_group_stride=gs)
                     return
-                ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE)
+                ops.qkv_gemm_norm_rope(*args, q_scale=ops.FOLDED_Q_SCALE, kv_group_stride=gs)
             else:
                 # three GEMMs into one [B, n, 3d] buffer, then one normalise / rotate / scatter pass
                 qkv = torch.empty(B, n_tok, 3 * d, dtype=torch.bfloat16, device=dev)
@@ -307,7 +338,7 @@ class EasyAnimateAttnProcessor2_0:
                 ops.qknorm_rope(qkv, ws["q"], ws["k"], ws["vt"], f32(nq.weight), f32(nq.bias), f32(nk.weight), f32(nk.bias),
                                 c, s_, seq_off, nq.eps, q_scale=ops.FOLDED_Q_SCALE)
             if start_exchange:
-                pending = sp.exchange_start(ws["kv"])
+                pending = start_exchange_now()
 
         qkv_stream(e, tattn, T, 0, None, None)      # text rows: no RoPE
         qkv_stream(x, attn, N, v_off, cos, sin,

@@ -121,6 +121,10 @@ class SequenceParallel:
         self.inplace = os.environ.get("EA_SP_INPLACE", "1") != "0"
         self._inplace_checked = False
         self._recv = None
+        # EA_SP_GROUPS (mode "keys"): the K / V^T exchange of a block runs as this many all-gathers, one per HEAD GROUP, posted
+        # back to back; the remote attention pass of group g starts when group g has arrived, while the later groups are still on
+        # the links -- the exposed link time drops from (t_link - t_cover) to (t_link / G - t_cover).  1 = one all-gather per block.
+        self.groups = max(1, int(os.environ.get("EA_SP_GROUPS", "2")))
         # bench.py: HIP events around every point where the compute stream waits for a collective (profile_wait = True)
         self.profile_wait = False
         self._waits = []
@@ -214,13 +218,20 @@ class SequenceParallel:
         """Does a block of this layout exchange K / V^T (more than one sequence rank, or the bring-up mode)?"""
         return self.size > 1 or lay.bringup_ranges is not None
 
-    def kv_buffer(self, B: int, H: int, lay: Layout, device, dtype=torch.bfloat16) -> torch.Tensor:
+    def head_groups(self, H: int) -> int:
+        """Head groups of the pipelined K / V^T exchange for a block with H heads (1: not pipelined)."""
+        g = self.groups
+        return g if (g > 1 and self.size > 1 and H % g == 0) else 1
+
+    def kv_buffer(self, B: int, H: int, lay: Layout, device, dtype=torch.bfloat16, groups: int = 1) -> torch.Tensor:
         """The exchange buffer [P, 2, B, H, rows * 64], zero-initialised ONCE and kept (one live shape): rows nobody writes --
         the gap behind unaligned text, the tail of a short last shard -- stay zero (the attention kernel masks them as keys
-        but needs a finite V^T there)."""
-        key = (self.size, B, H, lay.rows, str(device), dtype)
+        but needs a finite V^T there).  groups > 1: [G, P, 2, B, H / G, rows * 64] -- every buf[g] is a complete exchange buffer
+        of its own for the heads [g H / G, (g + 1) H / G) (slot_views / exchange_start / exchange_finish take buf[g])."""
+        key = (self.size, B, H, lay.rows, str(device), dtype, groups)
         if self._kv is None or self._kv[0] != key:
-            self._kv = (key, torch.zeros((self.size, 2, B, H, lay.rows * 64), dtype=dtype, device=device))
+            shape = (self.size, 2, B, H, lay.rows * 64) if groups == 1 else (groups, self.size, 2, B, H // groups, lay.rows * 64)
+            self._kv = (key, torch.zeros(shape, dtype=dtype, device=device))
         return self._kv[1]
 
     def slot_views(self, buf: torch.Tensor, rank: Optional[int] = None):
@@ -252,10 +263,14 @@ class SequenceParallel:
         if not self.inplace:
             # EA_SP_INPLACE=0 -- the out-of-place form of the same exchange (a second buffer of the same shape receives every
             # slot; the remote pass reads THAT one): the fallback if the in-place collective misbehaves on some RCCL build
-            if self._recv is None or self._recv.shape != buf.shape or self._recv.device != buf.device:
-                self._recv = torch.empty_like(buf)
-            work = dist.all_gather_into_tensor(self._recv.view(-1), own, group=self.axis.group, async_op=True)
-            return (work, self._recv)
+            # (one receive buffer per exchange buffer: with head groups several gathers are in flight at once)
+            if self._recv is None:
+                self._recv = {}
+            rk = (buf.data_ptr(), tuple(buf.shape), str(buf.device))
+            if rk not in self._recv:
+                self._recv[rk] = torch.empty_like(buf)
+            work = dist.all_gather_into_tensor(self._recv[rk].view(-1), own, group=self.axis.group, async_op=True)
+            return (work, self._recv[rk])
         if self.size > 1 and not self._inplace_checked:
             # first exchange of the process: the in-place form (input = the rank's slot of the output, sendbuff == recvbuff +
             # rank * count as NCCL's in-place all-gather requires) is checked ONCE against an out-of-place gather of the same slots
@@ -370,6 +385,7 @@ class EmulatedRank(SequenceParallel):
         self.profile_wait = False
         self._waits = []
         self.inplace, self._inplace_checked, self._recv = True, True, None
+        self.groups = max(1, int(os.environ.get("EA_SP_GROUPS", "2")))
 
     # head-parallel blocks (EA_SP_MODE=heads, sliding-window blocks): the rank receives what it sent -- its own rows stand in
     # for every peer's (same size, same statistics); no link time in the model
@@ -379,12 +395,16 @@ class EmulatedRank(SequenceParallel):
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
         return x[None].expand((self.size,) + tuple(x.shape))
 
-    def kv_buffer(self, B: int, H: int, lay: Layout, device, dtype=torch.bfloat16) -> torch.Tensor:
-        key = (self.size, B, H, lay.rows, str(device), dtype)
+    def kv_buffer(self, B: int, H: int, lay: Layout, device, dtype=torch.bfloat16, groups: int = 1) -> torch.Tensor:
+        key = (self.size, B, H, lay.rows, str(device), dtype, groups)
         if self._kv is None or self._kv[0] != key:
             # the remote slots: N(0,1) keys / values, written once (zeros would run at a higher clock); own slot zero
-            buf = torch.randn((self.size, 2, B, H, lay.rows * 64), device=device).to(dtype)
-            buf[self.rank].zero_()
+            if groups == 1:
+                buf = torch.randn((self.size, 2, B, H, lay.rows * 64), device=device).to(dtype)
+                buf[self.rank].zero_()
+            else:
+                buf = torch.randn((groups, self.size, 2, B, H // groups, lay.rows * 64), device=device).to(dtype)
+                buf[:, self.rank].zero_()
             self._kv = (key, buf)
             self._scratch = None
         return self._kv[1]

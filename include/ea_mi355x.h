@@ -183,6 +183,20 @@ int ea_qkv_gemm_norm_rope_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf1
                                const float* nk_b, const float* cos, const float* sin, int batch, int M, int heads,
                                int K, int64_t lda, int64_t a_batch_stride, int seq_off, int s_pad, int kv_off,
                                int kv_rows, int parts, float ln_eps, float q_scale, void* stream);
+
+/* The same launch with K / V^T written in HEAD GROUPS (round 5: the sequence-parallel exchange pipelined by head groups,
+ * easyanimate_amd/sequence_parallel.py): head h of batch element b lands in group g = h / kv_group_heads at
+ * k_out + g * kv_group_stride + ((b * kv_group_heads + h % kv_group_heads) * kv_rows + kv_off + row) * 64 (vt_out likewise with
+ * [64, kv_rows] per head), i.e. every group is its own [batch, kv_group_heads, kv_rows, 64] buffer kv_group_stride elements
+ * after the previous one -- one contiguous all-gather operand per group.  q_out is unchanged ([batch, heads, s_pad, 64]).
+ * kv_group_heads must divide heads; kv_group_heads = heads, kv_group_stride = 0 is ea_qkv_gemm_norm_rope_bf16. */
+int ea_qkv_gemm_norm_rope_grouped_bf16(const ea_bf16* A, const ea_bf16* Wq, const ea_bf16* Wk, const ea_bf16* Wv,
+                                       const float* bq, const float* bk, const float* bv, ea_bf16* q_out,
+                                       ea_bf16* k_out, ea_bf16* vt_out, const float* nq_w, const float* nq_b,
+                                       const float* nk_w, const float* nk_b, const float* cos, const float* sin,
+                                       int batch, int M, int heads, int K, int64_t lda, int64_t a_batch_stride,
+                                       int seq_off, int s_pad, int kv_off, int kv_rows, int parts, int kv_group_heads,
+                                       int64_t kv_group_stride, float ln_eps, float q_scale, void* stream);
 /* ... with the three weights stored as fp8 (see ea_gemm_bf16_w8): bit-identical to ea_qkv_gemm_norm_rope_bf16 on the up-cast weights. */
 int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq_fp8, const uint8_t* Wk_fp8, const uint8_t* Wv_fp8,
                                   const float* bq, const float* bk, const float* bv, ea_bf16* q_out, ea_bf16* k_out,
@@ -219,6 +233,17 @@ int ea_attention_fwd_segments_bf16(const ea_bf16* q, const ea_bf16* k_seg0, cons
                                    int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin, int q_end,
                                    int seg_rows, int n_seg, int skip_seg, int64_t seg_stride, int seg_first_row,
                                    int seg_used_rows, int kv_valid, float scale, float* state, int flags, void* stream);
+
+/* ea_attention_fwd_segments_bf16 over a HEAD WINDOW: the launch covers heads [q_head0, q_head0 + heads) of q / out / state, which
+ * are laid out over q_heads heads per batch element (q: [batch, q_heads, q_pad, 64], out rows of q_heads * 64 columns, the state
+ * of ea_attention_state_bytes(batch, q_heads, ..)), while the segments hold K / V^T of those `heads` heads only
+ * ([batch, heads, seg_rows, 64] per segment, kv_batch_stride elements between batch elements; 0 = heads * seg_rows * 64).  One
+ * call per head group of the pipelined sequence-parallel exchange; q_heads = 0 (then q_head0 = 0) is the plain call. */
+int ea_attention_fwd_segments_heads_bf16(const ea_bf16* q, const ea_bf16* k_seg0, const ea_bf16* vt_seg0, ea_bf16* out,
+                                         int64_t out_batch_stride, int batch, int heads, int q_pad, int q_begin, int q_end,
+                                         int seg_rows, int n_seg, int skip_seg, int64_t seg_stride, int seg_first_row,
+                                         int seg_used_rows, int kv_valid, float scale, float* state, int flags,
+                                         int q_head0, int q_heads, int64_t kv_batch_stride, void* stream);
 
 /* Single-head, head_dim 512 flash attention of the VAE mid block (vaemodules/attention.py:391-423 SpatialAttention with
  * attention_processors.py:76-139: per latent frame softmax(Q K^T * scale) V over all H x W tokens of the frame, one head of
@@ -274,6 +299,13 @@ int ea_attention_fwd_range_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf1
                                 int64_t out_batch_stride, int batch, int heads, int s_pad, int q_begin,
                                 int q_end, int kv_begin, int kv_end, float scale, float* state, int flags,
                                 void* stream);
+
+/* ea_attention_fwd_range_bf16 over a head window (see ea_attention_fwd_segments_heads_bf16): k / vt are
+ * [batch, heads, s_pad, 64] / [batch, heads, 64, s_pad] of the window's heads (kv_batch_stride elements between batch elements). */
+int ea_attention_fwd_range_heads_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out,
+                                      int64_t out_batch_stride, int batch, int heads, int s_pad, int q_begin, int q_end,
+                                      int kv_begin, int kv_end, float scale, float* state, int flags, int q_head0, int q_heads,
+                                      int64_t kv_batch_stride, void* stream);
 
 /* ---- latent-space elementwise ---------------------------------------------------------------- */
 

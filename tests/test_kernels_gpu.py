@@ -1258,3 +1258,81 @@ def test_qkv_fused_w4a_bit_identical_to_the_eight_wave_kernel(B, H, M, K, seq_of
     assert torch.isfinite(q[:, :, seq_off:seq_off + M].float()).all()
     assert (q[:, :, :seq_off] == 7).all() and (q[:, :, seq_off + M:] == 7).all()
     assert (k[:, :, :kv_off] == 7).all() and (k[:, :, kv_off + M:] == 7).all() and (vt[:, :, :, :kv_off] == 7).all() and (vt[:, :, :, kv_off + M:] == 7).all()
+
+
+# ---- round 5: head groups of the pipelined sequence-parallel exchange ------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,G,T,nl,P", [(1, 8, 2, 64, 192, 3), (2, 12, 3, 128, 128, 2), (1, 48, 2, 256, 320, 4)])
+def test_attention_head_window_equals_full_launch(B, H, G, T, nl, P):
+    """ea_attention_fwd_range_heads_bf16 / ea_attention_fwd_segments_heads_bf16: G launches over head windows, each with the K / V^T of
+    its own head group only ([.., H / G, ..] buffers), against one launch over all heads on the un-grouped buffers: the same
+    tiles in the same order per head -> out and the carried state bit-identical (own-slot pass with stored state, remote pass
+    over P - 1 segments resuming it)."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(5 + H + P)
+    rows = ops.round_up(T + nl, 256)
+    S_q = T + nl
+    rank = 1
+    q = torch.zeros(B, H, rows, 64, dtype=torch.bfloat16, device=DEV)
+    q[:, :, :S_q] = _bf(torch.randn(B, H, S_q, 64, generator=g) * 0.3).to(DEV)
+    buf = torch.zeros(P, 2, B, H, rows * 64, dtype=torch.bfloat16, device=DEV)
+    for r in range(P):
+        buf[r, 0].view(B, H, rows, 64)[:, :, :S_q] = _bf(torch.randn(B, H, S_q, 64, generator=g)).to(DEV)
+        buf[r, 1].view(B, H, 64, rows)[:, :, :, :S_q] = _bf(torch.randn(B, H, 64, S_q, generator=g)).to(DEV)
+    Hg = H // G
+    bufg = torch.zeros(G, P, 2, B, Hg, rows * 64, dtype=torch.bfloat16, device=DEV)
+    for gi in range(G):
+        bufg[gi] = buf.view(P, 2, B, G, Hg, rows * 64)[:, :, :, gi]
+    remote_valid = (P - 1) * nl
+    st_a, st_b = ops.attention_state(B, H, 0, S_q, DEV), ops.attention_state(B, H, 0, S_q, DEV)
+    o_a, o_b = (torch.full((B, S_q, H * 64), 7.0, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    k_own, vt_own = buf[rank, 0].view(B, H, rows, 64), buf[rank, 1].view(B, H, 64, rows)
+    ops.attention_range(q, k_own, vt_own, ops.FOLDED_ATTN_SCALE, 0, S_q, 0, S_q, state=st_a, store_state=True)
+    ops.attention_segments(q, buf, P, rank, rows, remote_valid, 0, S_q, state=st_a, load_state=True, out=o_a, first_row=T, used_rows=nl)
+    for gi in range(G):
+        kg, vg = bufg[gi, rank, 0].view(B, Hg, rows, 64), bufg[gi, rank, 1].view(B, Hg, 64, rows)
+        ops.attention_range(q, kg, vg, ops.FOLDED_ATTN_SCALE, 0, S_q, 0, S_q, state=st_b, store_state=True, head0=gi * Hg)
+    torch.cuda.synchronize()
+    assert torch.equal(st_a, st_b)
+    for gi in range(G):
+        ops.attention_segments(q, bufg[gi], P, rank, rows, remote_valid, 0, S_q, state=st_b, load_state=True, out=o_b, first_row=T, used_rows=nl,
+                               head0=gi * Hg, group_heads=Hg)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o_b.float()).all() and torch.equal(o_a, o_b)
+
+
+@pytest.mark.parametrize("B,H,G,M,K,seq_off", [(2, 8, 2, 512, 128, 64), (1, 48, 2, 1283, 256, 256), (2, 12, 3, 768, 64, 0)])
+def test_qkv_grouped_destination(B, H, G, M, K, seq_off):
+    """ea_qkv_gemm_norm_rope_grouped_bf16: K / V^T written per head group into [G, .., B, H / G, rows, 64] buffers (the own slots of
+    the group-wise exchange buffers) against the un-grouped launch: bit-identical values at the grouped addresses, q unchanged,
+    nothing else written; both launch forms (one launch; K | V then Q)."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(61 + H)
+    d = H * 64
+    x = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+    ws = [_bf(torch.randn(d, K, generator=g) / K ** 0.5).to(DEV) for _ in range(3)]
+    bs = [(0.3 * torch.randn(d, generator=g)).to(DEV) for _ in range(3)]
+    n4 = [(1 + 0.2 * torch.randn(64, generator=g)).to(DEV), (0.2 * torch.randn(64, generator=g)).to(DEV),
+          (1 + 0.2 * torch.randn(64, generator=g)).to(DEV), (0.2 * torch.randn(64, generator=g)).to(DEV)]
+    ang = torch.rand(M, 32, generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).contiguous().to(DEV), ang.sin().repeat_interleave(2, 1).contiguous().to(DEV)
+    kv_off = seq_off + 64
+    s_pad, kv_rows = ops.round_up(seq_off + M, 256), ops.round_up(kv_off + M + 64, 256)
+    full = lambda *shape: torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
+    q0, k0, vt0 = full(B, H, s_pad, 64), full(B, H, kv_rows, 64), full(B, H, 64, kv_rows)
+    ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q0, k0, vt0, n4[0], n4[1], n4[2], n4[3], cos, sin, seq_off, 1e-6,
+                           q_scale=ops.FOLDED_Q_SCALE, kv_off=kv_off)
+    Hg, P, rank = H // G, 3, 1
+    for split in (False, True):
+        q1 = full(B, H, s_pad, 64)
+        kvg = full(G, P, 2, B, Hg, kv_rows * 64)                 # group-wise exchange buffers; the launch writes into slot `rank` of each
+        k_own, vt_own = kvg[0, rank, 0].view(B, Hg, kv_rows, 64), kvg[0, rank, 1].view(B, Hg, 64, kv_rows)
+        for parts in ((ops.QKV_KV, ops.QKV_Q) if split else (ops.QKV_ALL,)):
+            ops.qkv_gemm_norm_rope(x, ws[0], ws[1], ws[2], bs[0], bs[1], bs[2], q1, k_own, vt_own, n4[0], n4[1], n4[2], n4[3], cos, sin, seq_off, 1e-6,
+                                   q_scale=ops.FOLDED_Q_SCALE, kv_off=kv_off, parts=parts, kv_group_stride=kvg.stride(0))
+        torch.cuda.synchronize()
+        assert torch.equal(q1, q0)
+        for gi in range(G):
+            kg, vg = kvg[gi, rank, 0].view(B, Hg, kv_rows, 64), kvg[gi, rank, 1].view(B, Hg, 64, kv_rows)
+            assert torch.equal(kg, k0[:, gi * Hg:(gi + 1) * Hg]) and torch.equal(vg, vt0[:, gi * Hg:(gi + 1) * Hg])
+        others = [r for r in range(P) if r != rank]
+        assert (kvg[:, others] == 7).all()

@@ -284,3 +284,55 @@ def test_layout_invariants_over_random_shapes():
             assert all(shards[i][1] == shards[i + 1][0] for i in range(len(shards) - 1))
             assert all(hi - lo == shards[0][1] - shards[0][0] for lo, hi in shards[:-1]) and 0 < shards[-1][1] - shards[-1][0]
     check()
+
+
+def _worker_groups(rank, world, port, cfg_parallel, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easyanimate_amd.sequence_parallel import SequenceParallel
+        torch.manual_seed(0)
+        sp = SequenceParallel(cfg_parallel=cfg_parallel)
+        sp.groups = 3
+        B, H, T, N = 2, 6, 64, 700
+        b0, b1 = sp.begin(B)
+        Bl = b1 - b0
+        sp.plan(N)
+        lo, hi = sp.shard_range()
+        lay = sp.layout(T, hi - lo)
+        assert sp.head_groups(H) == (3 if sp.size > 1 else 1) and sp.head_groups(4) == 1      # 4 heads do not split into 3 groups
+        G = 3
+        buf = sp.kv_buffer(Bl, H, lay, "cpu", torch.float32, groups=G)
+        assert buf.shape == (G, sp.size, 2, Bl, H // G, lay.rows * 64) and sp.kv_buffer(Bl, H, lay, "cpu", torch.float32, groups=G) is buf
+        # every rank writes a value that names (group, rank, K / V^T, batch, head) into its own slots, group by group
+        gen = lambda g, r: (torch.arange(2 * Bl * (H // G), dtype=torch.float32).view(2, Bl, H // G, 1) + 1000 * g + 100 * r + 0.5).expand(2, Bl, H // G, lay.rows * 64)
+        for g in range(G):
+            k_own, vt_own = sp.slot_views(buf[g])
+            assert k_own.shape == (Bl, H // G, lay.rows, 64) and k_own.data_ptr() == buf[g, sp.rank, 0].data_ptr()
+            buf[g, sp.rank].copy_(gen(g, sp.rank))
+        pend = [sp.exchange_start(buf[g]) for g in range(G)]          # posted back to back ...
+        for g in (2, 0, 1):                                          # ... and finished in any order, each on its own
+            sp.exchange_finish(pend[g])
+            for r in range(sp.size):
+                assert torch.equal(buf[g, r], gen(g, r)), (g, r)
+        # EA_SP_INPLACE=0: one receive buffer per group
+        sp.inplace = False
+        ok = True
+        if sp.size > 1:
+            pend = [sp.exchange_start(buf[g]) for g in range(G)]
+            outs = [sp.exchange_finish(p) for p in pend]
+            ok = all(o is None for o in outs) or (len({o.data_ptr() for o in outs}) == G and all(torch.equal(o[r], gen(g, r)) for g, o in enumerate(outs) for r in range(sp.size)))
+        ret[rank] = (sp.size, ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cfg_parallel", [(2, False), (3, False), (4, True)])
+def test_grouped_exchange_buffers(world, cfg_parallel):
+    """EA_SP_GROUPS: the exchange buffer split by head groups ([G, P, 2, B, H / G, rows * 64]) -- every buf[g] is a complete exchange
+    buffer of its own: own-slot views, G all-gathers in flight at once, finished independently, every slot of every group filled
+    with its owner's data; one receive buffer per group in the out-of-place form."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_groups, args=(world, _free_port(), cfg_parallel, ret), nprocs=world, join=True)
+    assert len(ret) == world and all(ret[r][1] for r in range(world)), dict(ret)
