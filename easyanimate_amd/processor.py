@@ -207,7 +207,7 @@ class EasyAnimateAttnProcessor2_0:
                     ops.attention_range(ws["q"], k_g, vt_g, ops.FOLDED_ATTN_SCALE, 0, S, lo, hi, state=state, load_state=i > 0,
                                         store_state=True, head0=g * Hg)
             for g in range(G):
-                other = sp.exchange_finish(pending[g])
+                other = sp.exchange_finish(pending[g], kind=f"kv_all_gather_wait_g{g}")
                 buf = other if other is not None else kvb[g]
                 ops.attention_segments(ws["q"], buf, sp.size, sp.rank, lay.rows, lay.remote_valid, 0, S, state=state, load_state=True,
                                        out=o, first_row=lay.t_pad, used_rows=lay.n_loc, head0=g * Hg, group_heads=Hg)

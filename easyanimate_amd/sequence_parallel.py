@@ -288,11 +288,12 @@ class SequenceParallel:
         work = dist.all_gather_into_tensor(buf.view(-1), own, group=self.axis.group, async_op=True)
         return (work,)
 
-    def exchange_finish(self, handle) -> Optional[torch.Tensor]:
+    def exchange_finish(self, handle, kind: str = "kv_all_gather_wait") -> Optional[torch.Tensor]:
         """Wait for the all-gather (a stream-level wait with RCCL): the remote slots are then readable in place.  Returns the
-        buffer the remote slots are in when that is not the exchange buffer itself (EA_SP_INPLACE=0), else None."""
+        buffer the remote slots are in when that is not the exchange buffer itself (EA_SP_INPLACE=0), else None.  `kind` names the
+        wait in the exposed-wait report (head groups: kv_all_gather_wait_g<g>)."""
         if handle is not None:
-            self._timed_wait("kv_all_gather_wait", handle[0].wait if handle[0] is not None else (lambda: None), "cuda")
+            self._timed_wait(kind, handle[0].wait if handle[0] is not None else (lambda: None), "cuda")
             if len(handle) > 1:
                 return handle[1]
         return None
@@ -431,9 +432,9 @@ class EmulatedRank(SequenceParallel):
             ev.record(self._side)
         return (ev,)
 
-    def exchange_finish(self, handle) -> None:
+    def exchange_finish(self, handle, kind: str = "kv_all_gather_wait") -> None:
         if handle is not None and handle[0] is not None:
-            torch.cuda.current_stream().wait_event(handle[0])
+            self._timed_wait(kind, lambda: torch.cuda.current_stream().wait_event(handle[0]), "cuda")
         return None
 
     def all_reduce_sums(self, sums: torch.Tensor, n: int):
