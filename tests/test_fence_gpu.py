@@ -12,7 +12,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GUARDED = os.path.join(ROOT, "tools", "guarded.py")
-SELECTION = "permute_cols or swa_window_mapped or attention_window or segments or exchange_slot or kblocked_ffn_pair"
+SELECTION = ("permute_cols or swa_window_mapped or attention_window or segments or exchange_slot or kblocked_ffn_pair or "
+             "gemm_w4a or qkv_fused_w4a or head_window or grouped_destination")       # round 5: the hand-placed kernels and the head groups
 
 
 def _run(args, env=None, timeout=600):
@@ -30,6 +31,14 @@ def test_kernels_behind_the_fence(mode):
     assert r.returncode == 0, tail
     assert "passed" in r.stdout and "slack_hits=0" in r.stderr
     assert "Memory access fault" not in r.stderr and "OUT-OF-BOUNDS" not in r.stderr
+
+
+def test_conv_w4a_behind_the_fence():
+    """The four-wave row-slab convolutions (buffer-addressed slab requests, zero padding by the descriptor's range check)."""
+    r = _run(["-m", "pytest", "tests/test_vae_gpu.py", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x", "-k", "conv_w4a"])
+    tail = (r.stdout[-1500:] + r.stderr[-1500:])
+    print(f"[fence] conv w4a: rc {r.returncode}\n{tail}")
+    assert r.returncode == 0 and "passed" in r.stdout and "slack_hits=0" in r.stderr and "Memory access fault" not in r.stderr, tail
 
 
 def test_fence_positive_control():
