@@ -373,6 +373,7 @@ def main():
                        "devices": sorted(set(gathered_devices)), "launched_by": os.environ.get("TORCHELASTIC_RUN_ID", "external")}
         out["rank_agreement"] = len({r["latents_sha1"] for r in rank_reports}) == 1
         out["exchange"] = {"mode": model.sequence_parallel.mode,
+                           "head_groups": model.sequence_parallel.head_groups(H) if model.sequence_parallel.mode == "keys" else 1,
                            "what": "per rank: time the compute stream spent between two HIP events around each wait for a collective "
                                    "(the EXPOSED part of the exchange), per denoise step; step_ms = the rank's own wall time per step",
                            "per_rank": [{k: v for k, v in r.items() if k != "latents_sha1"} for r in rank_reports]}
@@ -385,6 +386,7 @@ def main():
                                    + (" -- except that the bytes of the K / V^T all-gather are moved device-to-device on a side stream "
                                       "under the own-slot pass (--emulate-exchange)" if args.emulate_exchange else ""),
                            "exchange_emulated": bool(args.emulate_exchange),
+                           "head_groups": model.sequence_parallel.head_groups(H) if model.sequence_parallel.mode == "keys" else 1,
                            "speedup_upper_bound_needs": "T_1 / this ms_per_step, T_1 from the plain N=1 run of the same session"}
         out["config"]["step_mfma_frac"] = flop_step * K / elapsed / (PEAK_BF16_TFLOPS * 1e12 * P)
     if rank == 0 and world == 1 and not args.no_vae and args.config == "c3":

@@ -39,8 +39,9 @@ def main():
         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
         "algorithmic_bytes_per_launch": 4 * B * H * S * 64 * 2,
     }
-    p = os.path.join(ROOT, "profiles", "attention_hbm_bytes_per_launch.json")
-    json.dump(out, open(p, "w"), indent=1)
+    # profiles/ is where bench.py reads it; the copy in the run directory is what travels back from the GPU box (gpurun_out/)
+    for p in (os.path.join(ROOT, "profiles", "attention_hbm_bytes_per_launch.json"), os.path.join(d, "attention_hbm_bytes_per_launch.json")):
+        json.dump(out, open(p, "w"), indent=1)
     print(json.dumps(out))
 
 
