@@ -1838,12 +1838,12 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
                     attr6_done = true;
                 }
                 if (k32_128) {
+                    ea_count("conv_w4a");            // (marker first: ea_last_dispatch() names the kernel family, as before)
                     ea_count("conv_row16_m512");
-                    ea_count("conv_w4a");
                     hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<128, 512>), dim3((unsigned)grid5), dim3(256), 100 * 1024, (hipStream_t)stream, p);
                 } else {
-                    ea_count("conv_row16_256_k32");
                     ea_count("conv_w4a");
+                    ea_count("conv_row16_256_k32");
                     hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<256, 256>), dim3((unsigned)grid5), dim3(256), 112 * 1024, (hipStream_t)stream, p);
                 }
                 return ea_check_launch("ea_conv3d_cl_bf16");

@@ -1438,16 +1438,17 @@ int qkv_entry(const ea_bf16* A, const void* Wq, const void* Wk, const void* Wv,
         hipFuncSetAttribute((const void*)gemm256_qkv_kernel<W8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
         attr_done = true;
     }
-    ea_count(W8 ? "gemm_qkv_fused_w8" : "gemm_qkv_fused");
-    if (parts != 7) ea_count(parts == 6 ? "gemm_qkv_fused_kv_part" : "gemm_qkv_fused_q_part");
     // the four-wave hand-placed main loop (32-bit buffer offsets: a 256-row tile of A / W must be reachable within 4 GiB)
-    if (!W8 && (g_gemm_w4a & 2) && (255 * lda + K) * 2 < (int64_t)0xFFFFFFFF && (int64_t)256 * K * 2 < (int64_t)0xFFFFFFFF) {
+    const bool qkv_w4a = !W8 && (g_gemm_w4a & 2) && (255 * lda + K) * 2 < (int64_t)0xFFFFFFFF && (int64_t)256 * K * 2 < (int64_t)0xFFFFFFFF;
+    if (qkv_w4a) ea_count("gemm_qkv_fused_w4a");       // (markers first: ea_last_dispatch() stays "gemm_qkv_fused")
+    if (parts != 7) ea_count(parts == 6 ? "gemm_qkv_fused_kv_part" : "gemm_qkv_fused_q_part");
+    ea_count(W8 ? "gemm_qkv_fused_w8" : "gemm_qkv_fused");
+    if (qkv_w4a) {
         static bool attrw4_done = false;
         if (!attrw4_done) {
             hipFuncSetAttribute((const void*)gemm256_qkv_w4a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
             attrw4_done = true;
         }
-        ea_count("gemm_qkv_fused_w4a");
         hipLaunchKernelGGL(gemm256_qkv_w4a_kernel, grid, dim3(256), GEMM2_LDS, (hipStream_t)stream, q);
         return ea_check_launch("ea_qkv_gemm_norm_rope_bf16");
     }

@@ -4,7 +4,6 @@ with the build it was measured on.  bench.py prints `roofline.traffic` only whil
 
     python tools/update_traffic_json.py gpurun_out/prof_<tag> <tag>
 """
-import csv
 import datetime
 import json
 import os
@@ -14,9 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_launch(path, prefix):
-    for row in csv.DictReader(open(path)):
-        if row["kernel"].startswith(prefix):
-            return float(row["avg_per_dispatch"]), int(row["dispatches"])
+    # kernel,counter,dispatches,sum,avg_per_dispatch,min,max -- the kernel name itself contains commas (template arguments)
+    for line in open(path).read().splitlines()[1:]:
+        if line.startswith(prefix):
+            f = line.rsplit(",", 6)
+            return float(f[4]), int(f[2])
     raise SystemExit(f"{path}: no kernel starting with {prefix}")
 
 
