@@ -24,6 +24,11 @@ Structure (one wave per SIMD, 128 x 128 wave tile = 8 x 8 MFMA tiles of 16x16x32
   vmcnt bookkeeping stays uniform)."""
 import os
 
+# schedule experiments (the committed .inc is generated with the defaults): EA_W4A_TOP=prog -> progressive lgkmcnt waits in front of
+# the first eight MFMAs of a tile instead of one full drain; EA_W4A_BAR1=<slot> -> the "W(t) consumed" barrier (default 20)
+TOP_PROG = os.environ.get("EA_W4A_TOP", "drain") == "prog"
+BAR1 = int(os.environ.get("EA_W4A_BAR1", "20"))
+
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "easyanimate_amd", "csrc", "ea_gemm_w4_loop.inc")
 
 # fixed registers
@@ -78,9 +83,9 @@ def schedule():
     for x in range(8):                                   # W k-step 1 of tile t
         s[1 + 2 * x].append(rd("w", 1, x, "wk1"))
     s[17].append(f"v_xor_b32 v{ADDR['wk1']}, 0x8000, v{ADDR['wk1']}")     # -> the other stage, for the next tile
-    s[20] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
-    s[21].append(m0_first("w"))
-    w_slots = [23, 26, 29, 32, 35, 53, 56, 59]
+    s[BAR1] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    s[BAR1 + 1].append(m0_first("w"))
+    w_slots = [BAR1 + 3, BAR1 + 6, BAR1 + 9, BAR1 + 12, BAR1 + 15, 53, 56, 59]
     for x, n in enumerate(w_slots):                       # W(t+2)
         s[n].append(dma("w", x))
         if x < 7:
@@ -197,8 +202,13 @@ def loop_body(s, swap):
     B(f"s_cmp_gt_u32 s{S_LEFT}, 2")                    # tile t + 2 exists?
     B(f"s_cselect_b32 s{S_RA + 2}, s{S_NRA}, 0")
     B(f"s_cselect_b32 s{S_RW + 2}, s{S_NRW}, 0")
-    B("s_waitcnt lgkmcnt(0)")                          # buffer 0 = k-step 0 of this tile
+    if not TOP_PROG:
+        B("s_waitcnt lgkmcnt(0)")                      # buffer 0 = k-step 0 of this tile
     for n in range(128):
+        if TOP_PROG and n < 8:
+            # MFMA n needs activation fragment n (the eight A reads are the youngest of the previous tile, in order); W k-step-1
+            # reads issued at the odd slots before this point are younger still
+            B(f"s_waitcnt lgkmcnt({7 - n + n // 2})")
         for ins in s[n]:
             B(ins)
         B(mfma(0 if n < 64 else 1, n & 63, swap))
