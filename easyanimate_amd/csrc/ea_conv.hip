@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
                 u16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
-                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
+                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0));      // streaming: see conv_w4a_epilogue_img
+                if (m_dst1 >= 0) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0));
                 if (has_gn) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
                 u16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
-                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
+                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0));      // streaming: see conv_w4a_epilogue_img
+                if (m_dst1 >= 0) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0));
             }
         }
     }
@@ -782,8 +782,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
                 u16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
-                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
+                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0));      // streaming: see conv_w4a_epilogue_img
+                if (m_dst1 >= 0) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0));
             }
         }
     }
@@ -1089,8 +1089,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(p.y + e_dst0 + i * e_step + j * 16) = o;
-            if (dup_t) *reinterpret_cast<bf16x4*>(p.y + e_dst0 + e_dup + i * e_step + j * 16) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_dst0 + i * e_step + j * 16));      // streaming: see conv_w4a_epilogue_img
+            if (dup_t) __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_dst0 + e_dup + i * e_step + j * 16));
             if (has_gn) {   // GroupNorm statistics of the NEXT layer, over the values it will read (the rounded ones)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16));
             if (has_gn) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1462,7 +1462,7 @@ __device__ __forceinline__ void conv_w4a_epilogue(const ConvArgs& p, f32x4 (&acc
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16));
             if (has_gn) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1473,6 +1473,89 @@ __device__ __forceinline__ void conv_w4a_epilogue(const ConvArgs& p, f32x4 (&acc
             }
         }
     }
+    if (p.gn_partial) {
+        const int64_t in_frame = ((int64_t)h_out * tiles_w + (tm % tiles_w)) * WM + wr;
+        const int64_t blk = (int64_t)t_out * p.gn_nblk + in_frame;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s_ = gs[j], q_ = gq[j];
+#pragma unroll
+            for (int o_ = 1; o_ < 16; o_ <<= 1) {
+                s_ += __shfl_xor(s_, o_, 64);
+                q_ += __shfl_xor(q_, o_, 64);
+            }
+            const int n0 = col_w + j * 16 + lq * 4;
+            if (lr == 0) {
+                float* dst = p.gn_partial + (blk * (p.C_out >> 2) + (n0 >> 2)) * 2;
+                dst[0] = s_;
+                dst[1] = q_;
+            }
+        }
+    }
+}
+
+// ---- the same epilogue through a wave-private 16 KiB LDS image (128 voxels x 64 channels, 16-byte chunks XOR-swizzled with
+// (row >> 1) & 7: ea_gemm.hip's gemm_wave_epilogue), so that global memory sees whole 128-byte runs: the accumulator layout's own
+// stores are 16 rows x 32 bytes per instruction, partial lines that the store path takes at about a third of the rate (measured on
+// the GEMM: profiles/r05q_gemm_anatomy_direct_stores_dropped.jsonl).  The residual rows come in by LDS-DMA (requested for both
+// halves before the first accumulator is read out), the stores are streaming (the activations are far larger than the L2 and not
+// read again by this kernel).  Same arithmetic in the same order as conv_w4a_epilogue: bit-identical.
+__device__ __forceinline__ void conv_w4a_residual_request(const ConvArgs& p, const unsigned short* const resp, char* const img, const int64_t m0,
+                                                          const int col_w, const int lane) {
+    const int r8 = lane >> 3, c8 = lane & 7;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = q * 8 + r8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(resp + (m0 + r) * p.C_out + col_w + ((c8 ^ ((r >> 1) & 7)) << 3)),
+                                         (__attribute__((address_space(3))) void*)(img + q * 1024), 16, 0, 0);
+    }
+}
+
+template <int WM>
+__device__ __forceinline__ void conv_w4a_epilogue_img(const ConvArgs& p, f32x4 (&acc)[8][4], char* const img, const f32x4* const b4, const int col_w,
+                                                      const int wr, const int64_t m0, const int h_out, const int t_out, const int tiles_w, const int tm,
+                                                      const int lane) {
+    const int lr = lane & 15, lq = lane >> 4;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool has_res = p.res != nullptr, has_gn = p.gn_partial != nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + lr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            char* const cell = img + r * 128 + (((j * 2 + (lq >> 1)) ^ ((r >> 1) & 7)) << 4) + (lq & 1) * 8;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+            if (has_res) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(cell);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x4*>(cell) = o;
+            if (has_gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r_ = (float)o[e];
+                    gs[j] += r_;
+                    gq[j] += r_ * r_;
+                }
+            }
+        }
+    }
+    u16x8 o[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = q * 8 + r8;
+        o[q] = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        __builtin_nontemporal_store(o[q], reinterpret_cast<u16x8*>(p.y + (m0 + q * 8 + r8) * p.C_out + col_w + c8 * 8));
     if (p.gn_partial) {
         const int64_t in_frame = ((int64_t)h_out * tiles_w + (tm % tiles_w)) * WM + wr;
         const int64_t blk = (int64_t)t_out * p.gn_nblk + in_frame;
@@ -1610,10 +1693,32 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
     int lane_e;                                       // the lane id again: nothing lane-derived has to stay live across the main loop
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     f32x4 acc[8][4];
+#ifdef EA_CONV_DIRECT_EPILOGUE     // (diagnostic builds: the accumulator layout's own 8-byte stores)
     EA_W4A_READ_HALF0(acc)
     conv_w4a_epilogue<WM>(p, acc, col0 + wc * 128, wr, orow, w0, h_out, t_out, tiles_w, tm, lane_e);
     EA_W4A_READ_HALF1(acc)
     conv_w4a_epilogue<WM>(p, acc, col0 + wc * 128 + 64, wr, orow, w0, h_out, t_out, tiles_w, tm, lane_e);
+#else
+    __builtin_amdgcn_s_barrier();      // every wave is past its last fragment read: the stages become the epilogue images (2 x 16 KiB per wave)
+    char* const img0 = smem + wave * 32768;
+    char* const img1 = img0 + 16384;
+    const int col_w = col0 + wc * 128;
+    const int64_t m0 = (int64_t)orow * p.W_out + w0 + wr * 128;
+    if (p.res) {
+        const unsigned short* const resp = p.res - (p.vres ? (int64_t)(t_out - ((t_out + 1) >> 1)) * p.H_out * p.W_out * p.C_out : 0);
+        conv_w4a_residual_request(p, resp, img0, m0, col_w, lane_e);
+        conv_w4a_residual_request(p, resp, img1, m0, col_w + 64, lane_e);
+    }
+    f32x4 b4[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col_w + j * 16 + (lane_e >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    EA_W4A_READ_HALF0(acc)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as the builtin (the compiler's bookkeeping sees it): bias vectors and residual rows, in flight under the read-out
+    __builtin_amdgcn_sched_barrier(0);
+    conv_w4a_epilogue_img<WM>(p, acc, img0, b4, col_w, wr, m0, h_out, t_out, tiles_w, tm, lane_e);
+    EA_W4A_READ_HALF1(acc)
+    conv_w4a_epilogue_img<WM>(p, acc, img1, b4 + 4, col_w + 64, wr, m0, h_out, t_out, tiles_w, tm, lane_e);
+#endif
 }
 
 // ea_set_option("conv_m512", bit 0: the 512-voxel x 128-channel kernel, bit 1: the 256 x 256 kernel over 32-channel stages).
@@ -1833,18 +1938,18 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
             if ((k32_128 && (g_conv_w4a & 1)) || (!k32_128 && (g_conv_w4a & 2))) {
                 static bool attr6_done = false;
                 if (!attr6_done) {
-                    (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-                    (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+                    (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                    (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
                     attr6_done = true;
                 }
                 if (k32_128) {
                     ea_count("conv_w4a");            // (marker first: ea_last_dispatch() names the kernel family, as before)
                     ea_count("conv_row16_m512");
-                    hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<128, 512>), dim3((unsigned)grid5), dim3(256), 100 * 1024, (hipStream_t)stream, p);
+                    hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<128, 512>), dim3((unsigned)grid5), dim3(256), 128 * 1024, (hipStream_t)stream, p);
                 } else {
                     ea_count("conv_w4a");
                     ea_count("conv_row16_256_k32");
-                    hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<256, 256>), dim3((unsigned)grid5), dim3(256), 112 * 1024, (hipStream_t)stream, p);
+                    hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<256, 256>), dim3((unsigned)grid5), dim3(256), 128 * 1024, (hipStream_t)stream, p);
                 }
                 return ea_check_launch("ea_conv3d_cl_bf16");
             }

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 //   * same operand roles / row swizzles / epilogue as the 128^2 kernel (C^T tiles, swap-2/3 W rows, 16-byte stores).
 #ifdef EA_GEMM_TIMESTAMPS
 __device__ unsigned long long* g_gemm_ts = nullptr;   // diagnostic builds: per-workgroup s_memtime stamps
+__device__ int g_gemm_stagger = 0;                    // diagnostic builds: the first workgroup of CU c starts ((c >> 3) & 3) * n * 8128 cycles late
 #endif
 constexpr int OPER2 = 256 * 128;   // one operand tile, 32 KiB
 constexpr int GEMM2_LDS = 4 * OPER2;
@@ -663,68 +664,97 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 // orientation: a lane holds 4 consecutive columns of row lr) through the wave-private 16 KiB LDS image `img` (rows = the wave's
 // 128 output rows, 128 B = its 64 columns, 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and
 // the read-out use).  p.c_kstep != 0 writes the tile K-blocked (one [rows][64] block of the next GEMM's A operand).
+// Round 5 (profiles/r05p_gemm_anatomy_w4a_vs_w4p.jsonl: the epilogue was 11-17 % of a K = 3072 tile, most of it exposed latency): nothing in
+// here waits for a global load it issued itself.  The lane's bias / gate vectors are loaded by gemm_load_bias_gate -- by the four-wave
+// kernel BEFORE its main loop --, the residual rows are requested by gemm_residual_request (four-wave kernel: both halves into two
+// images before the first accumulator is read out), and the image is read out in one batch before the stores go.
 template <int EPI>
-__device__ __forceinline__ void gemm_wave_epilogue(const GemmArgs& p, int b, f32x4_t (&acc)[8][4], char* const img, const int mrow0,
-                                                   const int ncol0, const int lane) {
-    const int lr = lane & 15, lq = lane >> 4;
+__device__ __forceinline__ void gemm_load_bias_gate(const GemmArgs& p, const int b, const int ncol0, const int lane, f32x4_t* const bv,
+                                                    f32x4_t* const gv) {
+    const int lq = lane >> 4;
+    const float* gb = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int n0 = ncol0 + j * 16 + lq * 4;                 // this lane's 4 columns of MFMA tile column j
+        n0 = n0 < p.N ? n0 : 0;                           // N tail: any in-bounds address, never used
+        bv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        gv[j] = bv[j];
+        if (p.bias) bv[j] = *reinterpret_cast<const f32x4_t*>(p.bias + n0);
+        if (EPI == EA_EPI_BIAS_GATE_RES) gv[j] = *reinterpret_cast<const f32x4_t*>(gb + n0);
+    }
+}
+
+// residual rows of the wave tile -> image (LDS-DMA, 16 x 1 KiB); the caller waits (vmcnt) before the epilogue reads the image
+__device__ __forceinline__ void gemm_residual_request(const GemmArgs& p, const int b, char* const img, const int mrow0, const int ncol0,
+                                                      const int lane) {
     const int r8 = lane >> 3, c8 = lane & 7;
-    if (EPI == EA_EPI_BIAS_GATE_RES) {
-        const unsigned short* Rb = p.res + b * p.rbs;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = q * 8 + r8;
-            int m = mrow0 + r;
-            m = m < p.M ? m : p.M - 1;
-            int n = ncol0 + ((c8 ^ ((r >> 1) & 7)) << 3);
-            n = n < p.N ? n : 0;
-            glds16(Rb + (int64_t)m * p.ldres + n, img + q * 1024);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-        const float* gb = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs : nullptr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n0 = ncol0 + j * 16 + lq * 4;          // this lane's 4 columns of MFMA tile column j
-            if (n0 >= p.N) continue;                          // N tail (N % 8 == 0, lq*4 pairs stay inside a chunk of 8)
-            f32x4_t bv = {0.f, 0.f, 0.f, 0.f}, gv = bv;
-            if (p.bias) bv = *reinterpret_cast<const f32x4_t*>(p.bias + n0);
-            if (EPI == EA_EPI_BIAS_GATE_RES) gv = *reinterpret_cast<const f32x4_t*>(gb + n0);
-            const int ch = j * 2 + (lq >> 1);                 // 16-byte chunk of the row, 8-byte half lq & 1
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = i * 16 + lr;
-                char* cell = img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq & 1) * 8;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
-                if (EPI == EA_EPI_BIAS_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                }
-                if (EPI == EA_EPI_BIAS_GATE_RES) {
-                    const u16x4 rr = *reinterpret_cast<const u16x4*>(cell);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = bf16_bits_to_f32(rr[e]) + gv[e] * v[e];
-                }
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                *reinterpret_cast<u16x4*>(cell) = o;
-            }
-        }
-    }
-    unsigned short* Cb = p.C + b * p.cbs;
+    const unsigned short* Rb = p.res + b * p.rbs;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int r = q * 8 + r8;
-        const int m = mrow0 + r;
-        const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
+        int m = mrow0 + r;
+        m = m < p.M ? m : p.M - 1;
+        int n = ncol0 + ((c8 ^ ((r >> 1) & 7)) << 3);
+        n = n < p.N ? n : 0;                                   // N tail: any in-bounds address, never used
+        glds16(Rb + (int64_t)m * p.ldres + n, img + q * 1024);
+    }
+}
+
+// RES_READY: the residual rows are already in the image (requested and waited for by the caller)
+template <int EPI, bool RES_READY = false>
+__device__ __forceinline__ void gemm_wave_epilogue(const GemmArgs& p, int b, f32x4_t (&acc)[8][4], char* const img, const int mrow0,
+                                                   const int ncol0, const int lane, const f32x4_t* const bv, const f32x4_t* const gv) {
+    const int lr = lane & 15, lq = lane >> 4;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    if (EPI == EA_EPI_BIAS_GATE_RES && !RES_READY) {
+        gemm_residual_request(p, b, img, mrow0, ncol0, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n0 = ncol0 + j * 16 + lq * 4;          // this lane's 4 columns of MFMA tile column j
+        if (n0 >= p.N) continue;                          // N tail (N % 8 == 0, lq*4 pairs stay inside a chunk of 8)
+        const int ch = j * 2 + (lq >> 1);                 // 16-byte chunk of the row, 8-byte half lq & 1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 16 + lr;
+            char* cell = img + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4) + (lq & 1) * 8;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[j][e];
+            if (EPI == EA_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+            }
+            if (EPI == EA_EPI_BIAS_GATE_RES) {
+                const u16x4 rr = *reinterpret_cast<const u16x4*>(cell);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(gv[j][e], v[e], bf16_bits_to_f32(rr[e]));
+            }
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16_bits(v[e]);
+            *reinterpret_cast<u16x4*>(cell) = o;
+        }
+    }
+    unsigned short* Cb = p.C + b * p.cbs;
+    u16x8 o[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = q * 8 + r8;
+        o[q] = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int m = mrow0 + q * 8 + r8;
         // (K-blocked C: the wave's 64 columns are one [rows][64] block of the next GEMM's A operand -- 128 rows x 128 B, contiguous)
         unsigned short* const crow = p.c_kstep ? Cb + (int64_t)(ncol0 >> 6) * p.c_kstep + (int64_t)m * 64 + c8 * 8
                                                : Cb + (int64_t)m * p.ldc + ncol0 + c8 * 8;
-        if (m < p.M && ncol0 + c8 * 8 < p.N) *reinterpret_cast<u16x8*>(crow) = o;
+        // streaming stores: C is far larger than the L2 and is not read again by this kernel -- written with the default policy it
+        // pushes operand tiles out of the L2 under the main loops of the other CUs (FFN-up at config 3: 1377 -> 1427 TFLOP/s,
+        // out-proj 1309 -> 1347, profiles/r05q_gemm_nt_stores_ab.txt)
+        if (m < p.M && ncol0 + c8 * 8 < p.N) __builtin_nontemporal_store(o[q], reinterpret_cast<u16x8*>(crow));
     }
 }
 
@@ -806,7 +836,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_mi16_kernel(GemmArgs p) {
     // 16-byte chunks XOR-swizzled with (row >> 1) & 7: the layout the residual LDS-DMA and the read-out already use)
     char* const img = smem + wave * 16384;
     const int mrow0 = row0 + wr * 128, ncol0 = col0 + wc * 64;
-    gemm_wave_epilogue<EPI>(p, b, acc, img, mrow0, ncol0, lane);
+    f32x4_t bv[4], gv[4];
+    gemm_load_bias_gate<EPI>(p, b, ncol0, lane, bv, gv);       // one batch of loads, in flight under the residual request
+    gemm_wave_epilogue<EPI>(p, b, acc, img, mrow0, ncol0, lane, bv, gv);
 #ifdef EA_GEMM_TIMESTAMPS
     if (g_gemm_ts && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -838,6 +870,13 @@ __global__ __launch_bounds__(256) void gemm256_w4a_kernel(GemmArgs p) {
     const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 15, lq = lane >> 4;
 
+#ifdef EA_GEMM_TIMESTAMPS
+    if (g_gemm_stagger && blockIdx.x < 256 && blockIdx.y == 0) {
+        const int n = ((blockIdx.x >> 3) & 3) * g_gemm_stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
     int tm, tn;
     if (!tile_of_block(p, tm, tn)) return;
     const int b = blockIdx.y;
@@ -877,10 +916,27 @@ __global__ __launch_bounds__(256) void gemm256_w4a_kernel(GemmArgs p) {
     const unsigned w_kst = __builtin_amdgcn_readfirstlane((unsigned)(p.w_kstep * 2));
     const unsigned a_ext_s = __builtin_amdgcn_readfirstlane(a_ext), w_ext_s = __builtin_amdgcn_readfirstlane(w_ext);
     const unsigned nk_s = __builtin_amdgcn_readfirstlane((unsigned)nk);
+    // the lane's bias / gate vectors (4 columns in each of its 8 column blocks) are fetched by the main asm itself, in front of the first
+    // operand request, into registers it returns as outputs: landed long before the epilogue asks for them (EA_W4A_MAINLOOP_ASM_BG)
+    const float* const bptr = p.bias ? p.bias + col0 : nullptr;
+    const float* const gptr = EPI == EA_EPI_BIAS_GATE_RES ? p.gate + b * p.gbs + col0 : nullptr;
+    const unsigned bg_bytes = p.N - col0 > 0 ? (unsigned)(p.N - col0) * 4u : 0u;                  // columns past N read as zeros
+    const unsigned b_lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)bptr);
+    const unsigned b_hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)bptr >> 32));
+    const unsigned b_ext = __builtin_amdgcn_readfirstlane(bptr ? bg_bytes : 0u);
+    const unsigned g_lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)gptr);
+    const unsigned g_hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)gptr >> 32));
+    const unsigned g_ext = __builtin_amdgcn_readfirstlane(gptr ? bg_bytes : 0u);
+    const int boff = (wc * 128 + lq * 4) * 4;
+    f32x4_t bias_v[8], gate_v[8];
+#ifdef EA_GEMM_TIMESTAMPS
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
 
-    asm volatile(EA_W4A_MAINLOOP_ASM
-                 :
-                 : [wk0] "v"(wk0), [ak0] "v"(ak0),
+    asm volatile(EA_W4A_MAINLOOP_ASM_BG
+                 : EA_W4A_BG_OUTPUTS(bias_v, gate_v)
+                 : [boff] "v"(boff), [b_lo] "s"(b_lo), [b_hi] "s"(b_hi), [b_ext] "s"(b_ext), [g_lo] "s"(g_lo), [g_hi] "s"(g_hi), [g_ext] "s"(g_ext),
+                   [wk0] "v"(wk0), [ak0] "v"(ak0),
                    [aoff0] "v"(aoff[0]), [aoff1] "v"(aoff[1]), [aoff2] "v"(aoff[2]), [aoff3] "v"(aoff[3]),
                    [aoff4] "v"(aoff[4]), [aoff5] "v"(aoff[5]), [aoff6] "v"(aoff[6]), [aoff7] "v"(aoff[7]),
                    [woff0] "v"(woff[0]), [woff1] "v"(woff[1]), [woff2] "v"(woff[2]), [woff3] "v"(woff[3]),
@@ -888,16 +944,41 @@ __global__ __launch_bounds__(256) void gemm256_w4a_kernel(GemmArgs p) {
                    [a_lo] "s"(a_lo), [a_hi] "s"(a_hi), [a_ext] "s"(a_ext_s), [w_lo] "s"(w_lo), [w_hi] "s"(w_hi), [w_ext] "s"(w_ext_s),
                    [a_kst] "s"(a_kst), [w_kst] "s"(w_kst), [nk] "s"(nk_s), [lds_w] "s"(lds_w), [lds_a] "s"(lds_a)
                  : EA_W4A_CLOBBERS);
+#ifdef EA_GEMM_TIMESTAMPS
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
     __builtin_amdgcn_s_barrier();   // every wave's requests have landed and its fragment reads are done: the LDS becomes the epilogue images
 
-    // ---- epilogue: the wave's 128 x 128 tile as two 128 x 64 halves through its private 16 KiB image, gemm256_mi16_kernel's code
-    char* const img = smem + wave * 16384;
+    // ---- epilogue: the wave's 128 x 128 tile as two 128 x 64 halves, each through its own private 16 KiB image (the four waves share
+    // 128 KiB), gemm256_mi16_kernel's code.  Both halves' residual rows are requested before the first accumulator is read out and
+    // waited for once, in front of the first store: no wait in here ever covers a store.
+    char* const img0 = smem + wave * 32768;
+    char* const img1 = img0 + 16384;
     const int mrow0 = row0 + wr * 128;
+    if (EPI == EA_EPI_BIAS_GATE_RES) {
+        gemm_residual_request(p, b, img0, mrow0, col0 + wc * 128, lane);
+        gemm_residual_request(p, b, img1, mrow0, col0 + wc * 128 + 64, lane);
+    }
     f32x4_t acc[8][4];
     EA_W4A_READ_HALF0(acc)
-    gemm_wave_epilogue<EPI>(p, b, acc, img, mrow0, col0 + wc * 128, lane);
+    if (EPI == EA_EPI_BIAS_GATE_RES) {
+        // vmcnt(0) as the BUILTIN, so that the compiler's own wait bookkeeping sees it (an asm wait would leave it to place its
+        // own in front of the image reads -- inside the per-column branches, and again in the middle of the stores)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    gemm_wave_epilogue<EPI, true>(p, b, acc, img0, mrow0, col0 + wc * 128, lane, bias_v, gate_v);
     EA_W4A_READ_HALF1(acc)
-    gemm_wave_epilogue<EPI>(p, b, acc, img, mrow0, col0 + wc * 128 + 64, lane);
+    gemm_wave_epilogue<EPI, true>(p, b, acc, img1, mrow0, col0 + wc * 128 + 64, lane, bias_v + 4, gate_v + 4);
+#ifdef EA_GEMM_TIMESTAMPS
+    if (g_gemm_ts && tid == 0) {
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g_gemm_ts + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 5;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3;
+        d[4] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 // =================================================================================================
@@ -954,10 +1035,13 @@ __device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[
 #pragma clang fp contract(off)
     const int lr = lane & 15, lq = lane >> 4;
     // lane holds tokens i*16 + 4*lq + 0..3 of feature j*16 + lr  ->  image^T [feature][token]
+    float bv4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv4[j] = biasb ? biasb[feat0 + j * 16 + lr] : 0.f;      // one batch of loads: one round trip, not four
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = j * 16 + lr;
-        const float bv = biasb ? biasb[feat0 + n] : 0.f;
+        const float bv = bv4[j];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             u16x4 o;
@@ -975,7 +1059,7 @@ __device__ __forceinline__ void qkv_epilogue_v(const QkvArgs& q, f32x4_t (&acc)[
         for (int qq = 0; qq < 16; ++qq) {
             const int n = qq * 4 + r4;
             const u16x8 o = *reinterpret_cast<const u16x8*>(img + n * 256 + ((c16 ^ (n & 15)) << 4));
-            *reinterpret_cast<u16x8*>(dst + (int64_t)n * q.kv_rows) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(dst + (int64_t)n * q.kv_rows));   // streaming, as in gemm_wave_epilogue
         }
     } else if (nv > 0) {   // the one straddling group of a row: element stores, nothing past column kv_off + M is written
         for (int qq = 0; qq < 16; ++qq) {
@@ -1070,7 +1154,7 @@ __device__ __forceinline__ void qkv_epilogue_qk(const QkvArgs& q, f32x4_t (&acc)
     for (int qq = 0; qq < 16; ++qq) {
         const int r = qq * 8 + r8;
         const u16x8 o = *reinterpret_cast<const u16x8*>(img + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4));
-        if (tok0 + r < Mv) *reinterpret_cast<u16x8*>(dst + (int64_t)r * 64) = o;
+        if (tok0 + r < Mv) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(dst + (int64_t)r * 64));
     }
 }
 
@@ -1494,6 +1578,9 @@ extern "C" int ea_qkv_gemm_norm_rope_bf16_w8(const ea_bf16* A, const uint8_t* Wq
 #ifdef EA_GEMM_TIMESTAMPS
 extern "C" int ea_debug_gemm_timestamps(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_ts), &buf, sizeof(void*));
+}
+extern "C" int ea_debug_gemm_stagger(int n) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stagger), &n, sizeof(int));
 }
 #endif
 

@@ -158,6 +158,14 @@ def test_compiler_leaves_the_accumulators_alone(isa, src, name, loop_mfmas):
     body = text[st:en]
     meta = {k: int([l.split()[-1] for l in body if k in l][0]) for k in (".amdhsa_private_segment_fixed_size", ".amdhsa_accum_offset")}
     assert meta[".amdhsa_private_segment_fixed_size"] == 0 and not any("scratch_" in l for l in body)
+    if "gemm256_w4a_kernel" in name:
+        # the bias / gate vectors land in v132..v195 (outputs of the main asm, written in its prologue): no input operand of the
+        # asm -- the request offsets, the fragment addresses -- may have been placed there or in the clobbered v0..v131
+        main = [l for l in body if re.search(r"buffer_load_dwordx4 v\d+, s\[\d+:\d+\], s\d+ offen lds", l)]
+        assert len(main) >= 48
+        assert all(int(re.search(r"buffer_load_dwordx4 v(\d+),", l).group(1)) >= 196 for l in main), main[:3]
+        outs = [l for l in body if re.search(r"buffer_load_dwordx4 v\[\d+:\d+\], v\d+, s\[96:99\], 0 offen", l)]
+        assert len(outs) == 16 and all(int(re.search(r", v(\d+), s\[96", l).group(1)) >= 196 for l in outs), outs[:3]
     errors, n_w, n_r, n_loop_mfma, loops_ok = _analyse(name, body)
     assert n_loop_mfma == loop_mfmas and loops_ok
     print(f"[isa] {name}: arch VGPRs {meta['.amdhsa_accum_offset']}, compiler AGPR spill writes / reads behind the main loop: {n_w} / {n_r}")

@@ -1,6 +1,9 @@
-"""Where does a 256^2 GEMM workgroup spend its time?  Needs a diagnostic build:
-    EA_HIPCC_EXTRA=-DEA_GEMM_TIMESTAMPS python -m easyanimate_amd.build --force
-prints per-workgroup s_memtime deltas: prologue (start -> first tile landed), main loop, epilogue."""
+"""Where does a 256^2 GEMM workgroup spend its time?  Needs a diagnostic build beside the product library:
+    EA_HIPCC_EXTRA=-DEA_GEMM_TIMESTAMPS EA_LIB_OUT=easyanimate_amd/lib/diag/libea_diag.so python -m easyanimate_amd.build
+    EA_LIB_PATH=easyanimate_amd/lib/diag/libea_diag.so python tools/gemm_anatomy.py
+Per output tile, s_memtime stamps of wave 0: start -> main asm entered (set-up), the main asm (first requests .. last MFMA), the
+epilogue up to its last store ISSUED, and (one-tile kernels) until those stores are acknowledged.  gemm_w4a = 3: one tile per
+workgroup (gemm256_w4a_kernel), 7: persistent workgroups with cross-tile prefetch (gemm256_w4p_kernel), 0: the eight-wave kernel."""
 import ctypes
 import json
 import os
@@ -11,34 +14,44 @@ from easyanimate_amd import _lib, ops
 
 lib = _lib.load()
 _lib.set_option("gemm_tile", 256)
-print(json.dumps({"gemm_mfma": _lib.get_option("gemm_mfma")}))
-for (M, N, K, epi) in [(106496, 3072, 3072, 0), (106496, 12288, 3072, 1), (106496, 3072, 12288, 2), (8192, 8192, 8192, 0)]:
+lib.ea_debug_gemm_timestamps.argtypes = [ctypes.c_void_p]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [3]
+# optional second argument: stagger values to sweep (diagnostic: the first workgroup of a CU starts ((cu >> 3) & 3) * n * 8128 cycles late,
+# which puts the CUs of an XCD in four phases -- do the epilogues' stores go faster when they do not all come at once?)
+staggers = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+lib.ea_debug_gemm_stagger.argtypes = [ctypes.c_int]
+for (M, N, K, epi) in [(106496, 12288, 3072, 1), (106496, 9216, 3072, 0), (106496, 3072, 3072, 2), (106496, 3072, 12288, 2), (8192, 8192, 8192, 0)]:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda")
     o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     gate = torch.randn(1, N, device="cuda")
     run = (lambda: ops.gemm(A, W, bias, 2, out=o, res=o, gate=gate)) if epi == 2 else (lambda: ops.gemm(A, W, bias, epi, out=o))
-    run(); run()
     tiles_m, tiles_n = (M + 255) // 256, N // 256
     rpx = (tiles_m + 7) // 8 if tiles_m >= 64 else 0
     nblk = 8 * rpx * tiles_n if rpx else tiles_m * tiles_n
-    ts = torch.zeros(nblk * 5, dtype=torch.int64, device="cuda")
-    lib.ea_debug_gemm_timestamps.argtypes = [ctypes.c_void_p]
-    assert lib.ea_debug_gemm_timestamps(ts.data_ptr()) == 0
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); run(); e1.record(); torch.cuda.synchronize()
-    lib.ea_debug_gemm_timestamps(None)
-    t = ts.view(nblk, 5).cpu()
-    t = t[t[:, 3] != 0].double()
-    pro, loop, epi_t, tot = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
-    span = (t[:, 3].max() - t[:, 0].min()).item()
-    ms = e0.elapsed_time(e1)
-    tick_ns = ms * 1e6 / span
-    med = lambda x: x.median().item()
-    print(json.dumps({"M": M, "N": N, "K": K, "epi": epi, "kernel_ms": ms, "wgs": int(t.shape[0]), "tick_ns(upper bound)": tick_ns,
-                      "ticks_per_wg": {"prologue": med(pro), "mainloop": med(loop), "epilogue": med(epi_t), "total": med(tot)},
-                      "mainloop_ticks_per_ktile": med(loop) / (K // 64),
-                      "sum_wg_ticks / (256 CUs * span)": tot.sum().item() / (256 * span)}), flush=True)
+    for v, stg in [(v, g) for v in variants for g in staggers]:
+        _lib.set_option("gemm_w4a", v)
+        assert lib.ea_debug_gemm_stagger(stg) == 0
+        run(); run()
+        ts = torch.zeros(nblk * 5, dtype=torch.int64, device="cuda")
+        assert lib.ea_debug_gemm_timestamps(ts.data_ptr()) == 0
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        lib.ea_debug_gemm_timestamps(None)
+        t = ts.view(nblk, 5).cpu()
+        t = t[t[:, 3] != 0].double()
+        ms = e0.elapsed_time(e1)
+        us = 0.01                                 # s_memtime: 100 MHz (the XCDs' counters have different origins: only differences inside a workgroup are used)
+        span = ms * 1e3 / us
+        med = lambda x: round(x.median().item() * us, 3)
+        rec = {"M": M, "N": N, "K": K, "epi": epi, "gemm_w4a": v, "stagger": stg, "kernel_ms": round(ms, 4), "tiles": int(t.shape[0]), "median_ticks": [int((t[:, k + 1] - t[:, k]).median().item()) for k in range(4)],
+               "median_us_per_tile": {"set-up": med(t[:, 1] - t[:, 0]), "main asm": med(t[:, 2] - t[:, 1]), "epilogue (stores issued)": med(t[:, 3] - t[:, 2]),
+                                      "store drain": med(t[:, 4] - t[:, 3]), "total": med(t[:, 4] - t[:, 0])},
+               "main_asm_us_per_ktile": round((t[:, 2] - t[:, 1]).median().item() * us / (K // 64), 4),
+               "sum of tile times / (256 CUs x span)": round((t[:, 4] - t[:, 0]).sum().item() / (256 * span), 4)}
+        print(json.dumps(rec), flush=True)
+    _lib.set_option("gemm_w4a", 3)
+    lib.ea_debug_gemm_stagger(0)
     del A, W, o

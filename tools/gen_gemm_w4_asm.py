@@ -41,7 +41,9 @@ S_KA, S_KW = 88, 89              # scalar byte offset of the tile being requeste
 S_MW, S_MA = 90, 91              # LDS byte address of this wave's first W / A piece in the stage being filled
 S_LEFT = 92                      # K tiles left, including the current one
 S_NRA, S_NRW = 93, 94            # real num_records
-S_KSTA, S_KSTW = 95, 96          # bytes to the next K tile
+S_KSTA, S_KSTW = 95, 100         # bytes to the next K tile
+S_RB = 96                        # bias, then gate buffer resource (4 SGPRs; the _BG variant)
+V_BIAS, V_GATE = 132, 164        # the _BG variant's outputs: the lane's 8 bias / 8 gate vectors (4 columns each), v132..v163 / v164..v195
 
 
 def acc(i, j):
@@ -49,14 +51,15 @@ def acc(i, j):
     return 4 * (j * 8 + i)
 
 
-def mfma(b, n, swap=False):
+def mfma(b, n, swap=False, zero_c=False):
     """swap = False: the weight fragment is the MFMA's A operand (C^T orientation: a lane ends with 4 consecutive output columns of
     one row); swap = True: the activation fragment is (a lane ends with 4 consecutive ROWS of one column -- the V^T tiles of the
     fused QKV kernel)."""
     j, i = n >> 3, n & 7
     a = acc(i, j)
     w, x = f"v[{FW[b] + 4 * j}:{FW[b] + 4 * j + 3}]", f"v[{FA[b] + 4 * i}:{FA[b] + 4 * i + 3}]"
-    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {x}, {w}, a[{a}:{a + 3}]" if swap else f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {w}, {x}, a[{a}:{a + 3}]"
+    c = "0" if zero_c else f"a[{a}:{a + 3}]"
+    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {x}, {w}, {c}" if swap else f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {w}, {x}, {c}"
 
 
 def rd(oper, b, x, addr):
@@ -140,8 +143,14 @@ def check(s):
     return True
 
 
-def loop_body(s, swap):
-    """The whole asm block (prologue, K loop, drain) as a list of instructions."""
+def loop_body(s, swap, bias_gate=False):
+    """The whole asm block (prologue, K loop, drain) as a list of instructions.
+
+    bias_gate = True (EA_W4A_MAINLOOP_ASM_BG, gemm256_w4a_kernel): the lane's epilogue vectors -- bias and gate of its 4 columns in each of
+    the 8 column blocks -- are fetched by 16 buffer loads in front of the first operand requests into FIXED registers that the asm
+    statement declares as outputs ("={v[132:135]}" ..), so the epilogue never waits for a load: they are older than every operand
+    request (the in-order vmcnt bookkeeping of the loop is untouched) and complete long before the loop ends.  A missing bias / gate
+    is a resource with num_records = 0 (zeros, no traffic); columns past N read as zeros the same way."""
     body = []
     B = body.append
     # ---- prologue: resources, tile 0 and tile 1 requests, accumulators := 0, first fragments
@@ -189,33 +198,54 @@ def loop_body(s, swap):
     B(f"s_xor_b32 s{S_MA}, s{S_MA}, 0x8000")
     B(f"s_add_u32 s{S_KA}, s{S_KA}, s{S_KSTA}")
     B(f"s_add_u32 s{S_KW}, s{S_KW}, s{S_KSTW}")
-    for r in range(256):                               # accumulators := 0 while tile 0 is on its way
-        B(f"v_accvgpr_write_b32 a{r}, 0")
-    B("s_waitcnt vmcnt(16)")                           # tile 0 (this wave's pieces) has landed; tile 1 stays in flight
+    nbg = 0
+    if bias_gate:                                      # behind the operand requests: tile 0 does not queue up behind them
+        nbg = 16
+        for what, v0 in (("b", V_BIAS), ("g", V_GATE)):
+            B(f"s_mov_b32 s{S_RB}, %[{what}_lo]")
+            B(f"s_mov_b32 s{S_RB + 1}, %[{what}_hi]")
+            B(f"s_mov_b32 s{S_RB + 2}, %[{what}_ext]")
+            B(f"s_mov_b32 s{S_RB + 3}, 0x00020000")
+            for j in range(8):
+                off = f" offset:{j * 64}" if j else ""
+                B(f"buffer_load_dwordx4 v[{v0 + 4 * j}:{v0 + 4 * j + 3}], %[boff], s[{S_RB}:{S_RB + 3}], 0 offen{off}")
+    B(f"s_waitcnt vmcnt({16 + nbg})")                  # tile 0 (this wave's pieces) has landed; tile 1 (and the bias / gate vectors) stay in flight
     B("s_barrier")
     for x in range(8):
         B(rd("w", 0, x, "wk0"))
     for x in range(8):
         B(rd("a", 0, x, "ak0"))
-    # ---- the K loop
-    B("1:")
-    B(f"s_cmp_gt_u32 s{S_LEFT}, 2")                    # tile t + 2 exists?
-    B(f"s_cselect_b32 s{S_RA + 2}, s{S_NRA}, 0")
-    B(f"s_cselect_b32 s{S_RW + 2}, s{S_NRW}, 0")
-    if not TOP_PROG:
-        B("s_waitcnt lgkmcnt(0)")                      # buffer 0 = k-step 0 of this tile
-    for n in range(128):
-        if TOP_PROG and n < 8:
-            # MFMA n needs activation fragment n (the eight A reads are the youngest of the previous tile, in order); W k-step-1
-            # reads issued at the odd slots before this point are younger still
-            B(f"s_waitcnt lgkmcnt({7 - n + n // 2})")
-        for ins in s[n]:
+
+    def k_tile(first):
+        """One K tile.  first: the peeled tile 0 -- its k-step-0 MFMAs take C = 0 (no accumulator initialisation anywhere), and its
+        two vmcnt waits allow for the bias / gate loads, which are younger than tile 1's requests and older than tile 2's."""
+        B(f"s_cmp_gt_u32 s{S_LEFT}, 2")                # tile t + 2 exists?
+        B(f"s_cselect_b32 s{S_RA + 2}, s{S_NRA}, 0")
+        B(f"s_cselect_b32 s{S_RW + 2}, s{S_NRW}, 0")
+        if not TOP_PROG:
+            B("s_waitcnt lgkmcnt(0)")                  # buffer 0 = k-step 0 of this tile
+        for n in range(128):
+            if TOP_PROG and n < 8:
+                # MFMA n needs activation fragment n (the eight A reads are the youngest of the previous tile, in order); W k-step-1
+                # reads issued at the odd slots before this point are younger still
+                B(f"s_waitcnt lgkmcnt({7 - n + n // 2})")
+            for ins in s[n]:
+                if first and nbg and ins.startswith("s_waitcnt vmcnt("):
+                    ins = f"s_waitcnt vmcnt({int(ins[len('s_waitcnt vmcnt('):-1]) + nbg})"
+                B(ins)
+            B(mfma(0 if n < 64 else 1, n & 63, swap, zero_c=first and n < 64))
+        for ins in s[128]:
             B(ins)
-        B(mfma(0 if n < 64 else 1, n & 63, swap))
-    for ins in s[128]:
-        B(ins)
+
+    k_tile(True)
+    B(f"s_cmp_lg_u32 s{S_LEFT}, 0")
+    B("s_cbranch_scc0 9f")                             # nk == 1
+    # ---- the K loop (tiles 1 ..)
+    B("1:")
+    k_tile(False)
     B(f"s_cmp_lg_u32 s{S_LEFT}, 0")
     B("s_cbranch_scc1 1b")
+    B("9:")
     # ---- everything this wave requested has landed (the empty requests of the last two tiles too), the last MFMAs have left the pipe
     B("s_waitcnt vmcnt(0) lgkmcnt(0)")
     B("s_nop 15")
@@ -230,18 +260,24 @@ def emit():
     A = L.append
     A("// GENERATED by tools/gen_gemm_w4_asm.py -- do not edit; see that file for the schedule.")
     n_lines = 0
-    for swap in (False, True):
-        A("#define EA_W4A_MAINLOOP_ASM_SWAP \\" if swap else "#define EA_W4A_MAINLOOP_ASM \\")
-        body = loop_body(s, swap)
+    for swap, bg in ((False, False), (True, False), (False, True)):
+        A("#define EA_W4A_MAINLOOP_ASM_BG \\" if bg else "#define EA_W4A_MAINLOOP_ASM_SWAP \\" if swap else "#define EA_W4A_MAINLOOP_ASM \\")
+        body = loop_body(s, swap, bg)
         n_lines = len(body)
         for ins in body:
             A(f'    "{ins}\\n\\t" \\')
         L[-1] = L[-1][:-2]      # no continuation behind the last line
         A("")
-    clob = [f'"v{r}"' for r in range(132)] + [f'"a{r}"' for r in range(256)] + [f'"s{r}"' for r in range(80, 97)] + ['"m0"', '"scc"', '"memory"']
+    clob = [f'"v{r}"' for r in range(132)] + [f'"a{r}"' for r in range(256)] + [f'"s{r}"' for r in range(80, 102)] + ['"m0"', '"scc"', '"memory"']
     A("#define EA_W4A_CLOBBERS \\")
     for k in range(0, len(clob), 16):
         A("    " + ", ".join(clob[k:k + 16]) + (", \\" if k + 16 < len(clob) else ""))
+    A("")
+    # ---- the _BG variant's output operands: f32x4_t bias[8], gate[8]
+    A("#define EA_W4A_BG_OUTPUTS(bias, gate) \\")
+    outs = [f'"=&{{v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 3}]}}"(bias[{j}])' for j in range(8)] + [f'"=&{{v[{V_GATE + 4 * j}:{V_GATE + 4 * j + 3}]}}"(gate[{j}])' for j in range(8)]
+    for k in range(0, 16, 4):
+        A("    " + ", ".join(outs[k:k + 4]) + (", \\" if k + 4 < 16 else ""))
     A("")
     # ---- accumulator read-out: column half h (j = 4h .. 4h + 3) into f32x4_t dst[8][4]
     for h in range(2):
