@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvArgs p) {
                 u16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0));      // streaming: see conv_w4a_epilogue_img
-                if (m_dst1 >= 0) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0));
+                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
+                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
                 if (has_gn) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_pp_kernel(ConvArgs p) {
                 u16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0));      // streaming: see conv_w4a_epilogue_img
-                if (m_dst1 >= 0) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0));
+                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
+                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
             }
         }
     }
@@ -782,8 +782,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row_kernel(ConvArgs p) {
                 u16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(v[e]);
-                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0));      // streaming: see conv_w4a_epilogue_img
-                if (m_dst1 >= 0) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0));
+                *reinterpret_cast<u16x8*>(p.y + m_dst0 * p.C_out + n0) = o;
+                if (m_dst1 >= 0) *reinterpret_cast<u16x8*>(p.y + m_dst1 * p.C_out + n0) = o;
             }
         }
     }
@@ -1089,8 +1089,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_kernel(ConvArgs p) {
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_dst0 + i * e_step + j * 16));      // streaming: see conv_w4a_epilogue_img
-            if (dup_t) __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_dst0 + e_dup + i * e_step + j * 16));
+            *reinterpret_cast<bf16x4*>(p.y + e_dst0 + i * e_step + j * 16) = o;
+            if (dup_t) *reinterpret_cast<bf16x4*>(p.y + e_dst0 + e_dup + i * e_step + j * 16) = o;
             if (has_gn) {   // GroupNorm statistics of the NEXT layer, over the values it will read (the rounded ones)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_row16_k32_kernel(ConvArgs p)
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16));
+            *reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16) = o;
             if (has_gn) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1462,7 +1462,7 @@ __device__ __forceinline__ void conv_w4a_epilogue(const ConvArgs& p, f32x4 (&acc
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16));
+            *reinterpret_cast<bf16x4*>(p.y + e_base + i * e_step + j * 16) = o;
             if (has_gn) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1499,7 +1499,9 @@ __device__ __forceinline__ void conv_w4a_epilogue(const ConvArgs& p, f32x4 (&acc
 // stores are 16 rows x 32 bytes per instruction, partial lines that the store path takes at about a third of the rate (measured on
 // the GEMM: profiles/r05q_gemm_anatomy_direct_stores_dropped.jsonl).  The residual rows come in by LDS-DMA (requested for both
 // halves before the first accumulator is read out), the stores are streaming (the activations are far larger than the L2 and not
-// read again by this kernel).  Same arithmetic in the same order as conv_w4a_epilogue: bit-identical.
+// read again by this kernel; only with whole-line stores: on the 8- and 16-byte-per-lane stores of the other convolution kernels the
+// same hint made the sub-pixel up-sampler 12 % and the eight-wave row-slab kernels 6 % slower, profiles/r05t_bench_c3_kernel_stats.csv
+// against r05m).  Same arithmetic in the same order as conv_w4a_epilogue: bit-identical.
 __device__ __forceinline__ void conv_w4a_residual_request(const ConvArgs& p, const unsigned short* const resp, char* const img, const int64_t m0,
                                                           const int col_w, const int lane) {
     const int r8 = lane >> 3, c8 = lane & 7;
