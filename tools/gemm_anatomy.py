@@ -2,8 +2,10 @@
     EA_HIPCC_EXTRA=-DEA_GEMM_TIMESTAMPS EA_LIB_OUT=easyanimate_amd/lib/diag/libea_diag.so python -m easyanimate_amd.build
     EA_LIB_PATH=easyanimate_amd/lib/diag/libea_diag.so python tools/gemm_anatomy.py
 Per output tile, s_memtime stamps of wave 0: start -> main asm entered (set-up), the main asm (first requests .. last MFMA), the
-epilogue up to its last store ISSUED, and (one-tile kernels) until those stores are acknowledged.  gemm_w4a = 3: one tile per
-workgroup (gemm256_w4a_kernel), 7: persistent workgroups with cross-tile prefetch (gemm256_w4p_kernel), 0: the eight-wave kernel."""
+epilogue up to its last store ISSUED, and until those stores are acknowledged.  First argument: the gemm_w4a option values to run
+(3 = gemm256_w4a_kernel, the product; 0 = the eight-wave kernel, which stamps start / first tile landed / loop end / end).
+__builtin_readcyclecounter counts shader-clock cycles (about 1.85 GHz under load), every XCD from its own origin: only differences
+inside a workgroup are used."""
 import ctypes
 import json
 import os
@@ -43,14 +45,14 @@ for (M, N, K, epi) in [(106496, 12288, 3072, 1), (106496, 9216, 3072, 0), (10649
         t = ts.view(nblk, 5).cpu()
         t = t[t[:, 3] != 0].double()
         ms = e0.elapsed_time(e1)
-        us = 0.01                                 # s_memtime: 100 MHz (the XCDs' counters have different origins: only differences inside a workgroup are used)
-        span = ms * 1e3 / us
-        med = lambda x: round(x.median().item() * us, 3)
-        rec = {"M": M, "N": N, "K": K, "epi": epi, "gemm_w4a": v, "stagger": stg, "kernel_ms": round(ms, 4), "tiles": int(t.shape[0]), "median_ticks": [int((t[:, k + 1] - t[:, k]).median().item()) for k in range(4)],
-               "median_us_per_tile": {"set-up": med(t[:, 1] - t[:, 0]), "main asm": med(t[:, 2] - t[:, 1]), "epilogue (stores issued)": med(t[:, 3] - t[:, 2]),
-                                      "store drain": med(t[:, 4] - t[:, 3]), "total": med(t[:, 4] - t[:, 0])},
-               "main_asm_us_per_ktile": round((t[:, 2] - t[:, 1]).median().item() * us / (K // 64), 4),
-               "sum of tile times / (256 CUs x span)": round((t[:, 4] - t[:, 0]).sum().item() / (256 * span), 4)}
+        med = lambda x: int(x.median().item())
+        tot = t[:, 4] - t[:, 0]
+        rec = {"M": M, "N": N, "K": K, "epi": epi, "gemm_w4a": v, "stagger": stg, "kernel_ms": round(ms, 4), "tiles": int(t.shape[0]),
+               "median_cycles_per_tile": {"set-up": med(t[:, 1] - t[:, 0]), "main asm": med(t[:, 2] - t[:, 1]), "epilogue (stores issued)": med(t[:, 3] - t[:, 2]),
+                                          "store drain": med(t[:, 4] - t[:, 3]), "total": med(tot)},
+               "main_asm_cycles_per_ktile": round((t[:, 2] - t[:, 1]).median().item() / (K // 64), 1),
+               # every CU runs its tiles back to back: cycles of all tiles / 256 CUs / kernel time = the clock the stamps ran at (lower bound)
+               "implied_GHz": round(tot.sum().item() / 256 / (ms * 1e6), 3)}
         print(json.dumps(rec), flush=True)
     _lib.set_option("gemm_w4a", 3)
     lib.ea_debug_gemm_stagger(0)
