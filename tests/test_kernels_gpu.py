@@ -1173,6 +1173,38 @@ def test_gemm_w4a_bit_identical_to_the_eight_wave_kernel(B, M, N, K, epi):
     assert torch.equal(outs[2], outs[1])          # repeated launches agree (race screen)
 
 
+@pytest.mark.parametrize("epi", [0, 2])
+def test_gemm_w4a_without_bias(epi):
+    """The four-wave kernel fetches its bias / gate vectors inside the main asm through buffer descriptors: a missing bias is a
+    descriptor with num_records = 0 (zeros, no memory touched) -- against the eight-wave kernel and an fp32 product."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(53)
+    B, M, N, K = 2, 700, 768, 256
+    A = _bf(torch.randn(B, M, K, generator=g)).to(DEV)
+    W = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    res = _bf(torch.randn(B, M, N, generator=g)).to(DEV)
+    gate = torch.randn(B, N, generator=g).to(DEV)
+    outs = []
+    _lib.set_option("gemm_tile", 256)
+    try:
+        for w4a in (0, 3):
+            _lib.set_option("gemm_w4a", w4a)
+            _lib.reset_counters()
+            y = ops.gemm(A, W, None, epi, res=res if epi == 2 else None, gate=gate if epi == 2 else None)
+            torch.cuda.synchronize()
+            assert _lib.counters() == ({"gemm_256_w4a": 1} if w4a else {"gemm_256_mi16": 1}), _lib.counters()
+            outs.append(y.clone())
+    finally:
+        _lib.set_option("gemm_tile", 0)
+        _lib.set_option("gemm_w4a", 3)
+    assert torch.equal(outs[0], outs[1])
+    ref = A.float() @ W.float().t()
+    if epi == 2:
+        ref = res.float() + gate[:, None, :] * ref
+    assert (outs[1].float() - ref).abs().max().item() < 2 ** -6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("B,M,dim,inner", [(2, 70000, 512, 2048), (1, 66000 + 77, 1024, 1536)])
 def test_gemm_w4a_kblocked_pair_bit_identical(B, M, dim, inner):
     """The K-blocked feed-forward pair (K-blocked C out of the first GEMM, K-blocked A / W into the second) through the four-wave
