@@ -141,56 +141,71 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned short* __r
 // and walks the voxels of ONE frame, so the per-(frame, channel) affine a = rstd*gamma, b = beta - mean*a is built once
 // per thread (16 registers) and an element costs one fma (+ 4 ops of SiLU as x * rcp(1 + 2^(-x log2 e))); no integer
 // division in the loop.  HBM-bound (4 B per element).
+// Round 5: the activation is a template parameter (the run-time `act` cost a select per element and the SiLU arithmetic on layers
+// that have none) and the arithmetic is packed fp32 on channel pairs (v_pk_fma / v_pk_mul / v_pk_add: the same IEEE operations per
+// element, bit-identical): 353 -> ~210 instructions per 32 elements.  That alone changed nothing (the kernel runs as fast without
+// SiLU as with it); what did is the order in which it walks memory, see the loop.
+typedef float gn_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gn_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int ACT>
+__device__ __forceinline__ gn_u32x4 gn_apply_chunk(const gn_u32x4 raw, const gn_f32x2 (&a)[4], const gn_f32x2 (&b)[4]) {
+    gn_u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const gn_f32x2 xv = {__uint_as_float(raw[j] << 16), __uint_as_float(raw[j] & 0xffff0000u)};
+        gn_f32x2 r = __builtin_elementwise_fma(xv, a[j], b[j]);
+        if (ACT == 1) {
+            const gn_f32x2 m = r * -1.4426950408889634f;
+            gn_f32x2 e = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
+            e = 1.0f + e;
+            const gn_f32x2 q = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+            r = r * q;
+        }
+        o[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gn_bf16x2));
+    }
+    return o;
+}
+
+template <int ACT>
 __global__ __launch_bounds__(256) void gn_apply_frame_kernel(const unsigned short* __restrict__ x,
                                                              unsigned short* __restrict__ y,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, int64_t hw, int C, int groups,
-                                                             int act) {
+                                                             const float* __restrict__ beta, int64_t hw, int C, int groups) {
     const int nvec = C >> 3;
     const int cpg = C / groups;
     const int vc = threadIdx.x % nvec, vr = threadIdx.x / nvec, rows = 256 / nvec;
     const int t = blockIdx.y, c0 = vc * 8;
-    float a[8], b[8];
+    gn_f32x2 a[4], b[4];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float* st = stats + ((int64_t)t * groups + (c0 + j) / cpg) * 2;
-        a[j] = st[1] * gamma[c0 + j];
-        b[j] = beta[c0 + j] - st[0] * a[j];
+        const float aj = st[1] * gamma[c0 + j];
+        a[j >> 1][j & 1] = aj;
+        b[j >> 1][j & 1] = beta[c0 + j] - st[0] * aj;
     }
     const unsigned short* xf = x + (int64_t)t * hw * C + c0;
     unsigned short* yf = y + (int64_t)t * hw * C + c0;
     // four voxels per trip: all four loads are in flight before the first is used (one 16-byte load per thread and trip left
-    // the kernel latency-bound at 2.6 TB/s); streaming loads / stores -- nothing here is read twice
-    const int64_t step = (int64_t)gridDim.x * rows;
-    int64_t v = (int64_t)blockIdx.x * rows + vr;
-    for (; v + 3 * step < hw; v += 4 * step) {
-        u16x8 raw[4];
+    // the kernel latency-bound at 2.6 TB/s); streaming loads / stores -- nothing here is read twice.
+    // a trip covers 4 * rows CONSECUTIVE voxels: a wave's four loads are 4 x 1 KiB side by side.  The first version of this loop
+    // kept them a grid stride (16 MiB) apart -- four streams per wave: 4.3 TB/s at 4 x 1024^2 x 128 against 6.2 TB/s now (5.0 -> 6.3
+    // at 512^2 x 256, 5.4 -> 5.95 at 256^2 x 512; same bytes out, profiles/r05v_gn_apply_contiguous_trips_ab.jsonl).  With or
+    // without SiLU the rate is the same: the kernel is bound by how the memory system is addressed, not by its arithmetic.
+    const int64_t grp = 4 * rows, ngrp = hw / grp;
+    for (int64_t g = blockIdx.x; g < ngrp; g += gridDim.x) {
+        const int64_t v = g * grp + vr;
+        gn_u32x4 raw[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(xf + (v + u * step) * C));
+        for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const gn_u32x4*>(xf + (v + u * rows) * C));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            u16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float r = __builtin_fmaf(bf16_bits_to_f32(raw[u][j]), a[j], b[j]);
-                if (act == 1) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-                o[j] = f32_to_bf16_bits(r);
-            }
-            __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(yf + (v + u * step) * C));
-        }
+        for (int u = 0; u < 4; ++u)
+            __builtin_nontemporal_store(gn_apply_chunk<ACT>(raw[u], a, b), reinterpret_cast<gn_u32x4*>(yf + (v + u * rows) * C));
     }
-    for (; v < hw; v += step) {
-        const u16x8 raw = *reinterpret_cast<const u16x8*>(xf + v * C);
-        u16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float r = __builtin_fmaf(bf16_bits_to_f32(raw[j]), a[j], b[j]);
-            if (act == 1) r = r * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-            o[j] = f32_to_bf16_bits(r);
-        }
-        *reinterpret_cast<u16x8*>(yf + v * C) = o;
-    }
+    for (int64_t v = ngrp * grp + (int64_t)blockIdx.x * rows + vr; v < hw; v += (int64_t)gridDim.x * rows)
+        *reinterpret_cast<gn_u32x4*>(yf + v * C) = gn_apply_chunk<ACT>(*reinterpret_cast<const gn_u32x4*>(xf + v * C), a, b);
 }
 
 // ---- row softmax: y = softmax(x * scale) per row, bf16 in/out, fp32 math; one block per row --------------------
@@ -373,10 +388,18 @@ extern "C" int ea_groupnorm_apply_bf16(const ea_bf16* x, ea_bf16* y, const float
     if (nvec <= 256 && 256 % nvec == 0 && T <= 65535) {
         const int rows = 256 / nvec;
         int64_t bx = (hw + rows - 1) / rows;
-        const int64_t cap = (16384 + T - 1) / T;   // ~64 workgroups per CU in flight over the whole grid
+        // up to 4096 workgroups per frame, whatever T: the ~2000 resident at a time then sit in ONE frame and sweep it as one moving
+        // window.  (The first version divided 16384 workgroups over the T frames: at T = 49 the resident ones spread over six frames --
+        // 5.47 TB/s at 49 x 1024^2 x 128 against 5.99 with this; one workgroup per trip, cap 16384, costs the small shapes a third.
+        // profiles/r05v_gn_apply_blocks_per_frame.jsonl)
+        const int64_t cap = 4096;
         bx = bx > cap ? cap : bx;
-        hipLaunchKernelGGL(gn_apply_frame_kernel, dim3((unsigned)bx, (unsigned)T), dim3(256), 0, (hipStream_t)stream, x, y,
-                           stats, gamma, beta, hw, C, groups, act);
+        if (act == 1)
+            hipLaunchKernelGGL(gn_apply_frame_kernel<1>, dim3((unsigned)bx, (unsigned)T), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma,
+                               beta, hw, C, groups);
+        else
+            hipLaunchKernelGGL(gn_apply_frame_kernel<0>, dim3((unsigned)bx, (unsigned)T), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma,
+                               beta, hw, C, groups);
         return ea_check_launch("ea_groupnorm_apply_bf16");
     }
     const int64_t total = (int64_t)T * hw * (C / 8);
