@@ -1,6 +1,7 @@
 """GroupNorm-apply (+SiLU) at the VAE's full-resolution shape (4 frames x 1024^2 x 128 channels) with the library EA_LIB_PATH names:
 time, effective HBM rate (4 B per element) and a checksum of the output (two builds that print the same checksum on the same seed are
-bit-identical).      EA_LIB_PATH=... python tools/ab_gn_apply_lib.py"""
+bit-identical).      EA_LIB_PATH=... [EA_GN_CLIP=1] python tools/ab_gn_apply_lib.py
+EA_GN_CLIP=1: the whole-clip shapes a 49 x 1024^2 decode launches (T = 49 / 25 / 13) instead of 4-frame chunks."""
 import hashlib, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,5 +22,5 @@ for T, H, W, C, G in SHAPES:
         torch.cuda.synchronize()
         h = hashlib.sha256(y.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
         ms = timeit(lambda: ops.groupnorm_apply(x, stats, gamma, beta, G, act=act), warm=2, iters=10)
-        print(json.dumps({"lib": lib, "cap": os.environ.get("EA_GN_CAP", "default"), "shape": [T, H, W, C], "silu": act, "ms": round(ms, 4), "TB_per_s": round(x.numel() * 4 / ms / 1e9, 3), "sha256_16": h}), flush=True)
+        print(json.dumps({"lib": lib, "shape": [T, H, W, C], "silu": act, "ms": round(ms, 4), "TB_per_s": round(x.numel() * 4 / ms / 1e9, 3), "sha256_16": h}), flush=True)
     del x
