@@ -170,3 +170,16 @@ def test_compiler_leaves_the_accumulators_alone(isa, src, name, loop_mfmas):
     assert n_loop_mfma == loop_mfmas and loops_ok
     print(f"[isa] {name}: arch VGPRs {meta['.amdhsa_accum_offset']}, compiler AGPR spill writes / reads behind the main loop: {n_w} / {n_r}")
     assert not errors, "\n".join(errors[:10])
+
+
+@pytest.mark.parametrize("gen,inc", [("gen_gemm_w4_asm.py", "ea_gemm_w4_loop.inc"), ("gen_conv_w4_asm.py", "ea_conv_w4_loop.inc")])
+def test_committed_loops_are_what_the_generators_write(gen, inc, tmp_path):
+    """The .inc files are generated (tools/gen_*_w4_asm.py, default switches) and committed: a hand edit, or a generator change
+    without regenerating, would leave the build on code that the schedule tables no longer describe."""
+    import sys
+    out = str(tmp_path / inc)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("EA_W4A_")}
+    env["EA_GEN_OUT"] = out
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert open(out).read() == open(os.path.join(CSRC, inc)).read()

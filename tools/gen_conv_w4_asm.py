@@ -22,7 +22,7 @@ Fixed registers: accumulators a0..a255 (acc(i, j) = 4 * (8 j + i), the read-out 
 double buffer v0..v127, fragment addresses v128..v131 (a_k[dw = 0, 1, 2], w_k), scalars s80..s101."""
 import os
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "easyanimate_amd", "csrc", "ea_conv_w4_loop.inc")
+OUT = os.environ.get("EA_GEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "easyanimate_amd", "csrc", "ea_conv_w4_loop.inc")     # EA_GEN_OUT: write somewhere else (tests/test_w4a_isa_cpu.py compares with the committed file)
 
 FW = [0, 64]
 FA = [32, 96]

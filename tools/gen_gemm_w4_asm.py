@@ -29,7 +29,7 @@ import os
 TOP_PROG = os.environ.get("EA_W4A_TOP", "drain") == "prog"
 BAR1 = int(os.environ.get("EA_W4A_BAR1", "20"))
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "easyanimate_amd", "csrc", "ea_gemm_w4_loop.inc")
+OUT = os.environ.get("EA_GEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "easyanimate_amd", "csrc", "ea_gemm_w4_loop.inc")     # EA_GEN_OUT: write somewhere else (tests/test_w4a_isa_cpu.py compares with the committed file)
 
 # fixed registers
 FW = [0, 64]      # first VGPR of W fragment buffer b (8 fragments x 4 registers)
