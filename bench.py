@@ -40,6 +40,8 @@ CONFIGS = {
                     "(i2v_conditioning) -- BASELINE config 5 on ONE of its four GPUs",
                layers=48, frames=49, height=768, width=768, in_channels=33),
     "tiny": dict(desc="2-layer d=3072 DiT, 5f x 128x128 (debug)", layers=2, frames=5, height=128, width=128),
+    "small": dict(desc="2-layer d=3072 DiT, 9f x 256x256 = 768 video tokens (debug: enough tokens for 8 sequence shards)",
+                  layers=2, frames=9, height=256, width=256),
 }
 
 
@@ -198,6 +200,22 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+_STAGE = {"stage": "start"}
+
+
+def _stage(name: str) -> None:
+    _STAGE["stage"] = name
+
+
+def _error_line(args, world: int, rank: int, err: str) -> str:
+    """What rank 0 prints INSTEAD of the result line when a run dies (VERDICT r5 next #3b): the same keys a reader of the result
+    line looks for, value null, the stage the rank was in and the error -- one JSON line, not a launcher traceback."""
+    return json.dumps({"metric": "denoise-steps/sec (49f x 1024^2, 12B DiT)" if args.config == "c3" else f"denoise-steps/sec ({args.config})",
+                       "value": None, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                       "error": err, "stage": _STAGE["stage"], "rank": rank,
+                       "env": {k: os.environ.get(k) for k in ("EA_SP_MODE", "EA_SP_GROUPS", "EA_SP_INPLACE", "NCCL_MAX_NCHANNELS")}})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,9 +247,42 @@ def main():
         args.gpus = world
     # EA_BENCH_SHARED_DEVICE=1 (testing only, 1-GPU box): every rank uses cuda:0 and the rendezvous is gloo -- RCCL
     # refuses two ranks on one device; the timing of such a run means nothing, it exercises the multi-rank code path.
+    if world > 1:
+        # a multi-rank run that dies must still leave ONE JSON line on rank 0's stdout: exceptions on this rank are caught below;
+        # when ANOTHER rank dies first the launcher sends SIGTERM to the survivors, which rank 0 turns into the same line
+        import signal
+        import traceback
+
+        def on_term(signum, frame):
+            if rank == 0:
+                print(_error_line(args, world, rank, "terminated by the launcher (SIGTERM): another rank failed first -- its "
+                                                     "traceback is on stderr"), flush=True)
+            os._exit(1)
+        signal.signal(signal.SIGTERM, on_term)
+        try:
+            return _run(args, world, rank, local_rank)
+        except BaseException as ex:      # noqa: BLE001  (SystemExit included: argument errors inside _run)
+            if isinstance(ex, SystemExit) and ex.code in (0, None):
+                raise
+            traceback.print_exc()
+            line = _error_line(args, world, rank, f"{type(ex).__name__}: {ex}")
+            print(line, file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+            if rank != 0:
+                try:    # hand the line to rank 0's watchdog (it may sit in a collective's C++ wait, where no signal handler runs)
+                    import torch.distributed as dist
+                    dist.distributed_c10d._get_default_store().set("ea_bench_error", line)
+                    time.sleep(2.0)
+                except Exception:   # noqa: BLE001
+                    pass
+            os._exit(1)                 # no destroy_process_group: the other ranks may be inside a collective
+    return _run(args, world, rank, local_rank)
+
+
+def _run(args, world: int, rank: int, local_rank: int):
     shared = os.environ.get("EA_BENCH_SHARED_DEVICE") == "1"
     if shared:
         local_rank = 0
+    _stage("set_device")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -242,17 +293,39 @@ def main():
         # stretch the exchange beyond the own-slot pass that hides it (every exposed ms is paid 48 times per step), too many
         # cost the attention kernel a few percent for ~2 ms per block -- the asymmetric risk favours RCCL's own default until
         # a multi-GPU node has measured the knee
+        import datetime
+        _stage("init_process_group")
+        # a hang must end in minutes, not in the driver's timeout: 5 minutes cover RCCL's lazy communicator set-up on 8 ranks
+        tmo = datetime.timedelta(seconds=int(os.environ.get("EA_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if shared:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
+        if rank == 0:
+            # watchdog: another rank that dies hands its error line over through the rendezvous store; this thread prints it as
+            # rank 0's ONE JSON line even while the main thread is blocked inside a collective, then ends the process
+            import threading
+            store = dist.distributed_c10d._get_default_store()
+
+            def watch():
+                while True:
+                    time.sleep(0.5)
+                    try:
+                        if store.check(["ea_bench_error"]):
+                            print(store.get("ea_bench_error").decode(), flush=True)
+                            os._exit(1)
+                    except Exception:   # noqa: BLE001  (store gone: the run is over)
+                        return
+            threading.Thread(target=watch, daemon=True).start()
 
     from easyanimate_amd import FlowMatchEulerDiscreteScheduler, ops, sequence_parallel
     from easyanimate_amd.pipeline import EasyAnimatePipeline
 
     cfg = CONFIGS[args.config]
+    _stage("build_model")
     model = build_model(cfg["layers"], device, cfg.get("in_channels", 16))
     if world > 1:
+        _stage("sequence_parallel.enable (sub-groups)")
         sequence_parallel.enable(model, mode=args.sp_mode)
     emu = None
     if args.emulate_rank:
@@ -286,10 +359,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("EA_BENCH_FAULT_RANK") == str(rank):     # tests: this rank dies in its first forward
+        def _boom(*a, **k):
+            raise RuntimeError("EA_BENCH_FAULT_RANK: injected failure in the first forward")
+        model.forward = _boom
     with torch.no_grad():
+        _stage("warmup (first forward: RCCL communicators, first-use check of the in-place all-gather)" if world > 1 else "warmup")
         if W > 0:
             latents = pipe.denoise(latents, embeds, rope, sched.timesteps[:W], 6.0, inpaint_latents=inpaint)
         sync()
+        _stage("timed steps")
         if world > 1:
             model.sequence_parallel.profile_wait = True    # HIP events around every stream-level wait for a collective
         t0 = time.perf_counter()
@@ -298,6 +377,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
     elapsed_own = elapsed
+    _stage("report")
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -365,14 +445,26 @@ def main():
                    "finite_output": finite},
         "roofline": {"bound": "mfma", "kernel": "attention_fwd_v3_kernel (ea_attention_fwd_bf16 / _range_bf16)",
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": traffic, "flop_per_launch": att_flop, "avg_launch_ms": att_ms,
+                     "traffic": traffic,
+                     "traffic_source": None if traffic is None else "profiles/attention_hbm_bytes_per_launch.json: rocprofv3 --pmc FETCH_SIZE / "
+                                       "WRITE_SIZE passes of a builder run on this build (sha-matched), replayed -- not measured in this run",
+                     "flop_per_launch": att_flop, "avg_launch_ms": att_ms,
                      "launches_timed": len(durs), "launches_per_block": len(durs) / max(n_blocks, 1)},
     }
     if world > 1:
         out["rccl"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
                        "devices": sorted(set(gathered_devices)), "launched_by": os.environ.get("TORCHELASTIC_RUN_ID", "external")}
         out["rank_agreement"] = len({r["latents_sha1"] for r in rank_reports}) == 1
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001
+            rccl_version = None
+        out["rccl"].update({"rccl_version": rccl_version, "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                            "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")})
         out["exchange"] = {"mode": model.sequence_parallel.mode,
+                           # false = the first-use check of the in-place all-gather failed on some rank and every rank fell back
+                           "inplace": bool(model.sequence_parallel.inplace), "inplace_requested": bool(model.sequence_parallel.inplace_requested),
                            "head_groups": model.sequence_parallel.head_groups(H) if model.sequence_parallel.mode == "keys" else 1,
                            "what": "per rank: time the compute stream spent between two HIP events around each wait for a collective "
                                    "(the EXPOSED part of the exchange), per denoise step; step_ms = the rank's own wall time per step",

@@ -34,6 +34,7 @@ Communication and indexing only (no arithmetic): works on any device; covered by
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -41,6 +42,7 @@ import torch.distributed as dist
 
 _ACTIVE: Optional["TemporalParallel"] = None
 _SUBGROUPS: dict = {}
+_WORLD_REF = None      # weakref to the default process group _SUBGROUPS was filled under
 
 
 def _subgroups(rank_lists: List[List[int]], parent: Optional[dist.ProcessGroup]) -> dist.ProcessGroup:
@@ -54,13 +56,19 @@ def _subgroups(rank_lists: List[List[int]], parent: Optional[dist.ProcessGroup])
       world-collective call cannot be made; the groups are created member-locally (`use_local_synchronization=True`) -- possible
       only when the default group has no eagerly bound communicator to split from; otherwise the caller has to create the groups
       up front, world-collectively."""
-    # (keyed by the default group's NAME -- c10d numbers its groups with a per-process counter, so a world built after
-    # destroy_process_group() never has the name of the old one, while id() of the new object may repeat; entries of a world that
-    # is gone are evicted)
-    world_name = dist.distributed_c10d._get_default_group().group_name
-    for k in [k for k in _SUBGROUPS if k[0] != world_name]:
-        del _SUBGROUPS[k]
-    key = (world_name,) + tuple(tuple(r) for r in rank_lists)
+    # The cache belongs to ONE world: the default-group OBJECT it was filled under, held by weak reference and compared by identity.
+    # (Not its name -- c10d restarts its group counter when the world is destroyed, so every default group is named "0" -- and not a
+    # bare id(), which a later object may reuse; ADVICE r5.)  A world that is gone takes its sub-groups with it; cached groups are
+    # also checked against c10d's own registry before they are handed out again.
+    global _WORLD_REF
+    default = dist.distributed_c10d._get_default_group()
+    if _WORLD_REF is None or _WORLD_REF() is not default:
+        _SUBGROUPS.clear()
+        _WORLD_REF = weakref.ref(default)
+    key = tuple(tuple(r) for r in rank_lists)
+    pg_map = dist.distributed_c10d._world.pg_map
+    if key in _SUBGROUPS and any(isinstance(g, dist.ProcessGroup) and g not in pg_map for g in _SUBGROUPS[key].values()):
+        del _SUBGROUPS[key]
     me = dist.get_rank()
     if key not in _SUBGROUPS:
         world = dist.get_world_size()

@@ -904,6 +904,127 @@ def gen_swa_long(ns, shim):
                     floor_mse=_mse(outb.float(), out)), os.path.join(OUT, "transformer_swa_long.pt"))
 
 
+DIT_12B = dict(FULL_DIT, num_layers=48)                       # BASELINE configs[2]: 12B (v5 MMDiT), SURVEY Appendix B
+DIT_12B_INP = dict(FULL_DIT, num_layers=48, in_channels=33)   # BASELINE configs[4]: 12B InP (image-latent concat)
+DEPTH_TAPS = (1, 12, 24, 48)          # residual streams kept after these many blocks
+TAP_VIDEO_STRIDE, TAP_TEXT_STRIDE = 256, 4
+
+
+def config3_inputs():
+    """BASELINE.json configs[2]: 12B DiT at 49 x 1024 x 1024 -> latents [1,16,13,128,128] (53 248 video + 256 text tokens,
+    S = 53 504); the text embedding of the CONDITIONAL sample (the CFG pair's second element).  bf16-representable values."""
+    enc = (torch.randn(1, 256, 3584, generator=_g(71)) * 3).bfloat16().float()
+    latents = torch.randn(1, 16, 13, 128, 128, generator=_g(72)).bfloat16().float()
+    return latents, None, enc
+
+
+def config5_inputs():
+    """BASELINE.json configs[4]: 12B InP DiT at 49 x 768 x 768 -> latents [1,16,13,96,96] (29 952 video + 256 text tokens,
+    S = 30 208) with the 17 conditioning channels pipeline_easyanimate_inpaint.py:1383 concatenates: the resized mask (0 on the
+    first latent frame, 1 elsewhere: the I2V case of utils/utils.py:152-157) in front of 16 channels of masked-video latents
+    (synthetic N(0, 0.5^2); the real ones are a VAE encode, config 4's subject).  bf16-representable values."""
+    enc = (torch.randn(1, 256, 3584, generator=_g(81)) * 3).bfloat16().float()
+    latents = torch.randn(1, 16, 13, 96, 96, generator=_g(82)).bfloat16().float()
+    mask = torch.ones(1, 1, 13, 96, 96)
+    mask[:, :, 0] = 0
+    inp = torch.cat([mask, (torch.randn(1, 16, 13, 96, 96, generator=_g(83)) * 0.5).bfloat16().float()], 1)
+    return latents, inp, enc
+
+
+def _streamed_reference(ns, cfg, seed, style, dtype, taps):
+    """The UNCHANGED reference EasyAnimateTransformer3DModel with its blocks' weights STREAMED: the module tree is built on the
+    meta device, everything outside `transformer_blocks` is filled once, and each EasyAnimateDiTBlock is filled from
+    synth_tensor by a forward-pre hook and returned to the meta device by a forward hook -- the 47 GB of fp32 block weights of
+    the 12B model never coexist (one block = 0.9 GB).  The reference's own forward (transformer3d.py:1496-1689) drives the
+    blocks; nothing of it is restated.  taps: {n: (video rows, text rows)} of the residual streams after n blocks."""
+    with torch.device("meta"):
+        m = ns.transformer3d.EasyAnimateTransformer3DModel(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    head = {k: s for k, s in shapes.items() if not k.startswith("transformer_blocks.")}
+    sd = {k: v.to(dtype) for k, v in synth_state_dict(head, seed, style).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False, assign=True)
+    assert not unexpected and all(k.startswith("transformer_blocks.") for k in missing)
+
+    def fill(i):
+        def pre(blk, args, kwargs):
+            pre_ = f"transformer_blocks.{i}."
+            sub = {k[len(pre_):]: s for k, s in shapes.items() if k.startswith(pre_)}
+            vals = synth_state_dict({pre_ + k: s for k, s in sub.items()}, seed, style)
+            blk.load_state_dict({k: vals[pre_ + k].to(dtype) for k in sub}, strict=True, assign=True)
+        return pre
+
+    def drop(i):
+        def post(blk, args, kwargs, out):
+            blk.to("meta")
+            if i + 1 in taps:
+                h, e = out
+                taps[i + 1] = (h[0, ::TAP_VIDEO_STRIDE].float().clone(), e[0, ::TAP_TEXT_STRIDE].float().clone())
+            if (i + 1) % 4 == 0:
+                print(f"    block {i + 1}/{len(m.transformer_blocks)}: residual std video {out[0].float().std().item():.4f} "
+                      f"text {out[1].float().std().item():.4f}", flush=True)
+        return post
+
+    for i, blk in enumerate(m.transformer_blocks):
+        blk.register_forward_pre_hook(fill(i), with_kwargs=True)
+        blk.register_forward_hook(drop(i), with_kwargs=True)
+    return m.eval(), shapes
+
+
+def _depth_golden(ns, shim, name, cfg, inputs, grid, note):
+    import time
+    lat, inp, enc = inputs
+    Fr, gh, gw = grid
+    cc = ns.pipeline_easyanimate.get_resize_crop_region_for_grid((gh, gw), 45, 30)
+    rope = shim.get_3d_rotary_pos_embed(64, cc, (gh, gw), Fr, use_real=True)
+    s = shim.FlowMatchEulerDiscreteScheduler(shift=1.0)
+    s.set_timesteps(50, device="cpu", mu=1)
+    tt = torch.tensor([s.timesteps[0]]).to(torch.bfloat16).float()       # pipeline_easyanimate.py:1079-1081
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        taps = {n: None for n in DEPTH_TAPS}
+        m, shapes = _streamed_reference(ns, cfg, 0, "default_bf16", dtype, taps)
+        c = lambda x: None if x is None else x.to(dtype)
+        t0 = time.time()
+        with torch.no_grad():
+            v = m(c(lat), c(tt), encoder_hidden_states=c(enc), image_rotary_emb=rope, inpaint_latents=c(inp), return_dict=False)[0].float()
+        print(f"  {name}: {dtype} forward {time.time() - t0:.0f} s on {torch.get_num_threads()} threads; v std {v.std().item():.4f} "
+              f"|v| max {v.abs().max().item():.2f}", flush=True)
+        res[dtype] = (v, taps)
+        del m
+    v, taps = res[torch.float32]
+    vb, taps_b = res[torch.bfloat16]
+    floor_taps = {n: (_mse(taps_b[n][0], taps[n][0]), _mse(taps_b[n][1], taps[n][1])) for n in DEPTH_TAPS}
+    print(f"  {name}: reference bf16-vs-fp32 velocity MSE {_mse(vb, v):.3e}; residual-stream floors (video, text) by depth {floor_taps}", flush=True)
+    rec = dict(cfg=cfg, seed=0, style="default_bf16", timestep=float(tt), crops=cc, grid=grid, note=note,
+               v_sub_f16=v[..., ::2, ::2].half().contiguous(), v_shape=tuple(v.shape), v_std=v.std().item(),
+               v_frame_sums=v.double().sum(dim=(0, 1, 3, 4)), v_abs_max=v.abs().max().item(),
+               floor_mse=_mse(vb, v), rel_l2_floor=((vb - v).double().norm() / v.double().norm()).item(),
+               floor_mse_sub=_mse(vb[..., ::2, ::2], v[..., ::2, ::2]),
+               fp16_storage_mse=_mse(v[..., ::2, ::2].half().float(), v[..., ::2, ::2]),
+               taps={n: (taps[n][0].half(), taps[n][1].half()) for n in DEPTH_TAPS},
+               tap_std={n: (taps[n][0].std().item(), taps[n][1].std().item()) for n in DEPTH_TAPS},
+               tap_floor_mse=floor_taps, tap_strides=(TAP_VIDEO_STRIDE, TAP_TEXT_STRIDE),
+               latents_sum=lat.double().sum().item(), enc_sum=enc.double().sum().item(),
+               inp_sum=None if inp is None else inp.double().sum().item())
+    torch.save(rec, os.path.join(OUT, f"{name}.pt"))
+
+
+@section("config3_forward")
+def gen_config3_forward(ns, shim):
+    # ---- VERDICT r5 next #1: BASELINE configs[2] at its DECLARED DEPTH x LENGTH -- the 12B model (L = 48, d = 3072) at
+    # 49 x 1024^2 (S = 53 504), the conditional sample (B = 1), first timestep of the 50-step Flow schedule: the unchanged
+    # reference in fp32 (2.3e15 FLOP, > 1 h of the 8 host cores), block-streamed, then its own bf16 forward (the floor).
+    _depth_golden(ns, shim, "config3_12b_49x1024_v0", DIT_12B, config3_inputs(), (13, 64, 64),
+                  "12B L=48 d=3072, 49f x 1024^2, S=53504, B=1 (conditional sample), block-streamed unchanged reference")
+
+
+@section("config5_forward")
+def gen_config5_forward(ns, shim):
+    # ---- BASELINE configs[4]: the 12B InP model (33 input channels) at 49 x 768^2 (S = 30 208), same protocol.
+    _depth_golden(ns, shim, "config5_12b_inp_49x768_v0", DIT_12B_INP, config5_inputs(), (13, 48, 48),
+                  "12B InP L=48 d=3072 Cin=33, 49f x 768^2, S=30208, B=1 (conditional sample), block-streamed unchanged reference")
+
+
 @torch.no_grad()
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)

@@ -336,3 +336,57 @@ def test_grouped_exchange_buffers(world, cfg_parallel):
     ret = mgr.dict()
     mp.spawn(_worker_groups, args=(world, _free_port(), cfg_parallel, ret), nprocs=world, join=True)
     assert len(ret) == world and all(ret[r][1] for r in range(world)), dict(ret)
+
+
+def _worker_selfcheck(rank, world, port, faulty_rank, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from easyanimate_amd.sequence_parallel import SequenceParallel
+        sp = SequenceParallel(cfg_parallel=True)
+        B, H, T, N = 2, 4, 64, 512
+        b0, b1 = sp.begin(B)
+        Bl = b1 - b0
+        sp.plan(N)
+        lo, hi = sp.shard_range()
+        lay = sp.layout(T, hi - lo)
+        buf = sp.kv_buffer(Bl, H, lay, "cpu", torch.float32)
+        gen = lambda r: torch.full((2, Bl, H, lay.rows * 64), 10.0 * sp.axis.cfg_rank + r + 0.25)
+        buf[sp.rank].copy_(gen(sp.rank))
+        # ONE rank of the world sees the in-place gather disagree with the out-of-place one (injected: gloo has no in-place form)
+        sp._selfcheck_fault = lambda s: 1 if s.world_rank == faulty_rank else 0
+        assert sp.inplace and not sp._inplace_checked
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            sp.exchange_finish(sp.exchange_start(buf))
+        first_ok = all(torch.equal(buf[r], gen(r)) for r in range(sp.size))
+        # every rank -- the faulty one's CFG half and the other half alike -- agreed on the verdict and fell back; the exchange of
+        # the call that ran the check is complete; later exchanges take the out-of-place form (a receive buffer comes back)
+        fell_back = (not sp.inplace) and sp._inplace_checked and sp.inplace_requested and len(w) == 1
+        buf[sp.rank].copy_(gen(sp.rank) + 1)
+        for r in range(sp.size):
+            if r != sp.rank:
+                buf[r].zero_()
+        other = sp.exchange_finish(sp.exchange_start(buf))
+        src = other if other is not None else buf
+        later_ok = all(torch.equal(src[r], gen(r) + 1) for r in range(sp.size) if r != sp.rank)
+        ret[rank] = (first_ok, fell_back, later_ok, faulty_rank < 0)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,faulty_rank", [(4, 3), (3, 0), (4, -1)])
+def test_inplace_selfcheck_verdict_is_agreed_and_falls_back(world, faulty_rank):
+    """VERDICT r5 weak #11 / next #3a: the first-use check of the in-place K / V^T all-gather must never leave the ranks in
+    different states.  One rank reporting a mismatch (injected) makes EVERY rank of the world -- both CFG halves -- switch to the
+    out-of-place exchange, with a warning instead of an exception, and the exchange that carried the check is complete; with no
+    fault (faulty_rank = -1) every rank stays in place."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_selfcheck, args=(world, _free_port(), faulty_rank, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        first_ok, fell_back, later_ok, clean = ret[r]
+        assert first_ok and later_ok, (r, ret[r])
+        assert fell_back == (not clean), (r, ret[r])

@@ -283,6 +283,53 @@ def test_bench_self_launches_its_ranks():
         assert r2.returncode != 0 and "one rank per GPU" in r2.stderr
 
 
+def _bench(args, env, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args, "--no-cpu-baseline", "--no-vae"], env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_world_sizes_the_driver_does_not_try():
+    """VERDICT r5 next #3c: `bench.py --gpus N` for N that does not divide the 48 heads evenly into CFG x sequence ranks the way
+    2 / 4 / 8 do: N = 3 (odd: no CFG split, three sequence shards, three head groups of 16) and N = 8 (CFG 2 x sequence 4, the
+    driver's largest world) in both exchange modes, N = 6 (CFG 2 x sequence 3) -- ranks sharing cuda:0 over gloo.  Every run must
+    end with ONE JSON line, bit-identical final latents on all ranks, and the partition it claims."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["EA_BENCH_SHARED_DEVICE"] = "1"
+    for n, mode, par in ((3, "keys", "cfg1 x sp3"), (8, "keys", "cfg2 x sp4"), (8, "heads", "cfg2 x sp4"), (6, "keys", "cfg2 x sp3")):
+        r, out = _bench(["--gpus", str(n), "--config", "small", "--steps", "1", "--warmup", "1", "--sp-mode", mode], env)
+        assert r.returncode == 0 and len(out) == 1, (n, mode, r.stderr[-3000:], r.stdout[-1000:])
+        o = out[0]
+        print(f"[bench --gpus {n} --sp-mode {mode}]", o["config"]["parallelism"][:12], o["exchange"]["inplace"], o["rank_agreement"],
+              o["exchange"]["per_rank"][0])
+        assert o["n_gpus"] == n and o["value"] > 0 and o["config"]["finite_output"] and o["rank_agreement"] is True
+        assert o["config"]["parallelism"].startswith(par) and o["exchange"]["mode"] == mode and len(o["exchange"]["per_rank"]) == n
+        assert o["exchange"]["inplace"] is True and "rccl_version" in o["rccl"]
+
+
+def test_bench_failure_leaves_one_json_error_line():
+    """VERDICT r5 next #3b: a rank that dies inside the first sequence-parallel forward (injected on rank 1 of 2, and on rank 0)
+    must leave rank 0's stdout with ONE JSON line carrying "error" and the stage, and a non-zero exit code -- not a hang until
+    the collective timeout and not only a launcher traceback."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["EA_BENCH_SHARED_DEVICE"] = "1"
+    for faulty in ("1", "0"):
+        env["EA_BENCH_FAULT_RANK"] = faulty
+        t0 = time.time()
+        r, out = _bench(["--gpus", "2", "--config", "tiny", "--steps", "1", "--warmup", "1"], env, timeout=600)
+        took = time.time() - t0
+        print(f"[bench --gpus 2, rank {faulty} fails in its first forward] rc {r.returncode}, {took:.0f} s, line:", out)
+        assert r.returncode != 0 and len(out) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+        assert out[0]["value"] is None and "injected failure" in out[0]["error"] and out[0]["stage"].startswith("warmup")
+        assert out[0]["rank"] == int(faulty) and took < 280          # well inside the 300 s collective timeout
+
+
 # ---- ONE four-rank world (CFG 2 x sequence 2, the ranks share cuda:0) for every full-width case -----------------------------------
 # Round 5 (VERDICT r4 next #3): these used to be five separate spawns, each rank of each building the same 0.5-billion-parameter
 # model on the CPU (default init + synthetic fill) -- 45 s per test, 225 s of the suite.  Now the parent generates each model's

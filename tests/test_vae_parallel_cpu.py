@@ -326,3 +326,31 @@ def test_subgroups_are_cached_and_world_collective():
     ret = mgr.dict()
     mp.spawn(_subgroup_worker, args=(4, _free_port(), ret), nprocs=4, join=True)
     assert len(ret) == 4 and all(a and b for a, b in ret.values()), dict(ret)
+
+
+def _rebuilt_world_worker(rank, world, port, ret):
+    from easyanimate_amd import vae_parallel
+    seen, ok = [], True
+    for it in range(3):                 # init -> destroy -> init in ONE process: every default group is named "0" again
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + it))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        g = vae_parallel._subgroups([[0], [1]], None)
+        ok = ok and vae_parallel._subgroups([[0], [1]], None) is g and g not in seen        # cached inside a world, never across worlds
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, group=g)     # a group of the destroyed world would raise or hang here
+        ok = ok and t.item() == float(rank + 1) and dist.distributed_c10d._get_default_group().group_name == "0"
+        seen.append(g)
+        dist.barrier()
+        dist.destroy_process_group()
+    ret[rank] = ok
+
+
+def test_subgroup_cache_does_not_survive_its_world():
+    """c10d restarts its group counter when the world is destroyed, so a cache keyed by the default group's name hands
+    a rebuilt world the sub-groups of the destroyed one.  The cache is tied to the default-group object (weak reference, identity)
+    and to c10d's registry: each world gets fresh, working groups."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rebuilt_world_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert len(ret) == 2 and all(ret.values()), dict(ret)
