@@ -66,18 +66,7 @@ def build_model(layers: int, device, in_channels: int = 16):
     return m.eval()
 
 
-def cpu_baseline(S_bench: int, budget_s: float = 25.0):
-    """The oracle restatement (a port: kind="port") on the host cores, fp32, on a bounded sample, extrapolated to one
-    denoise step of the benchmark shape.  The two parts of a block scale differently with the sequence length S, so they
-    are timed and extrapolated SEPARATELY: (i) one full-width MMDiT block at B=1, 1024 video + 256
-    text tokens, where the linear layers are 97 % of the FLOPs -> seconds per token of everything but the SDPA; (ii) the
-    oracle's attention call (F.scaled_dot_product_attention, 48 heads x 64) alone at S=4096 -> seconds per S^2.
-    Returns (seconds per block and sample at S_bench, description)."""
-    import torch.nn.functional as F
-    from easyanimate_amd.synthetic import synth_state_dict
-    from oracle import restatement as R
-    torch.set_num_threads(os.cpu_count() or 1)
-    d, H, T, N = 3072, 48, 256, 1024
+def _block_shapes(d=3072):
     shapes = {}
     for n in ("norm1", "norm2"):
         shapes.update({f"{n}.linear.weight": (6 * d, 512), f"{n}.linear.bias": (6 * d,), f"{n}.norm.weight": (d,), f"{n}.norm.bias": (d,)})
@@ -88,10 +77,49 @@ def cpu_baseline(S_bench: int, budget_s: float = 25.0):
             shapes.update({f"{a}.{l}.weight": (64,), f"{a}.{l}.bias": (64,)})
     for f in ("ff", "txt_ff"):
         shapes.update({f"{f}.net.0.proj.weight": (4 * d, d), f"{f}.net.0.proj.bias": (4 * d,), f"{f}.net.2.weight": (d, 4 * d), f"{f}.net.2.bias": (d,)})
-    sd = synth_state_dict(shapes, 0)
-    g = torch.Generator().manual_seed(0)
-    h, e, temb = torch.randn(1, N, d, generator=g), torch.randn(1, T, d, generator=g), torch.randn(1, 512, generator=g)
-    rope = R.rope_3d(64, ((0, 8), (30, 38)), (32, 32), 1)
+    return shapes
+
+
+def cpu_baseline(S_bench: int, grid, quick: bool = False, budget_s: float = 25.0, full_limit_s: float = 400.0):
+    """One MMDiT block of the benchmark shape on the host cores, fp32, B = 1 -- the UNCHANGED reference block
+    (easyanimate/models/attention.py:1028-1163 through oracle/ref_loader, kind "reference") where /root/reference exists (the build
+    container), else the oracle restatement (oracle/restatement.dit_block, kind "port"; measured bit-identical to the reference
+    block and equally fast, profiles/r04b_cpu_reference_vs_port.json).  SURVEY 8(d): time ONE BLOCK AT FULL S and report L x that.
+
+    Two stages: (1) a bounded sample -- one block at 1024 video + 256 text tokens and the SDPA alone at S = 4096, extrapolated
+    separately (linear in S / quadratic in S) -- which also warms the thread pool and predicts the full-S time; (2) unless `quick`
+    or the prediction exceeds full_limit_s, ONE block at the FULL sequence length (grid = (frames, h, w) patches; S = 53 504 at
+    config 3), measured, not extrapolated.  Returns (seconds per block and sample, kind, measured_at_full_S, threads, description)."""
+    import torch.nn.functional as F
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle import ref_loader
+    from oracle import restatement as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    d, H, T = 3072, 48, 256
+    sd = synth_state_dict(_block_shapes(d), 0)
+    crops = ((0, 8), (30, 38))
+    kind, blk, shim = "port", None, None
+    if ref_loader.available():
+        try:
+            ns = ref_loader.load()
+            blk = ns.attention.EasyAnimateDiTBlock(dim=d, num_attention_heads=H, attention_head_dim=64, time_embed_dim=512, norm_eps=1e-5,
+                                                   is_mmdit_block=True).eval()
+            blk.load_state_dict(sd, strict=True)
+            kind, shim = "reference", ns.shim
+        except Exception as ex:     # noqa: BLE001
+            print(f"[cpu_baseline] reference block not usable ({ex!r}); timing the port", file=sys.stderr)
+            blk = None
+
+    def block_fn(frames, gh, gw, seed):
+        g = torch.Generator().manual_seed(seed)
+        n = frames * gh * gw
+        h, e, temb = torch.randn(1, n, d, generator=g), torch.randn(1, T, d, generator=g), torch.randn(1, 512, generator=g)
+        if blk is not None:
+            rope = shim.get_3d_rotary_pos_embed(64, crops, (gh, gw), frames, use_real=True)
+            return lambda: blk(h, e, temb, image_rotary_emb=rope)
+        rope = R.rope_3d(64, crops, (gh, gw), frames)
+        return lambda: R.dit_block(sd, "", h, e, temb, rope, H, 1e-5)
 
     def timed(fn, budget, max_reps=3):
         fn()  # warm-up
@@ -102,52 +130,86 @@ def cpu_baseline(S_bench: int, budget_s: float = 25.0):
             reps += 1
         return (time.perf_counter() - t0) / max(reps, 1), reps
 
+    N = 1024
     S_s, S_a = T + N, 4096
+    g = torch.Generator().manual_seed(0)
     qs = torch.randn(1, H, S_s, 64, generator=g)
     qa = torch.randn(1, H, S_a, 64, generator=g)
     with torch.no_grad():
-        t_blk, r1 = timed(lambda: R.dit_block(sd, "", h, e, temb, rope, H, 1e-5), budget_s * 0.5)
+        t_blk, r1 = timed(block_fn(1, 32, 32, 0), budget_s * 0.5)
         t_att_s, _ = timed(lambda: F.scaled_dot_product_attention(qs, qs, qs), budget_s * 0.1)
         t_att_a, r2 = timed(lambda: F.scaled_dot_product_attention(qa, qa, qa), budget_s * 0.4)
     per_token = max(t_blk - t_att_s, 0.0) / S_s
     per_s2 = t_att_a / (S_a * S_a)
-    t_bench = per_token * S_bench + per_s2 * S_bench * S_bench
-    desc = (f"oracle/restatement.dit_block fp32, 1 full-width block, B=1, {N} video + {T} text tokens ({r1} reps, {t_blk:.2f} s; its SDPA "
-            f"{t_att_s:.2f} s) -> {per_token * 1e3:.3f} ms per token for the linear part; the oracle's SDPA alone at S={S_a} "
-            f"({r2} reps, {t_att_a:.2f} s) -> {per_s2 * 1e9:.3f} ns per S^2; extrapolated separately to S={S_bench}: "
-            f"linear {per_token * S_bench:.1f} s + attention {per_s2 * S_bench * S_bench:.1f} s per block and sample")
-    return t_bench, desc
+    t_est = per_token * S_bench + per_s2 * S_bench * S_bench
+    what = ("the unchanged reference EasyAnimateDiTBlock (attention.py:1028-1163 via oracle/ref_loader)" if kind == "reference"
+            else "oracle/restatement.dit_block (the port; /root/reference is absent on this box)")
+    sample = (f"{what}, fp32, B=1, {threads} threads. Bounded sample: one block at {N} video + {T} text tokens ({r1} reps, {t_blk:.2f} s; its SDPA "
+              f"{t_att_s:.2f} s) -> {per_token * 1e3:.3f} ms per token; SDPA alone at S={S_a} ({r2} reps, {t_att_a:.2f} s) -> {per_s2 * 1e9:.3f} ns "
+              f"per S^2; extrapolated to S={S_bench}: {t_est:.1f} s per block and sample")
+    if quick or t_est > full_limit_s:
+        why = "--quick-cpu-baseline" if quick else f"the predicted full-S block time exceeds {full_limit_s:.0f} s on these {threads} cores"
+        return t_est, kind, False, threads, sample + f" -- REPORTED VALUE IS THIS EXTRAPOLATION ({why})"
+    with torch.no_grad():
+        fn = block_fn(*grid, 1)
+        t0 = time.perf_counter()
+        fn()
+        t_full = time.perf_counter() - t0
+    return t_full, kind, True, threads, (f"ONE BLOCK AT THE FULL SEQUENCE LENGTH S={S_bench} MEASURED: {t_full:.1f} s (one pass, after the warm "
+                                         f"bounded sample; the sample's extrapolation predicted {t_est:.1f} s). " + sample)
 
 
-def vae_cpu_baseline(frames: int = 5, size: int = 192):
-    """Oracle restatement of the VAE (oracle/restatement_vae.py, fp32, full width) on the host cores on a bounded sample
-    (5 x 192^2): MPix/s of decode and encode, not extrapolated (the rate is what is reported)."""
+def vae_cpu_baseline(quick: bool = False):
+    """The VAE on the host cores, fp32, full width: the unchanged reference AutoencoderKLMagvit (kind "reference", build container) or
+    the oracle restatement (oracle/restatement_vae.py, kind "port") at 9 x 256^2 (quick: 5 x 192^2), after one warm pass
+    at 5 x 64^2.  MPix/s of decode and encode; the rate is what is reported."""
     from easyanimate_amd import AutoencoderKLMagvit
     from easyanimate_amd.synthetic import synth_state_dict
+    from oracle import ref_loader
     from oracle import restatement_vae as RV
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_vae
-    threads = min(os.cpu_count() or 1, 32)   # oneDNN convolutions of this size get slower beyond a few dozen threads
+    # oneDNN's direct 3-D convolutions at these sizes get SLOWER beyond a few dozen threads (measured on the 256-core host of round 4:
+    # 32 threads beat 256), hence the cap; the DiT leg (GEMM / SDPA bound) uses every core
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     with torch.device("meta"):
         shapes = {k: tuple(v.shape) for k, v in AutoencoderKLMagvit(**bench_vae.FULL).state_dict().items()}
     sd = synth_state_dict(shapes, 2)
+    kind, vae = "port", None
+    if ref_loader.available():
+        try:
+            ns = ref_loader.load()
+            vae = ns.autoencoder_magvit.AutoencoderKLMagvit(**bench_vae.FULL).eval()
+            vae.load_state_dict(sd, strict=True)
+            kind = "reference"
+        except Exception as ex:     # noqa: BLE001
+            print(f"[vae_cpu_baseline] reference VAE not usable ({ex!r}); timing the port", file=sys.stderr)
+            vae = None
+    dec = (lambda z: vae.decode(z)[0]) if vae is not None else (lambda z: RV.vae_decode(sd, z, 32))
+    enc = (lambda v: vae.encode(v)[0].mode()) if vae is not None else (lambda v: RV.vae_encode_moments(sd, v, 32))
+    frames, size = (5, 192) if quick else (9, 256)
     g = torch.Generator().manual_seed(9)
-    video = torch.rand(1, 3, frames, size, size, generator=g) * 2 - 1
-    z = torch.randn(1, 16, (frames - 1) // 4 + 1, size // 8, size // 8, generator=g)
-    mpix = frames * size * size / 1e6
+    mk = lambda f, s_: (torch.rand(1, 3, f, s_, s_, generator=g) * 2 - 1, torch.randn(1, 16, (f - 1) // 4 + 1, s_ // 8, s_ // 8, generator=g))
     with torch.no_grad():
+        wv, wz = mk(5, 64)
+        dec(wz), enc(wv)            # warm pass
+        video, z = mk(frames, size)
         t0 = time.perf_counter()
-        RV.vae_decode(sd, z, 32)
+        dec(z)
         t_dec = time.perf_counter() - t0
         t0 = time.perf_counter()
-        RV.vae_encode_moments(sd, video, 32)
+        enc(video)
         t_enc = time.perf_counter() - t0
-    return {"decode_mpix_s": mpix / t_dec, "encode_mpix_s": mpix / t_enc, "unit": "MPix/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/restatement_vae fp32, full width, {frames} x {size}^2 (decode {t_dec:.1f} s, encode {t_enc:.1f} s, one pass each)"}
+    mpix = frames * size * size / 1e6
+    what = "the unchanged reference AutoencoderKLMagvit via oracle/ref_loader" if kind == "reference" else "oracle/restatement_vae (port)"
+    return {"decode_mpix_s": mpix / t_dec, "encode_mpix_s": mpix / t_enc, "unit": "MPix/s", "cores": threads, "kind": kind,
+            "sample": f"{what}, fp32, full width, {frames} x {size}^2 (decode {t_dec:.1f} s, encode {t_enc:.1f} s; one timed pass each after a "
+                      f"warm pass at 5 x 64^2); {threads} threads: oneDNN's 3-D convolutions slow down beyond a few dozen threads, so this leg "
+                      f"is capped at 32 while the DiT leg uses every core"}
 
 
-def vae_section(cpu: bool):
+def vae_section(cpu: bool, quick: bool = False):
     """BASELINE.json metric, second half: VAE decode / encode MPix/s at 49 x 1024^2 (config 4), same process, after the
     DiT steps.  Inputs are resident in HBM when the timed region starts."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -174,7 +236,7 @@ def vae_section(cpu: bool):
     del vae
     torch.cuda.empty_cache()
     if cpu:
-        out["cpu_baseline"] = vae_cpu_baseline()
+        out["cpu_baseline"] = vae_cpu_baseline(quick)
     return out
 
 
@@ -223,6 +285,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true",
+                    help="cpu_baseline from the bounded sample only (extrapolated to the benchmark's S) instead of one block measured at full S")
     ap.add_argument("--emulate-rank", default=None, metavar="P,r",
                     help="one GPU runs the per-step COMPUTE of rank r in a world of P ranks (no communication): a labelled "
                          "MODEL of the scaling curve, never a measurement of it")
@@ -485,7 +549,7 @@ def _run(args, world: int, rank: int, local_rank: int):
         # the other half of BASELINE.json's metric: the DiT is released first (the VAE's activations peak at ~80 GB)
         del model, pipe, latents, embeds, kt
         torch.cuda.empty_cache()
-        out["vae"] = vae_section(cpu=not args.no_cpu_baseline)
+        out["vae"] = vae_section(cpu=not args.no_cpu_baseline, quick=args.quick_cpu_baseline)
     if rank == 0 and world == 1 and not args.no_vae and args.config == "c5" and not emu:
         # BASELINE config 5 = the denoise loop PLUS its one VAE encode of the masked conditioning video (predict_i2v.py:
         # pipeline_easyanimate_inpaint.py:1346-1383): timed here through the product pipeline method, reported beside the loop
@@ -514,12 +578,12 @@ def _run(args, world: int, rank: int, local_rank: int):
         del vae, ip
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        t_block, sample = cpu_baseline(S)
+        t_block, kind, measured, threads, sample = cpu_baseline(S, (Fl, hl // 2, wl // 2), quick=args.quick_cpu_baseline)
         est_step_s = t_block * B * L
-        out["cpu_baseline"] = {"value": 1.0 / est_step_s, "unit": "denoise-steps/s", "cores": os.cpu_count() or 1,
-                               "kind": "port", "sample": sample + f"; x B={B} x L={L} blocks = {est_step_s:.0f} s per denoise step"
-                               + " (the port against the unchanged reference block on the same weights / sample / cores in the build container: "
-                                 "bit-identical outputs, 0.379 s vs 0.385 s -- profiles/r04b_cpu_reference_vs_port.json)"}
+        out["cpu_baseline"] = {"value": 1.0 / est_step_s, "unit": "denoise-steps/s", "cores": threads, "kind": kind,
+                               "block_at_full_S_measured": measured, "seconds_per_block_and_sample": t_block,
+                               "sample": sample + f"; x B={B} x L={L} blocks = {est_step_s:.0f} s per denoise step (a full CPU step is "
+                                                  f"{B * L} such blocks: hours -- the per-block time is measured, the product is arithmetic)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

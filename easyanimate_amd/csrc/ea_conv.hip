@@ -1675,16 +1675,17 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
     [t_lo] "v"(t_lo), [t_hi] "v"(t_hi), [t_ext] "v"(t_ext), [ak0] "v"(ak[0]), [ak1] "v"(ak[1]), [ak2] "v"(ak[2]), [wk] "v"(wkf),   \
         [w_lo] "s"(w_lo), [w_hi] "s"(w_hi), [w_ext] "s"(w_ext), [cblocks] "s"(cblocks), [nslabs] "s"(nslabs), [cin2] "s"(cin2),     \
         [lds_w] "s"(lds_w), [lds_a] "s"(lds_a)
+    f32x4 accq[64];        // the 256 accumulators a0..a255, as the main asm's outputs: live until the read-outs consume them
     if constexpr (TM == 512) {
         asm volatile(EA_CONV_W4A_ASM_M512
-                     :
+                     : EA_W4A_ACC_OUTPUTS(accq)
                      : EA_CW4_COMMON, [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]),
                        [aoff4] "v"(a_voff[4]), [aoff5] "v"(a_voff[5]), [aoff6] "v"(a_voff[6]), [aoff7] "v"(a_voff[7]), [aoff8] "v"(a_voff[8]),
                        [woff0] "v"(w_voff[0]), [woff1] "v"(w_voff[1])
                      : EA_CONV_W4A_CLOBBERS);
     } else {
         asm volatile(EA_CONV_W4A_ASM_N256
-                     :
+                     : EA_W4A_ACC_OUTPUTS(accq)
                      : EA_CW4_COMMON, [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]),
                        [aoff4] "v"(a_voff[4]), [woff0] "v"(w_voff[0]), [woff1] "v"(w_voff[1]), [woff2] "v"(w_voff[2]), [woff3] "v"(w_voff[3])
                      : EA_CONV_W4A_CLOBBERS);
@@ -1696,9 +1697,9 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     f32x4 acc[8][4];
 #ifdef EA_CONV_DIRECT_EPILOGUE     // (diagnostic builds: the accumulator layout's own 8-byte stores)
-    EA_W4A_READ_HALF0(acc)
+    EA_W4A_READ_HALF0(acc, accq)
     conv_w4a_epilogue<WM>(p, acc, col0 + wc * 128, wr, orow, w0, h_out, t_out, tiles_w, tm, lane_e);
-    EA_W4A_READ_HALF1(acc)
+    EA_W4A_READ_HALF1(acc, accq)
     conv_w4a_epilogue<WM>(p, acc, col0 + wc * 128 + 64, wr, orow, w0, h_out, t_out, tiles_w, tm, lane_e);
 #else
     __builtin_amdgcn_s_barrier();      // every wave is past its last fragment read: the stages become the epilogue images (2 x 16 KiB per wave)
@@ -1714,11 +1715,11 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
     f32x4 b4[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) b4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col_w + j * 16 + (lane_e >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    EA_W4A_READ_HALF0(acc)
+    EA_W4A_READ_HALF0(acc, accq)
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as the builtin (the compiler's bookkeeping sees it): bias vectors and residual rows, in flight under the read-out
     __builtin_amdgcn_sched_barrier(0);
     conv_w4a_epilogue_img<WM>(p, acc, img0, b4, col_w, wr, m0, h_out, t_out, tiles_w, tm, lane_e);
-    EA_W4A_READ_HALF1(acc)
+    EA_W4A_READ_HALF1(acc, accq)
     conv_w4a_epilogue_img<WM>(p, acc, img1, b4 + 4, col_w + 64, wr, m0, h_out, t_out, tiles_w, tm, lane_e);
 #endif
 }

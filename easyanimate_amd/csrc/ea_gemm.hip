@@ -933,8 +933,9 @@ __global__ __launch_bounds__(256) void gemm256_w4a_kernel(GemmArgs p) {
     const unsigned long long ts1 = __builtin_readcyclecounter();
 #endif
 
+    f32x4_t accq[64];      // the 256 accumulators a0..a255, as the main asm's outputs: live until the read-outs consume them
     asm volatile(EA_W4A_MAINLOOP_ASM_BG
-                 : EA_W4A_BG_OUTPUTS(bias_v, gate_v)
+                 : EA_W4A_BG_OUTPUTS(bias_v, gate_v), EA_W4A_ACC_OUTPUTS(accq)
                  : [boff] "v"(boff), [b_lo] "s"(b_lo), [b_hi] "s"(b_hi), [b_ext] "s"(b_ext), [g_lo] "s"(g_lo), [g_hi] "s"(g_hi), [g_ext] "s"(g_ext),
                    [wk0] "v"(wk0), [ak0] "v"(ak0),
                    [aoff0] "v"(aoff[0]), [aoff1] "v"(aoff[1]), [aoff2] "v"(aoff[2]), [aoff3] "v"(aoff[3]),
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(256) void gemm256_w4a_kernel(GemmArgs p) {
         gemm_residual_request(p, b, img1, mrow0, col0 + wc * 128 + 64, lane);
     }
     f32x4_t acc[8][4];
-    EA_W4A_READ_HALF0(acc)
+    EA_W4A_READ_HALF0(acc, accq)
     if (EPI == EA_EPI_BIAS_GATE_RES) {
         // vmcnt(0) as the BUILTIN, so that the compiler's own wait bookkeeping sees it (an asm wait would leave it to place its
         // own in front of the image reads -- inside the per-column branches, and again in the middle of the stores)
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(256) void gemm256_w4a_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     }
     gemm_wave_epilogue<EPI, true>(p, b, acc, img0, mrow0, col0 + wc * 128, lane, bias_v, gate_v);
-    EA_W4A_READ_HALF1(acc)
+    EA_W4A_READ_HALF1(acc, accq)
     gemm_wave_epilogue<EPI, true>(p, b, acc, img1, mrow0, col0 + wc * 128 + 64, lane, bias_v + 4, gate_v + 4);
 #ifdef EA_GEMM_TIMESTAMPS
     if (g_gemm_ts && tid == 0) {
@@ -1305,10 +1306,11 @@ __global__ __launch_bounds__(256) void gemm256_qkv_w4a_kernel(QkvArgs q) {
         [woff6] "v"(woff[6]), [woff7] "v"(woff[7]), [a_lo] "s"(a_lo), [a_hi] "s"(a_hi), [a_ext] "s"(a_ext_s), [w_lo] "s"(w_lo),    \
         [w_hi] "s"(w_hi), [w_ext] "s"(w_ext_s), [a_kst] "s"(kst), [w_kst] "s"(kst), [nk] "s"(nk_s), [lds_w] "s"(lds_w),            \
         [lds_a] "s"(lds_a)
+    f32x4_t accq[64];      // the 256 accumulators a0..a255, as the main asm's outputs: live until the read-outs consume them
     if (which == 2) {
-        asm volatile(EA_W4A_MAINLOOP_ASM_SWAP : : EA_W4A_OPERANDS : EA_W4A_CLOBBERS);
+        asm volatile(EA_W4A_MAINLOOP_ASM_SWAP : EA_W4A_ACC_OUTPUTS(accq) : EA_W4A_OPERANDS : EA_W4A_CLOBBERS);
     } else {
-        asm volatile(EA_W4A_MAINLOOP_ASM : : EA_W4A_OPERANDS : EA_W4A_CLOBBERS);
+        asm volatile(EA_W4A_MAINLOOP_ASM : EA_W4A_ACC_OUTPUTS(accq) : EA_W4A_OPERANDS : EA_W4A_CLOBBERS);
     }
 #undef EA_W4A_OPERANDS
     __builtin_amdgcn_s_barrier();
@@ -1322,14 +1324,14 @@ __global__ __launch_bounds__(256) void gemm256_qkv_w4a_kernel(QkvArgs q) {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     f32x4_t acc[8][4];
     if (which == 2) {
-        EA_W4A_READ_HALF0(acc)
+        EA_W4A_READ_HALF0(acc, accq)
         qkv_epilogue_v(q, acc, img, biasb, head0 * 64, tok0, qkv_kv_base(q, b, head0), Mv, lane_e);
-        EA_W4A_READ_HALF1(acc)
+        EA_W4A_READ_HALF1(acc, accq)
         qkv_epilogue_v(q, acc, img, biasb, head0 * 64 + 64, tok0, qkv_kv_base(q, b, head0 + 1), Mv, lane_e);
     } else {
-        EA_W4A_READ_HALF0(acc)
+        EA_W4A_READ_HALF0(acc, accq)
         qkv_epilogue_qk(q, acc, img, biasb, head0 * 64, tok0, (int64_t)b * q.heads + head0, qkv_kv_base(q, b, head0), which, Mv, lane_e);
-        EA_W4A_READ_HALF1(acc)
+        EA_W4A_READ_HALF1(acc, accq)
         qkv_epilogue_qk(q, acc, img, biasb, head0 * 64 + 64, tok0, (int64_t)b * q.heads + head0 + 1, qkv_kv_base(q, b, head0 + 1), which, Mv,
                         lane_e);
     }

@@ -111,6 +111,117 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     }
 }
 
+// Round 6: the same arithmetic, another ORDER of memory accesses (what GroupNorm-apply taught in round 5: these streaming passes are
+// bound by how the resident waves are spread over the tensor, not by their arithmetic).  In layernorm_modulate_kernel a workgroup owns
+// 32 consecutive rows and a launch's ~1 500 resident workgroups touch the whole 0.65 GB tensor at ~6 000 separate points for the
+// kernel's whole life.  Here the workgroups SWEEP: trip k of workgroup g covers the four consecutive rows (k * G + g) * 4 .. + 3 (one
+// per wave), so the G resident workgroups read and write one window of G * 4 rows (24 MiB at G = 1024, d = 3072) that moves through
+// the tensor; the A / B table is built once per workgroup for all its trips; loads and stores are streaming (nontemporal: the 0.65 GB
+// in and out pass through a 4 MiB L2 nobody re-reads them from).  Same operations on the same values in the same order per row:
+// bit-identical to layernorm_modulate_kernel.
+template <int NV, int NT>
+__global__ __launch_bounds__(256) void layernorm_modulate_sweep_kernel(
+    const unsigned short* __restrict__ x, unsigned short* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift,
+    int64_t mod_stride, int rows, int dim, int64_t xbs, int64_t ybs, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float ln_ab[];   // A[dim] | B[dim]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int nvec = dim >> 3;
+    {
+        const float* sc = scale ? scale + b * mod_stride : nullptr;
+        const float* sh = shift ? shift + b * mod_stride : nullptr;
+        for (int c = threadIdx.x * 4; c < dim; c += 1024) {
+            f32x4 a = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+            if (gamma) {
+                a = *reinterpret_cast<const f32x4*>(gamma + c);
+                bb = *reinterpret_cast<const f32x4*>(beta + c);
+            }
+            if (sc) {
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(sc + c);
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(sh + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] *= 1.0f + s1[j];
+                    bb[j] = bb[j] * (1.0f + s1[j]) + h1[j];
+                }
+            }
+            *reinterpret_cast<f32x4*>(ln_ab + c) = a;
+            *reinterpret_cast<f32x4*>(ln_ab + dim + c) = bb;
+        }
+    }
+    __syncthreads();
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int64_t step = (int64_t)gridDim.x * 4;
+    const unsigned short* xb = x + b * xbs;
+    unsigned short* yb = y + b * ybs;
+    typedef unsigned ln_u32x4 __attribute__((ext_vector_type(4)));
+    auto ld = [&](const unsigned short* p) -> u16x8 {
+        if (NT & 1) return __builtin_bit_cast(u16x8, __builtin_nontemporal_load(reinterpret_cast<const ln_u32x4*>(p)));
+        return *reinterpret_cast<const u16x8*>(p);
+    };
+
+    u16x8 raw[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * 64 + lane;
+        if (vi < nvec) raw[i] = ld(xb + row * dim + vi * 8);
+    }
+    for (; row < rows; row += step) {
+        float v[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = i * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = vi < nvec ? bf16_bits_to_f32(raw[i][j]) : 0.f;
+                s += v[i][j];
+            }
+        }
+        if (row + step < rows) {   // the wave's next row in flight under this row's reductions
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int vi = i * 64 + lane;
+                if (vi < nvec) raw[i] = ld(xb + (row + step) * dim + vi * 8);
+            }
+        }
+        const float mean = wave_sum(s) / (float)dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = i * 64 + lane;
+            if (vi < nvec) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[i][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+        unsigned short* yr = yb + row * dim;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = i * 64 + lane;
+            if (vi < nvec) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ln_ab + vi * 8), a1 = *reinterpret_cast<const f32x4*>(ln_ab + vi * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln_ab + dim + vi * 8), b1 = *reinterpret_cast<const f32x4*>(ln_ab + dim + vi * 8 + 4);
+                u16x8 out;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    out[j] = f32_to_bf16_bits((v[i][j] - mean) * rstd * a0[j] + b0[j]);
+                    out[4 + j] = f32_to_bf16_bits((v[i][4 + j] - mean) * rstd * a1[j] + b1[j]);
+                }
+                if (NT & 2) __builtin_nontemporal_store(__builtin_bit_cast(ln_u32x4, out), reinterpret_cast<ln_u32x4*>(yr + vi * 8));
+                else *reinterpret_cast<u16x8*>(yr + vi * 8) = out;
+            }
+        }
+    }
+}
+
 // reference: easyanimate/models/norm.py:28-42 (EasyAnimateRMSNorm)
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __restrict__ x,
@@ -219,10 +330,29 @@ __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, float* __r
     out[(int64_t)b * dim + half + c] = sn;
 }
 
+int g_ln_wgs = 1024;   // ea_set_option("ln_wgs", n): workgroups per batch element of the sweeping LayerNorm kernel (0: the round-1 kernel, 32 rows per workgroup)
+int g_ln_nt = 3;       // ea_set_option("ln_nt", bits): 1 = streaming loads, 2 = streaming stores in the sweeping kernel
+
 template <int NV>
 int launch_ln(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* beta, const float* scale,
               const float* shift, int64_t mod_stride, int batch, int rows, int dim, int64_t xbs,
               int64_t ybs, float eps, hipStream_t st) {
+    if (g_ln_wgs > 0) {
+        const int chunks = (rows + 3) / 4;
+        dim3 grid(chunks < g_ln_wgs ? chunks : g_ln_wgs, batch);
+        const size_t lds = 2 * dim * sizeof(float);
+#define EA_LN_SWEEP(NT_)                                                                                                                \
+    hipLaunchKernelGGL((layernorm_modulate_sweep_kernel<NV, NT_>), grid, dim3(256), lds, st, x, y, gamma, beta, scale, shift, mod_stride, \
+                       rows, dim, xbs, ybs, eps)
+        switch (g_ln_nt & 3) {
+            case 0: EA_LN_SWEEP(0); break;
+            case 1: EA_LN_SWEEP(1); break;
+            case 2: EA_LN_SWEEP(2); break;
+            default: EA_LN_SWEEP(3); break;
+        }
+#undef EA_LN_SWEEP
+        return ea_check_launch("ea_layernorm_modulate_bf16");
+    }
     dim3 grid((rows + 4 * LN_ROWS - 1) / (4 * LN_ROWS), batch);
     hipLaunchKernelGGL(layernorm_modulate_kernel<NV>, grid, dim3(256), 2 * dim * sizeof(float), st, x, y, gamma, beta, scale, shift,
                        mod_stride, rows, dim, xbs, ybs, eps);
@@ -230,6 +360,11 @@ int launch_ln(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* bet
 }
 
 }  // namespace
+
+int ea_ln_wgs_set(int v) { if (v < 0 || v > 65535) return -1; g_ln_wgs = v; return 0; }
+int ea_ln_wgs_get() { return g_ln_wgs; }
+int ea_ln_nt_set(int v) { if (v < 0 || v > 3) return -1; g_ln_nt = v; return 0; }
+int ea_ln_nt_get() { return g_ln_nt; }
 
 extern "C" int ea_layernorm_modulate_bf16(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* beta,
                                           const float* scale, const float* shift, int64_t mod_stride,

@@ -67,6 +67,31 @@ def test_layernorm_modulate(B, R, D, affine, mod):
     assert rel < 4e-3 and err < 0.08  # one bf16 rounding of values up to ~16
 
 
+@pytest.mark.parametrize("B,R,D,wgs", [(2, 4099, 3072, 1024), (2, 4099, 3072, 7), (1, 3, 3072, 1024), (2, 513, 512, 16), (1, 260, 8192, 64)])
+def test_layernorm_sweep_bit_identical_to_block_kernel(B, R, D, wgs):
+    """Round 6: layernorm_modulate_sweep_kernel (workgroups sweep the tensor as one moving window, streaming loads / stores) does
+    the round-1 kernel's operations on the same values in the same order per row: bit-identical for every grid size, streaming
+    flag and ragged row count (rows % 4 != 0, fewer rows than waves, more trips than one)."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = _bf(torch.randn(B, R, D, generator=g) * 2 + 0.3).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    table = torch.randn(B, 6 * D, generator=g).to(DEV)
+    prev = _lib.get_option("ln_wgs"), _lib.get_option("ln_nt")
+    try:
+        _lib.set_option("ln_wgs", 0)
+        ref = ops.layernorm_modulate(x, gamma, beta, table[:, D:2 * D], table[:, 0:D], 1e-6).clone()
+        for nt in (0, 1, 2, 3):
+            _lib.set_option("ln_wgs", wgs)
+            _lib.set_option("ln_nt", nt)
+            y = ops.layernorm_modulate(x, gamma, beta, table[:, D:2 * D], table[:, 0:D], 1e-6)
+            assert torch.equal(y, ref), (nt, (y.float() - ref.float()).abs().max().item())
+    finally:
+        _lib.set_option("ln_wgs", prev[0])
+        _lib.set_option("ln_nt", prev[1])
+
+
 def test_rmsnorm():
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(2)

@@ -266,7 +266,8 @@ def emit():
         L.append(f"#define EA_CONV_W4A_AXOR_{g.name} 0x{g.A_XOR:x}")
         L.append("")
         print(g.name, len(b), "asm lines; PPW", g.PPW, "WP", g.WP, "vmcnt", g.vm)
-    clob = [f'"v{r}"' for r in range(132)] + [f'"a{r}"' for r in range(256)] + [f'"s{r}"' for r in range(80, 102)] + ['"m0"', '"scc"', '"memory"']
+    # (the accumulators a0..a255 are output operands: EA_W4A_ACC_OUTPUTS of ea_gemm_w4_loop.inc)
+    clob = [f'"v{r}"' for r in range(132)] + [f'"s{r}"' for r in range(80, 102)] + ['"m0"', '"scc"', '"memory"']
     L.append("#define EA_CONV_W4A_CLOBBERS \\")
     for k in range(0, len(clob), 16):
         L.append("    " + ", ".join(clob[k:k + 16]) + (", \\" if k + 16 < len(clob) else ""))

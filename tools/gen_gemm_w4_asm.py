@@ -268,7 +268,15 @@ def emit():
             A(f'    "{ins}\\n\\t" \\')
         L[-1] = L[-1][:-2]      # no continuation behind the last line
         A("")
-    clob = [f'"v{r}"' for r in range(132)] + [f'"a{r}"' for r in range(256)] + [f'"s{r}"' for r in range(80, 102)] + ['"m0"', '"scc"', '"memory"']
+    # The 256 accumulators are OUTPUT operands of the main asm (EA_W4A_ACC_OUTPUTS: f32x4_t accq[64] bound to a[4n:4n+3]) and INPUT
+    # operands of the read-out statements -- the register allocator knows they are live in between (as clobbers only,
+    # nothing but tests/test_w4a_isa_cpu.py stood between a compiler spill into an AGPR and silently wrong results)
+    clob = [f'"v{r}"' for r in range(132)] + [f'"s{r}"' for r in range(80, 102)] + ['"m0"', '"scc"', '"memory"']
+    A("#define EA_W4A_ACC_OUTPUTS(accq) \\")
+    outs = [f'"={{a[{4 * n}:{4 * n + 3}]}}"(accq[{n}])' for n in range(64)]
+    for k in range(0, 64, 4):
+        A("    " + ", ".join(outs[k:k + 4]) + (", \\" if k + 4 < 64 else ""))
+    A("")
     A("#define EA_W4A_CLOBBERS \\")
     for k in range(0, len(clob), 16):
         A("    " + ", ".join(clob[k:k + 16]) + (", \\" if k + 16 < len(clob) else ""))
@@ -281,13 +289,15 @@ def emit():
     A("")
     # ---- accumulator read-out: column half h (j = 4h .. 4h + 3) into f32x4_t dst[8][4]
     for h in range(2):
-        A(f"#define EA_W4A_READ_HALF{h}(dst) \\")
+        A(f"#define EA_W4A_READ_HALF{h}(dst, accq) \\")
         lines = []
         for jj in range(4):
             for i in range(8):
                 a = acc(i, 4 * h + jj)
                 for e in range(4):
-                    lines.append(f'    asm volatile("v_accvgpr_read_b32 %0, a{a + e}" : "=v"(dst[{i}][{jj}][{e}]));')
+                    assert a % 4 == 0
+                    if e == 0:
+                        lines.append(f'    dst[{i}][{jj}] = accq[{a // 4}];')
         for k, ln in enumerate(lines):
             A(ln + (" \\" if k + 1 < len(lines) else ""))
         A("")
