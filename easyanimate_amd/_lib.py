@@ -51,6 +51,11 @@ PROTOTYPES = {
     "ea_teacache_rel_l1_bf16": [_P, _P, _L, _P, _I, _P, _P],
     "ea_bf16_binary": [_P, _P, _P, _L, _I, _P],
     "ea_gated_residual_bf16": [_P, _P, _P, _P, _I, _L, _I, _L, _P],
+    "ea_rope_half_scatter_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P],
+    "ea_silu_mul_bf16": [_P, _P, _P, _L, _I, _L, _L, _P],
+    "ea_attention_causal_gqa_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "ea_tile_blend": [_P, _P, _I, _L, _I, _I, _L, _I, _L, _P],
+    "ea_tile_corner_blend": [_P, _P, _I, _L, _I, _I, _I, _I, _P],
     "ea_conv3d_cl_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ea_conv3d_cl_stats_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
     "ea_conv3d_cl_subpixel_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],

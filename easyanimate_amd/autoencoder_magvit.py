@@ -189,9 +189,11 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
                 f"AutoencoderKLMagvit (MI355X): cache_mag_vae={cache_mag_vae}, mini_batch_encoder={mini_batch_encoder}, "
                 f"mini_batch_decoder={mini_batch_decoder} -- only cache_mag_vae=True with an even mini_batch_encoder and "
                 "mini_batch_decoder=1 (the V5 / V5.1 configuration) is evaluated identically to the reference")
-        if use_tiling or use_tiling_encoder or use_tiling_decoder:
-            raise NotImplementedError("spatial tiling changes results (blended overlaps) and is never enabled by the "
-                                      "reference's entry points; not needed with 288 GB of HBM")
+        if upcast_vae:
+            # the reference's upcast_vae moves the encoder / decoder to fp32 inside encode / _decode (autoencoder_magvit.py:244-248,
+            # 272-275); this library computes in bf16 with fp32 accumulation and has no fp32 convolution path
+            raise NotImplementedError("AutoencoderKLMagvit (MI355X): upcast_vae=True asks for an fp32 VAE; the HIP library is bf16-only "
+                                      "(fp32 accumulation, fp32 GroupNorm statistics). Load the checkpoint with upcast_vae=False")
         common = dict(ch=ch, ch_mult=ch_mult, block_out_channels=block_out_channels, use_gc_blocks=use_gc_blocks,
                       mid_block_type=mid_block_type, mid_block_use_attention=mid_block_use_attention,
                       mid_block_attention_type=mid_block_attention_type,
@@ -210,8 +212,12 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         self.cache_compression_vae, self.cache_mag_vae = cache_compression_vae, cache_mag_vae
         self.cache_compression_vae_copy, self.cache_mag_vae_copy = cache_compression_vae, cache_mag_vae
         self.mini_batch_encoder, self.mini_batch_decoder = mini_batch_encoder, mini_batch_decoder
+        # use_slicing (one batch element at a time, autoencoder_magvit.py:256-258,299-301) is how this class always works
         self.use_slicing = False
-        self.use_tiling = self.use_tiling_encoder = self.use_tiling_decoder = False
+        # spatial tiling (autoencoder_magvit.py:249-254,276-279,339-448): host loops over the whole-tile kernels + ea_tile_blend.
+        # Never needed for memory here (288 GB) and it CHANGES results (blended overlaps) -- kept because a checkpoint's config.json
+        # may ask for it and the reference then returns the tiled result
+        self.use_tiling, self.use_tiling_encoder, self.use_tiling_decoder = use_tiling, use_tiling_encoder, use_tiling_decoder
         self.upcast_vae = upcast_vae
         self.tile_sample_min_size, self.tile_overlap_factor = tile_sample_min_size, tile_overlap_factor
         self.tile_latent_min_size = int(tile_sample_min_size / (2 ** (len(ch_mult) - 1)))
@@ -269,8 +275,8 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         ci = self.encoder.conv_in.in_channels
         return 8 if ci <= 8 else None
 
-    def encode(self, x: torch.Tensor, return_dict: bool = True) -> Union[AutoencoderKLOutput, Tuple[DiagonalGaussianDistribution]]:
-        self._check(x)
+    def _encode_moments(self, x: torch.Tensor) -> torch.Tensor:
+        """quant_conv(encoder(x)) of a whole clip (or one spatial tile of it): [B,3,F,H,W] -> moments [B,2C,F',H/8,W/8] in x's dtype."""
         if x.shape[2] != 1 and (x.shape[2] - 1) % self.mini_batch_encoder != 0:
             raise ValueError(f"encode: {x.shape[2]} frames -- the reference's chunked encoder only matches whole-clip evaluation for "
                              f"1 + k * mini_batch_encoder ({self.mini_batch_encoder}) frames (predict_t2v.py:288-291 trims the video to that)")
@@ -303,7 +309,45 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
                     m_loc = ops.ndhwc_to_ncdhw(conv_cl(self.quant_conv, h), self.quant_conv.out_channels, odt)
             like = torch.empty((self.quant_conv.out_channels, 1, xb.shape[2] // 8, xb.shape[3] // 8), dtype=odt, device=xb.device)
             moments.append(tp.gather_frames(m_loc, ranges, 1, like, row_dim=2))
-        posterior = DiagonalGaussianDistribution(torch.stack(moments).to(in_dtype))
+        return torch.stack(moments).to(in_dtype)
+
+    def _blend_and_stitch(self, rows, blend_extent: int, row_limit: int) -> torch.Tensor:
+        """The second half of tiled_encode / tiled_decode (autoencoder_magvit.py:362-375, 408-421): every tile is blended IN PLACE
+        with the (already blended) tile above it and the one left of it -- the reference's order, its in-place semantics -- then
+        cropped to row_limit and concatenated."""
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    ops.tile_blend_(rows[i - 1][j], tile, blend_extent, 3)
+                if j > 0:
+                    ops.tile_blend_(row[j - 1], tile, blend_extent, 4)
+                result_row.append(tile[:, :, :, :row_limit, :row_limit])
+            result_rows.append(torch.cat(result_row, dim=4))
+        return torch.cat(result_rows, dim=3)
+
+    def tiled_encode(self, x: torch.Tensor, return_dict: bool = True):
+        """reference: autoencoder_magvit.py:339-381.  Overlapping tile_sample_min_size^2 tiles, each encoded as a clip of its own
+        by the whole-tile kernels, seams blended over tile_latent_min_size * tile_overlap_factor latents."""
+        if self.temporal_parallel is not None:
+            raise NotImplementedError("spatial tiling together with the multi-GPU VAE split is not supported")
+        overlap_size = int(self.tile_sample_min_size * (1 - self.tile_overlap_factor))
+        blend_extent = int(self.tile_latent_min_size * self.tile_overlap_factor)
+        row_limit = self.tile_latent_min_size - blend_extent
+        t = self.tile_sample_min_size
+        rows = [[self._encode_moments(x[:, :, :, i:i + t, j:j + t].contiguous()).contiguous() for j in range(0, x.shape[4], overlap_size)]
+                for i in range(0, x.shape[3], overlap_size)]
+        posterior = DiagonalGaussianDistribution(self._blend_and_stitch(rows, blend_extent, row_limit))
+        if not return_dict:
+            return (posterior,)
+        return AutoencoderKLOutput(latent_dist=posterior)
+
+    def encode(self, x: torch.Tensor, return_dict: bool = True) -> Union[AutoencoderKLOutput, Tuple[DiagonalGaussianDistribution]]:
+        self._check(x)
+        if (self.use_tiling or self.use_tiling_encoder) and (x.shape[-1] > self.tile_sample_min_size or x.shape[-2] > self.tile_sample_min_size):
+            return self.tiled_encode(x, return_dict=return_dict)
+        posterior = DiagonalGaussianDistribution(self._encode_moments(x))
         if not return_dict:
             return (posterior,)
         return AutoencoderKLOutput(latent_dist=posterior)
@@ -347,13 +391,40 @@ class AutoencoderKLMagvit(nn.Module, ConfigMixin):
         like = torch.empty((self.out_channels, 1, z.shape[2] * s_, z.shape[3] * s_), dtype=out_dtype, device=z.device)
         return tp.gather_frames(y, out_ranges, 1, like, row_dim=2)
 
+    def _decode(self, z: torch.Tensor, postprocess: bool = False) -> torch.Tensor:
+        odt = z.dtype if z.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        return torch.stack([self._decode_one(z[b], odt, int(postprocess)) for b in range(z.shape[0])]).to(z.dtype)
+
+    def tiled_decode(self, z: torch.Tensor, return_dict: bool = True):
+        """reference: autoencoder_magvit.py:383-448.  Overlapping tile_latent_min_size^2 latent tiles decoded as clips of their own,
+        seams blended over tile_sample_min_size * tile_overlap_factor pixels, then the lower-right tile_latent_min_size^2 latents
+        decoded once more and mixed into the corner."""
+        if self.temporal_parallel is not None:
+            raise NotImplementedError("spatial tiling together with the multi-GPU VAE split is not supported")
+        overlap_size = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
+        blend_extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
+        row_limit = self.tile_sample_min_size - blend_extent
+        t = self.tile_latent_min_size
+        rows = [[self._decode(z[:, :, :, i:i + t, j:j + t].contiguous()).contiguous() for j in range(0, z.shape[4], overlap_size)]
+                for i in range(0, z.shape[3], overlap_size)]
+        dec = self._blend_and_stitch(rows, blend_extent, row_limit).contiguous()
+        corner = self._decode(z[:, :, :, -t:, -t:].contiguous()).contiguous()
+        ops.tile_corner_blend_(corner, dec)
+        if not return_dict:
+            return (dec,)
+        return DecoderOutput(sample=dec)
+
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None, postprocess: bool = False
                ) -> Union[DecoderOutput, Tuple[torch.Tensor]]:
         """postprocess=True additionally applies clamp(-1,1) -> /2+0.5 -> clamp(0,1) (pipeline decode_latents) in the
         final layout kernel."""
         self._check(z)
-        odt = z.dtype if z.dtype in (torch.float32, torch.bfloat16) else torch.float32
-        dec = torch.stack([self._decode_one(z[b], odt, int(postprocess)) for b in range(z.shape[0])]).to(z.dtype)
+        if (self.use_tiling or self.use_tiling_decoder) and (z.shape[-1] > self.tile_latent_min_size or z.shape[-2] > self.tile_latent_min_size):
+            dec = self.tiled_decode(z, return_dict=False)[0]
+            if postprocess:     # (the fused form lives in the layout kernel of the untiled path; tiles must be blended first)
+                dec = (dec.clamp(-1, 1) / 2 + 0.5).clamp(0, 1)
+        else:
+            dec = self._decode(z, postprocess)
         if not return_dict:
             return (dec,)
         return DecoderOutput(sample=dec)

@@ -67,7 +67,7 @@ extern "C" const char* ea_last_dispatch(void) { return g_last; }
 extern "C" void ea_reset_counters(void) {
     for (int i = 0; i < g_ncounters; ++i) g_counters[i].n = 0;
 }
-extern "C" int ea_version(void) { return 113; }   // 113: head groups (ea_qkv_gemm_norm_rope_grouped_bf16, ea_attention_fwd_{range,segments}_heads_bf16), options gemm_w4a / conv_w4a; 112: ea_attention_window_mapped_fwd_bf16, ea_permute_cols_bf16; 111: the default library requires the softmax scale folded into Q (ea_attention_fwd*); 110: K / V^T geometry + parts in the QKV entry points
+extern "C" int ea_version(void) { return 114; }   // 114: ea_tile_blend, ea_tile_corner_blend (VAE tiling), options ln_wgs / ln_nt; 113: head groups (ea_qkv_gemm_norm_rope_grouped_bf16, ea_attention_fwd_{range,segments}_heads_bf16), options gemm_w4a / conv_w4a; 112: ea_attention_window_mapped_fwd_bf16, ea_permute_cols_bf16; 111: the default library requires the softmax scale folded into Q (ea_attention_fwd*); 110: K / V^T geometry + parts in the QKV entry points
 
 // Tuning / benchmarking switches.  Each kernel file owns its switch; results never depend on them.
 #define EA_OPTION(n) int ea_##n##_set(int v); int ea_##n##_get();

@@ -152,6 +152,39 @@ __global__ void cfg_rescale_euler_kernel(const void* __restrict__ v, void* __res
         reinterpret_cast<float*>(x)[i] = xn;
 }
 
+// ---- spatial tiling of the VAE wrapper (reference: autoencoder_magvit.py:319-337 blend_v / blend_h, :426-445 the lower-right corner)
+// b[o, y, i] = a[o, a_n - extent + y, i] * (1 - y / extent) + b[o, y, i] * (y / extent)        y < extent, i < inner
+// (blend_v: o = (b c t), y = row, i = column; blend_h: o = (b c t h), y = column, inner = 1).  fp32 arithmetic, one rounding.
+template <bool BF16>
+__global__ void tile_blend_kernel(const void* __restrict__ a, void* __restrict__ b, int64_t outer, int extent, int inner,
+                                  int64_t a_os, int a_n, int64_t b_os) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= outer * extent * inner) return;
+    const int i = (int)(idx % inner);
+    const int y = (int)((idx / inner) % extent);
+    const int64_t o = idx / ((int64_t)inner * extent);
+    const int64_t ia = o * a_os + (int64_t)(a_n - extent + y) * inner + i, ib = o * b_os + (int64_t)y * inner + i;
+    const float w = (float)y / (float)extent;
+    const float r = load_lat<BF16>(a, ia) * (1.0f - w) + load_lat<BF16>(b, ib) * w;
+    if (BF16) reinterpret_cast<unsigned short*>(b)[ib] = f32_to_bf16_bits(r);
+    else reinterpret_cast<float*>(b)[ib] = r;
+}
+
+// dec[o, H - h + y, W - w + x] = wgt * q[o, y, x] + (1 - wgt) * dec[...],  wgt = min(x / (w - 1), y / (h - 1))   (linspace(0, 1, n))
+template <bool BF16>
+__global__ void tile_corner_kernel(const void* __restrict__ q, void* __restrict__ dec, int64_t outer, int h, int w, int H, int W) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= outer * h * w) return;
+    const int x = (int)(idx % w), y = (int)((idx / w) % h);
+    const int64_t o = idx / ((int64_t)w * h);
+    const int64_t id = (o * H + (H - h + y)) * W + (W - w + x);
+    const float wx = w > 1 ? (float)x / (float)(w - 1) : 0.f, wy = h > 1 ? (float)y / (float)(h - 1) : 0.f;
+    const float wg = fminf(wx, wy);
+    const float r = wg * load_lat<BF16>(q, idx) + (1.0f - wg) * load_lat<BF16>(dec, id);
+    if (BF16) reinterpret_cast<unsigned short*>(dec)[id] = f32_to_bf16_bits(r);
+    else reinterpret_cast<float*>(dec)[id] = r;
+}
+
 }  // namespace
 
 extern "C" int ea_patchify(const void* latents, const void* extra, ea_bf16* cols, int batch, int c_lat, int c_extra,
@@ -454,4 +487,28 @@ extern "C" int ea_bf16_binary(const ea_bf16* a, const ea_bf16* b, ea_bf16* out, 
     else
         hipLaunchKernelGGL(bf16_binary_kernel<1>, dim3(blocks), dim3(256), 0, st, a, b, out, n8);
     return ea_check_launch("ea_bf16_binary");
+}
+
+extern "C" int ea_tile_blend(const void* a, void* b, int bf16, int64_t outer, int extent, int inner, int64_t a_outer_stride, int a_n,
+                             int64_t b_outer_stride, void* stream) {
+    EA_REQUIRE(a && b, "ea_tile_blend: null tensor");
+    EA_REQUIRE(outer >= 0 && extent >= 0 && inner > 0 && a_n >= extent, "ea_tile_blend: bad geometry (outer %lld, extent %d, inner %d, a_n %d)",
+               (long long)outer, extent, inner, a_n);
+    const int64_t n = outer * extent * inner;
+    if (n == 0) return EA_OK;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(tile_blend_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, b, outer, extent, inner, a_outer_stride, a_n, b_outer_stride);
+    else hipLaunchKernelGGL(tile_blend_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, b, outer, extent, inner, a_outer_stride, a_n, b_outer_stride);
+    return ea_check_launch("ea_tile_blend");
+}
+
+extern "C" int ea_tile_corner_blend(const void* q, void* dec, int bf16, int64_t outer, int h, int w, int H, int W, void* stream) {
+    EA_REQUIRE(q && dec, "ea_tile_corner_blend: null tensor");
+    EA_REQUIRE(outer >= 0 && h > 0 && w > 0 && h <= H && w <= W, "ea_tile_corner_blend: bad geometry (%d x %d inside %d x %d)", h, w, H, W);
+    const int64_t n = outer * h * w;
+    if (n == 0) return EA_OK;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(tile_corner_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, dec, outer, h, w, H, W);
+    else hipLaunchKernelGGL(tile_corner_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, dec, outer, h, w, H, W);
+    return ea_check_launch("ea_tile_corner_blend");
 }

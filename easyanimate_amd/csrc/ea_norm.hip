@@ -330,8 +330,8 @@ __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, float* __r
     out[(int64_t)b * dim + half + c] = sn;
 }
 
-int g_ln_wgs = 1024;   // ea_set_option("ln_wgs", n): workgroups per batch element of the sweeping LayerNorm kernel (0: the round-1 kernel, 32 rows per workgroup)
-int g_ln_nt = 3;       // ea_set_option("ln_nt", bits): 1 = streaming loads, 2 = streaming stores in the sweeping kernel
+int g_ln_wgs = 768;    // ea_set_option("ln_wgs", n): workgroups per batch element of the sweeping LayerNorm kernel (0: the round-1 kernel, 32 rows per workgroup)
+int g_ln_nt = 2;       // ea_set_option("ln_nt", bits): 1 = streaming loads, 2 = streaming stores in the sweeping kernel
 
 template <int NV>
 int launch_ln(const ea_bf16* x, ea_bf16* y, const float* gamma, const float* beta, const float* scale,

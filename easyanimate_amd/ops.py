@@ -517,6 +517,79 @@ def gated_residual(x: torch.Tensor, res: torch.Tensor, gate: torch.Tensor) -> to
     return out
 
 
+def rope_half_scatter(src: torch.Tensor, heads: int, head_dim: int, batch: int, seq: int, cos: Optional[torch.Tensor] = None,
+                      sin: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src bf16 [batch*seq, >= heads*head_dim] (a column block of a projection output; row stride free) -> bf16 [batch, heads, seq,
+    head_dim] with the rotate-half rotary embedding applied (cos / sin fp32 [batch*seq, head_dim]; None: scatter only)."""
+    _dev(src, cos, sin)
+    _chk(src, _BF16, "src")
+    assert src.dim() == 2 and src.shape[0] == batch * seq and src.stride(1) == 1 and src.shape[1] >= heads * head_dim
+    if cos is not None:
+        _chk(cos, _F32, "cos"); _chk(sin, _F32, "sin")
+        assert cos.shape == (batch * seq, head_dim) and sin.shape == cos.shape and cos.is_contiguous() and sin.is_contiguous()
+    dst = torch.empty((batch, heads, seq, head_dim), dtype=_BF16, device=src.device)
+    _lib.call("ea_rope_half_scatter_bf16", _p(src), _p(dst), _p(cos), _p(sin), batch, seq, heads, head_dim, src.stride(0), _stream())
+    return dst
+
+
+def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """SiLU(gate) * up; gate / up bf16 [rows, cols] (row strides free: two column blocks of one projection output)."""
+    _dev(gate, up)
+    _chk(gate, _BF16, "gate"); _chk(up, _BF16, "up")
+    assert gate.dim() == 2 and gate.shape == up.shape and gate.stride(1) == 1 and up.stride(1) == 1
+    out = torch.empty(tuple(gate.shape), dtype=_BF16, device=gate.device)
+    _lib.call("ea_silu_mul_bf16", _p(gate), _p(up), _p(out), gate.shape[0], gate.shape[1], gate.stride(0), up.stride(0), _stream())
+    return out
+
+
+def attention_causal_gqa(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, seq: int, scale: float, valid: Optional[torch.Tensor] = None,
+                         causal: bool = True) -> torch.Tensor:
+    """q bf16 [B, Hq, S, D], k bf16 [B, Hkv, S, D], vt bf16 [B, Hkv, D, S_pad] (S_pad % 32 == 0, columns >= S finite), valid int32 [B]
+    (real tokens of each right-padded prompt) -> bf16 [B, S, Hq * D].  Prompt-sized sequences (ea_attention_causal_gqa_bf16)."""
+    _dev(q, k, vt, valid)
+    _chk(q, _BF16, "q"); _chk(k, _BF16, "k"); _chk(vt, _BF16, "vt")
+    B, Hq, S, D = q.shape
+    Hkv = k.shape[1]
+    assert S == seq and k.shape == (B, Hkv, S, D) and vt.shape[:3] == (B, Hkv, D) and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    if valid is not None:
+        assert valid.dtype == torch.int32 and valid.shape == (B,) and valid.is_contiguous()
+    out = torch.empty((B, S, Hq * D), dtype=_BF16, device=q.device)
+    _lib.call("ea_attention_causal_gqa_bf16", _p(q), _p(k), _p(vt), _p(out), _p(valid), B, Hq, Hkv, S, vt.shape[3], D, int(causal), float(scale),
+              _stream())
+    return out
+
+
+def tile_blend_(a: torch.Tensor, b: torch.Tensor, extent: int, axis: int) -> torch.Tensor:
+    """In place on b: the seam blend of two neighbouring VAE tiles [B,C,T,H,W] (contiguous, same dtype bf16 / fp32), axis 3 =
+    blend_v (a above b), axis 4 = blend_h (a left of b); autoencoder_magvit.py:319-337."""
+    _dev(a, b)
+    assert a.dim() == 5 and b.dim() == 5 and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.dtype in (_BF16, _F32)
+    assert a.shape[:3] == b.shape[:3] and axis in (3, 4)
+    if axis == 3:
+        assert a.shape[4] == b.shape[4]
+        extent = min(a.shape[3], b.shape[3], extent)
+        outer, inner, a_n = a.shape[0] * a.shape[1] * a.shape[2], a.shape[4], a.shape[3]
+        a_os, b_os = a.shape[3] * a.shape[4], b.shape[3] * b.shape[4]
+    else:
+        assert a.shape[3] == b.shape[3]
+        extent = min(a.shape[4], b.shape[4], extent)
+        outer, inner, a_n = a.shape[0] * a.shape[1] * a.shape[2] * a.shape[3], 1, a.shape[4]
+        a_os, b_os = a.shape[4], b.shape[4]
+    _lib.call("ea_tile_blend", _p(a), _p(b), int(a.dtype == _BF16), outer, extent, inner, a_os, a_n, b_os, _stream())
+    return b
+
+
+def tile_corner_blend_(q: torch.Tensor, dec: torch.Tensor) -> torch.Tensor:
+    """In place on dec [B,C,T,H,W]: mix the separately decoded lower-right tile q [B,C,T,h,w] into its last h x w pixels with the
+    weights min(linspace_x, linspace_y) (autoencoder_magvit.py:426-445)."""
+    _dev(q, dec)
+    assert q.dim() == 5 and dec.dim() == 5 and q.is_contiguous() and dec.is_contiguous() and q.dtype == dec.dtype and q.dtype in (_BF16, _F32)
+    assert q.shape[:3] == dec.shape[:3] and q.shape[3] <= dec.shape[3] and q.shape[4] <= dec.shape[4]
+    _lib.call("ea_tile_corner_blend", _p(q), _p(dec), int(q.dtype == _BF16), q.shape[0] * q.shape[1] * q.shape[2], q.shape[3], q.shape[4],
+              dec.shape[3], dec.shape[4], _stream())
+    return dec
+
+
 def patchify(latents: torch.Tensor, extra: Optional[torch.Tensor], k_pad: int) -> torch.Tensor:
     """latents [B,C,F,H,W] (+ extra [B,C2,F,H,W]) -> bf16 [B, F*(H/2)*(W/2), k_pad]."""
     _dev(latents, extra)

@@ -161,8 +161,12 @@ class EasyAnimatePipeline:
         return None
 
     def enable_vae_tiling(self):
-        raise NotImplementedError("tiled VAE (autoencoder_magvit.py:339-448) blends overlapping tiles and is not exact; the "
-                                  "whole-clip kernels fit 49 x 1024^2 in 83 GB")
+        """The reference's tiled VAE (autoencoder_magvit.py:339-448) blends overlapping tiles, so the result differs from the
+        whole-clip one; never needed for memory here (49 x 1024^2 fits in 83 GB), available for checkpoints / callers that ask."""
+        self.vae.use_tiling = True
+
+    def disable_vae_tiling(self):
+        self.vae.use_tiling = self.vae.use_tiling_encoder = self.vae.use_tiling_decoder = False
 
     # -- helpers --------------------------------------------------------------------------------
     def latent_shape(self, batch_size, num_channels_latents, video_length, height, width):

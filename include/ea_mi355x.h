@@ -353,6 +353,45 @@ int ea_teacache_rel_l1_bf16(const ea_bf16* cur, const ea_bf16* prev, int64_t n, 
  * `hidden_states += previous_residual` (:1590).  out may alias a or b.  n % 8 == 0. */
 int ea_bf16_binary(const ea_bf16* a, const ea_bf16* b, ea_bf16* out, int64_t n, int op, void* stream);
 
+/* ---- the text-encoder step (pipeline_easyanimate.py:438-447: Qwen2-VL-7B's penultimate hidden state of 256 padded prompt tokens,
+ * once per call; the encoder is a `transformers` dependency, its decoder layer restated from transformers' Qwen2-VL / Qwen2 model:
+ * RMSNorm -> q/k/v Linear (bias) -> rotate-half rotary embedding -> causal grouped-query attention -> o Linear -> residual ->
+ * RMSNorm -> down(SiLU(gate(x)) * up(x)) -> residual).  Linear layers: ea_gemm_bf16 (the residual adds ride in its gate + residual
+ * epilogue with a gate of ones); norms: ea_rmsnorm_bf16. */
+
+/* Rotary embedding in the rotate-half form (transformers apply_rotary_pos_emb: x * cos + rotate_half(x) * sin, rotate_half(x) =
+ * [-x2 | x1]) fused with the head-major scatter: src [batch*seq, src_ld] holds heads x head_dim columns of a projection output,
+ * dst [batch, heads, seq, head_dim]; cos / sin fp32 [batch*seq, head_dim] (both null: scatter only).  fp32 arithmetic, one rounding. */
+int ea_rope_half_scatter_bf16(const ea_bf16* src, ea_bf16* dst, const float* cos, const float* sin, int batch, int seq, int heads,
+                              int head_dim, int64_t src_ld, void* stream);
+
+/* out[r, c] = SiLU(gate[r, c]) * up[r, c]  (Qwen2MLP act_fn(gate_proj(x)) * up_proj(x)); gate / up rows gate_ld / up_ld apart (two
+ * column blocks of one projection output), out [rows, cols] contiguous; cols % 8 == 0. */
+int ea_silu_mul_bf16(const ea_bf16* gate, const ea_bf16* up, ea_bf16* out, int64_t rows, int cols, int64_t gate_ld, int64_t up_ld,
+                     void* stream);
+
+/* softmax(q k^T * scale + mask) v for SHORT sequences with grouped-query heads (transformers sdpa_attention_forward with the mask of
+ * create_causal_mask): q [batch, q_heads, seq, D], k [batch, kv_heads, seq, D], vt = v^T [batch, kv_heads, D, s_pad] (s_pad % 32 == 0,
+ * columns >= seq finite), out [batch, seq, q_heads * D]; head h reads kv head h / (q_heads / kv_heads).  Masked: key > query when
+ * causal != 0; key >= valid[b] when valid != NULL (int32 per batch element: the count of real tokens of a right-padded prompt).
+ * D = 64 or 128.  One wave per 16 queries, operands straight from global memory: for prompt-sized sequences only. */
+int ea_attention_causal_gqa_bf16(const ea_bf16* q, const ea_bf16* k, const ea_bf16* vt, ea_bf16* out, const int* valid, int batch,
+                                 int q_heads, int kv_heads, int seq, int s_pad, int head_dim, int causal, float scale, void* stream);
+
+/* Spatial tiling of the VAE wrapper (use_tiling / use_tiling_encoder / use_tiling_decoder, autoencoder_magvit.py:249-254,276-279):
+ * the seam blends of tiled_encode / tiled_decode, blend_v (:319-327) and blend_h (:329-337), in place on tile b:
+ *     b[o, y, i] = a[o, a_n - extent + y, i] * (1 - y / extent) + b[o, y, i] * (y / extent)      y < extent, i < inner, o < outer
+ * blend_v on [B,C,T,H,W] tiles: outer = B*C*T, a_n = H_a, inner = W, outer strides = H*W of each tile; blend_h: outer = B*C*T*H,
+ * a_n = W_a, inner = 1, outer strides = W of each tile.  bf16 != 0: bf16 elements, else fp32; fp32 arithmetic, one rounding (the
+ * reference rounds each product and the sum to the tensor dtype). */
+int ea_tile_blend(const void* a, void* b, int bf16, int64_t outer, int extent, int inner, int64_t a_outer_stride, int a_n,
+                  int64_t b_outer_stride, void* stream);
+
+/* tiled_decode's lower-right corner (autoencoder_magvit.py:426-445): the last tile_latent_min_size^2 latents are decoded once more
+ * (q [outer, h, w]) and mixed into the last h x w pixels of dec [outer, H, W], in place:
+ *     dec = wgt * q + (1 - wgt) * dec,   wgt[y][x] = min(linspace(0,1,w)[x], linspace(0,1,h)[y]). */
+int ea_tile_corner_blend(const void* q, void* dec, int bf16, int64_t outer, int h, int w, int H, int W, void* stream);
+
 /* out[b,r,:] = res[b,r,:] + gate[b,:] * x[b,r,:]  (bf16 in/out, fp32 fma, one rounding): the gated residual of
  * attention.py:1161-1162 as a stand-alone pass, used only by after_norm=True blocks (norm3 sits between the FFN GEMM and
  * the residual, :1150-1155, so the add cannot ride in the GEMM epilogue).  x/res/out: [batch, rows, dim] contiguous,

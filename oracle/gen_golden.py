@@ -904,6 +904,39 @@ def gen_swa_long(ns, shim):
                     floor_mse=_mse(outb.float(), out)), os.path.join(OUT, "transformer_swa_long.pt"))
 
 
+def vae_tiled_inputs(seed=19, frames=5, height=512, width=448):
+    """Inputs of the tiled-VAE fixture: a 5 x 512 x 448 clip (two tile rows, two tile columns of different widths: 384 + 224 rows,
+    384 + 160 columns) and a [1,16,2,64,56] latent."""
+    g = _g(seed)
+    video = (torch.rand(1, 3, frames, height, width, generator=g) * 2 - 1).bfloat16().float()
+    z = torch.randn(1, 16, (frames - 1) // 4 + 1, height // 8, width // 8, generator=g).bfloat16().float()
+    return video, z
+
+
+@section("vae_tiled")
+def gen_vae_tiled(ns, shim):
+    # ---- VERDICT r5 next #8: the reference's spatial tiling (autoencoder_magvit.py:249-254,276-279,319-448) with its default tile
+    # geometry (tile_sample_min_size 384, overlap 0.25): use_tiling=True, full-width VAE, fp32 on the host; encode moments and
+    # decode output of the UNCHANGED reference, plus the untiled results' distance (tiling changes the result: that it does, and by
+    # how much, is part of the fixture).
+    import time
+    vae, shapes = _meta_build(lambda: ns.autoencoder_magvit.AutoencoderKLMagvit(**dict(FULL_VAE, use_tiling=True)), 2, "default_bf16")
+    video, z = vae_tiled_inputs()
+    t0 = time.time()
+    mom = vae.encode(video)[0].parameters
+    t1 = time.time()
+    dec = vae.decode(z)[0]
+    print(f"  vae_tiled: tiled encode {t1 - t0:.0f} s, tiled decode {time.time() - t1:.0f} s", flush=True)
+    vae.use_tiling = False
+    mom_u = vae.encode(video)[0].parameters
+    dec_u = vae.decode(z)[0]
+    print(f"  vae_tiled: tiled-vs-untiled MSE: moments {_mse(mom, mom_u):.3e}, decode {_mse(dec, dec_u):.3e}", flush=True)
+    torch.save(dict(cfg=dict(FULL_VAE, use_tiling=True), seed=2, style="default_bf16", input_seed=19, frames=5, height=512, width=448,
+                    video_sum=video.double().sum().item(), z_sum=z.double().sum().item(), moments=mom.half(), dec=dec.half(),
+                    untiled_mse=(_mse(mom, mom_u), _mse(dec, dec_u)), moments_fp16_mse=_mse(mom.half().float(), mom),
+                    dec_fp16_mse=_mse(dec.half().float(), dec)), os.path.join(OUT, "vae_tiled_5x512x448.pt"))
+
+
 DIT_12B = dict(FULL_DIT, num_layers=48)                       # BASELINE configs[2]: 12B (v5 MMDiT), SURVEY Appendix B
 DIT_12B_INP = dict(FULL_DIT, num_layers=48, in_channels=33)   # BASELINE configs[4]: 12B InP (image-latent concat)
 DEPTH_TAPS = (1, 12, 24, 48)          # residual streams kept after these many blocks

@@ -286,3 +286,31 @@ def test_restatement_vae_ragged_shape_vs_golden_chunked_reference():
         d = RV.vae_decode(sd, z, 32)
     _close(m, g["moments"], 2e-5, "ragged full-width vae moments")
     _close(d, g["dec_f16"].float(), 1.5e-3, "ragged full-width vae decode (fixture stored fp16)")
+
+
+@pytest.mark.parametrize("hidden,heads,kv,inter,layers,lens", [(256, 4, 2, 512, 3, (48, 19)), (512, 4, 2, 768, 2, (5, 40)), (256, 2, 2, 512, 2, (48, 48))])
+def test_text_restatement_equals_transformers(hidden, heads, kv, inter, layers, lens):
+    """oracle/restatement_text.py (the text-only forward of the Qwen2-VL decoder: RMSNorm, biased q / k / v, rotate-half RoPE at the
+    positions transformers uses, causal + key-padding grouped-query attention, SwiGLU) against the INSTALLED transformers
+    implementation of the class the reference loads (Qwen2VLForConditionalGeneration, random init), fp32, every hidden state,
+    padded rows included -- the third-party arithmetic of pipeline_easyanimate.py:438-447 pinned where it can be."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_text_encoder_gpu import _prompt_batch, _qwen
+    from easyanimate_amd.text_encoder import _find_text_model
+    from oracle import restatement_text as RT
+    m = _qwen(hidden, heads, kv, inter, layers)
+    text = _find_text_model(m)
+    ids, mask = _prompt_batch(2, 48, 512, lens)
+    cfg = dict(hidden_size=hidden, num_attention_heads=heads, num_key_value_heads=kv, rms_norm_eps=text.config.rms_norm_eps, rope_theta=1e6,
+               num_hidden_layers=layers)
+    with torch.no_grad():
+        ref = m(input_ids=ids, attention_mask=mask, output_hidden_states=True).hidden_states
+        got = RT.text_hidden_states(text.state_dict(), cfg, ids, mask)
+        old = RT.text_hidden_states(text.state_dict(), cfg, ids, mask, padded_positions="cumsum_fill1")
+    assert len(got) == len(ref) == layers + 1
+    for a, b in zip(got, ref):
+        assert ((a - b).norm() / b.norm()).item() < 2e-6
+    # the other position convention (transformers 4.46 - 4.5x) moves the PADDED rows only
+    for a, b, n in ((old[-2][i], ref[-2][i], lens[i]) for i in range(2)):
+        assert ((a[:n] - b[:n]).norm() / b[:n].norm()).item() < 2e-6

@@ -860,3 +860,86 @@ def test_conv_w4a_bit_identical_to_the_eight_wave_kernels(T, H, W, Ci, Co, res, 
                              f"frames {bad[:, 0].unique().tolist()} rows {bad[:, 1].unique().tolist()[:8]} voxels {bad[:, 2].unique().tolist()[:16]} channels {bad[:, 3].unique().tolist()[:16]}")
     assert torch.equal(p1, p0)
     assert torch.equal(y2, y1) and torch.equal(p2, p1)       # repeated launches agree (race screen)
+
+
+# ---- round 6: the wrapper's spatial tiling (autoencoder_magvit.py:249-254,276-279,319-448) --------------------------------------------
+def _ref_blend_v(a, b, e):     # autoencoder_magvit.py:319-327, verbatim arithmetic on fp64 copies
+    e = min(a.shape[3], b.shape[3], e)
+    for y in range(e):
+        b[:, :, :, y, :] = a[:, :, :, -e + y, :] * (1 - y / e) + b[:, :, :, y, :] * (y / e)
+    return b
+
+
+def _ref_blend_h(a, b, e):     # :329-337
+    e = min(a.shape[4], b.shape[4], e)
+    for x in range(e):
+        b[:, :, :, :, x] = a[:, :, :, :, -e + x] * (1 - x / e) + b[:, :, :, :, x] * (x / e)
+    return b
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ha,hb,wa,wb,extent", [(48, 48, 48, 48, 12), (48, 28, 48, 20, 12), (7, 5, 9, 3, 12), (384, 224, 384, 160, 96)])
+def test_tile_blend_kernels(dtype, ha, hb, wa, wb, extent):
+    """ea_tile_blend / ea_tile_corner_blend against the reference's blend_v / blend_h / corner arithmetic in fp64 (tiles of different
+    sizes, an extent larger than a tile)."""
+    from easyanimate_amd import ops
+    g = torch.Generator().manual_seed(ha * 7 + wb)
+    B, C, T = 1, 3, 2
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    a, b = torch.randn(B, C, T, ha, wa, generator=g).to(dtype), torch.randn(B, C, T, hb, wa, generator=g).to(dtype)
+    got = ops.tile_blend_(a.to(DEV), b.clone().to(DEV), extent, 3)
+    ref = _ref_blend_v(a.double(), b.double().clone(), extent)
+    assert (got.double().cpu() - ref).abs().max().item() < tol
+    a, b = torch.randn(B, C, T, ha, wa, generator=g).to(dtype), torch.randn(B, C, T, ha, wb, generator=g).to(dtype)
+    got = ops.tile_blend_(a.to(DEV), b.clone().to(DEV), extent, 4)
+    ref = _ref_blend_h(a.double(), b.double().clone(), extent)
+    assert (got.double().cpu() - ref).abs().max().item() < tol
+    # the corner: weights = min(linspace_x, linspace_y) (:432-445)
+    dec, q = torch.randn(B, C, T, ha + 5, wa + 3, generator=g).to(dtype), torch.randn(B, C, T, hb, wb, generator=g).to(dtype)
+    got = ops.tile_corner_blend_(q.to(DEV), dec.clone().to(DEV))
+    wts = torch.min(torch.linspace(0, 1, wb, dtype=torch.float64).unsqueeze(0).repeat(hb, 1),
+                    torch.linspace(0, 1, hb, dtype=torch.float64).unsqueeze(1).repeat(1, wb))
+    ref = dec.double().clone()
+    ref[:, :, :, -hb:, -wb:] = wts * q.double() + (1 - wts) * ref[:, :, :, -hb:, -wb:]
+    assert (got.double().cpu() - ref).abs().max().item() < tol
+
+
+def test_vae_tiling_vs_reference_golden():
+    """use_tiling=True through the product wrapper -- tiled_encode / tiled_decode as host loops over the whole-tile kernels, seams by
+    ea_tile_blend, the corner by ea_tile_corner_blend -- against the UNCHANGED reference run with use_tiling=True (full width,
+    5 x 512 x 448, tile 384 / overlap 0.25: 2 x 2 tiles of unequal sizes; oracle/gen_golden.py section vae_tiled).  Also: the tiled
+    result really is the tiled one (it differs from the untiled result about as much as the reference's does), the per-component
+    switches, and upcast_vae's refusal."""
+    from easyanimate_amd import AutoencoderKLMagvit
+    from easyanimate_amd.synthetic import synth_state_dict
+    from oracle.gen_golden import vae_tiled_inputs
+    g = torch.load(os.path.join(GOLD, "vae_tiled_5x512x448.pt"), weights_only=False)
+    video, z = vae_tiled_inputs(g["input_seed"], g["frames"], g["height"], g["width"])
+    assert abs(video.double().sum().item() - g["video_sum"]) < 1e-6 and abs(z.double().sum().item() - g["z_sum"]) < 1e-6
+    with torch.device("meta"):
+        vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    assert vae.use_tiling and vae.tile_latent_min_size == 48
+    shapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    vae = vae.to_empty(device="cpu")
+    vae.load_state_dict(synth_state_dict(shapes, g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    with torch.no_grad():
+        mom = vae.encode(video.to(DEV).bfloat16())[0].parameters.float().cpu()
+        dec = vae.decode(z.to(DEV).bfloat16())[0].float().cpu()
+        vae.use_tiling = False
+        mom_u = vae.encode(video.to(DEV).bfloat16())[0].parameters.float().cpu()
+        dec_u = vae.decode(z.to(DEV).bfloat16())[0].float().cpu()
+        vae.use_tiling_decoder = True                      # the per-component switches (:252-254, 278-279)
+        dec_d = vae.decode(z.to(DEV).bfloat16())[0].float().cpu()
+        mom_d = vae.encode(video.to(DEV).bfloat16())[0].parameters.float().cpu()
+    assert mom.shape == g["moments"].shape == (1, 32, 2, 64, 56) and dec.shape == g["dec"].shape == (1, 3, 5, 512, 448)
+    mse = lambda a_, b_: ((a_.double() - b_.double()) ** 2).mean().item()
+    m_e, m_d = mse(mom, g["moments"].float()), mse(dec, g["dec"].float())
+    u_e, u_d = mse(mom, mom_u), mse(dec, dec_u)
+    print(f"[parity] tiled VAE (5 x 512 x 448, tile 384 / 0.25) vs the reference's tiled fp32 run: moments MSE {m_e:.3e}, decode MSE {m_d:.3e} "
+          f"(bar 1e-4); tiled-vs-untiled here {u_e:.3e} / {u_d:.3e}, in the reference {g['untiled_mse'][0]:.3e} / {g['untiled_mse'][1]:.3e}")
+    assert m_e < 1e-4 and m_d < 1e-4
+    assert 0.3 * g["untiled_mse"][0] < u_e < 3 * g["untiled_mse"][0] + 1e-4 and 0.3 * g["untiled_mse"][1] < u_d < 3 * g["untiled_mse"][1] + 1e-4
+    assert torch.equal(dec_d, dec) and torch.equal(mom_d, mom_u)
+    with pytest.raises(NotImplementedError, match="upcast_vae"):
+        AutoencoderKLMagvit.from_config(dict(g["cfg"], upcast_vae=True))

@@ -19,7 +19,7 @@ for what, B, R in (("video stream c3", 2, 53248), ("one rank of 8 (cfg2 x sp4)",
     _lib.set_option("ln_wgs", 0)
     fn(); torch.cuda.synchronize()
     ref = y.clone()
-    variants = [(0, 3)] + [(w, nt) for w in (256, 512, 768, 1024, 1536, 2048, 4096) for nt in (3,)] + [(1024, 0), (1024, 1), (1024, 2)]
+    variants = [(0, 3)] + [(w, nt) for w in (512, 640, 704, 768, 832, 896, 1024, 1536) for nt in (2, 3)] + [(768, 0), (768, 1)]
     for rep in range(reps):
         for wgs, nt in variants:
             _lib.set_option("ln_wgs", wgs)
@@ -28,4 +28,4 @@ for what, B, R in (("video stream c3", 2, 53248), ("one rank of 8 (cfg2 x sp4)",
             same = bool(torch.equal(y, ref))
             print(json.dumps({"what": what, "ln_wgs": wgs, "ln_nt": nt, "us": round(ms * 1e3, 1), "GB_s": round(4.0 * B * R * D / ms / 1e6, 1),
                               "bit_identical": same}), flush=True)
-    _lib.set_option("ln_wgs", 1024); _lib.set_option("ln_nt", 3)
+    _lib.set_option("ln_wgs", 768); _lib.set_option("ln_nt", 2)
