@@ -79,6 +79,8 @@ EA_OPTION(conv_tile)      // ea_conv.hip:      0 (auto) | 128 | 256 | 512 | 1024
 EA_OPTION(conv_m512)      // ea_conv.hip:      0 | 1
 EA_OPTION(conv_w4a)       // ea_conv.hip:      bits 1 (512 x 128 tiles) | 2 (256 x 256 tiles): four-wave row-slab kernels, hand-placed main loop
 EA_OPTION(attn_variant)   // ea_attention.hip: 3 (EA_BUILD_VARIANTS=1 libraries: also 1 | 2)
+EA_OPTION(attn_stages)    // ea_attention.hip: 2 | 3 LDS stages per operand of the v3 kernel (3: K / V^T tiles requested one tile earlier)
+EA_OPTION(attn_nw)        // ea_attention.hip: 4 | 8 waves per workgroup of the v3 kernel (8: one 512-query workgroup per CU, one K / V^T stream)
 EA_OPTION(ln_wgs)         // ea_norm.hip:      workgroups per batch element of the sweeping LayerNorm-modulate kernel (default 1024; 0 = the 32-rows-per-workgroup kernel)
 EA_OPTION(ln_nt)          // ea_norm.hip:      bits 1 (streaming loads) | 2 (streaming stores) of the sweeping kernel; default 3
 #undef EA_OPTION
@@ -89,7 +91,7 @@ namespace {
 struct Option { const char* name; int (*set)(int); int (*get)(); };
 #define EA_OPTION(n) {#n, ea_##n##_set, ea_##n##_get}
 const Option g_options[] = {EA_OPTION(gemm_tile), EA_OPTION(gemm_mfma), EA_OPTION(gemm_w4a), EA_OPTION(conv_mfma),
-                            EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(conv_w4a), EA_OPTION(attn_variant), EA_OPTION(ln_wgs), EA_OPTION(ln_nt), EA_OPTION(build_variants)};
+                            EA_OPTION(conv_tile), EA_OPTION(conv_m512), EA_OPTION(conv_w4a), EA_OPTION(attn_variant), EA_OPTION(attn_nw), EA_OPTION(attn_stages), EA_OPTION(ln_wgs), EA_OPTION(ln_nt), EA_OPTION(build_variants)};
 #undef EA_OPTION
 const Option* find_option(const char* name) {
     for (const Option& o : g_options)

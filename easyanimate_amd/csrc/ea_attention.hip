@@ -428,6 +428,20 @@ int g_attn_variant = 3;  // ea_set_option("attn_variant", 3): v3 (16x16x32 MFMA)
 
 }  // namespace
 
+int g_attn_stages = 2;   // ea_set_option("attn_stages", 2 | 3): LDS stages per operand of attention_fwd_v3_kernel (3: tiles requested one tile earlier; four-wave shape only)
+int ea_attn_stages_get() { return g_attn_stages; }
+int ea_attn_stages_set(int v) {
+    if (v != 2 && v != 3) return -1;
+    g_attn_stages = v;
+    return 0;
+}
+int g_attn_nw = 4;   // ea_set_option("attn_nw", 4 | 8): waves per workgroup of attention_fwd_v3_kernel (8: one 512-query workgroup per CU shares ONE K / V^T stream)
+int ea_attn_nw_get() { return g_attn_nw; }
+int ea_attn_nw_set(int v) {
+    if (v != 4 && v != 8) return -1;
+    g_attn_nw = v;
+    return 0;
+}
 int ea_attn_variant_get() { return g_attn_variant; }
 int ea_attn_variant_set(int v) {
     if (v != 3 && !((v == 1 || v == 2) && EA_BUILD_VARIANTS)) return -1;   // v1 / v2 (the cross-check generations): EA_BUILD_VARIANTS=1 libraries only
@@ -513,19 +527,38 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
 #endif
     (void)plain;
     ea_count("attention_v3");
-    const dim3 grid3((unsigned)att3_grid_blocks(bh, nqb));
     AttSegments hw = AttSegments();          // not a segment launch: only the head window fields are read
     hw.q_head0 = q_head0; hw.q_heads = q_heads; hw.kv_bstride = kv_bstride;
-#define EA_ATT_LAUNCH(MODE)                                                                                               \
-    hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE>), grid3, blk, ATT_LDS, st, q, k, vt, o16,                            \
-                       out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb, scale_log2e, st4, hw)
-    switch (flags) {
-        case 0: EA_ATT_LAUNCH(0); break;
-        case 1: EA_ATT_LAUNCH(1); break;
-        case 2: EA_ATT_LAUNCH(2); break;
-        default: EA_ATT_LAUNCH(3); break;
+    const int nw = g_attn_nw;
+    const int nqb3 = (q_end - q_begin + nw * 64 - 1) / (nw * 64);     // query blocks of nw * 64 rows
+    const dim3 grid3((unsigned)att3_grid_blocks(bh, nqb3)), blk3(nw * 64);
+#define EA_ATT_LAUNCH(MODE, NW_)                                                                                          \
+    hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE, false, NW_>), grid3, blk3, ATT_LDS, st, q, k, vt, o16,               \
+                       out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb3, scale_log2e, st4, hw)
+#define EA_ATT_LAUNCH3(MODE)                                                                                              \
+    hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE, false, 4, 3>), grid3, blk3, 3 * ATT_STAGE, st, q, k, vt, o16,         \
+                       out_batch_stride, heads, bh, kv_begin, kv_end, s_pad, q_begin, q_end, nqb3, scale_log2e, st4, hw)
+    if (nw == 4 && g_attn_stages == 3) {
+        switch (flags) {
+            case 0: EA_ATT_LAUNCH3(0); break;
+            case 1: EA_ATT_LAUNCH3(1); break;
+            case 2: EA_ATT_LAUNCH3(2); break;
+            default: EA_ATT_LAUNCH3(3); break;
+        }
+        return ea_check_launch("ea_attention_fwd");
+    }
+    switch (flags + (nw == 8 ? 4 : 0)) {
+        case 0: EA_ATT_LAUNCH(0, 4); break;
+        case 1: EA_ATT_LAUNCH(1, 4); break;
+        case 2: EA_ATT_LAUNCH(2, 4); break;
+        case 3: EA_ATT_LAUNCH(3, 4); break;
+        case 4: EA_ATT_LAUNCH(0, 8); break;
+        case 5: EA_ATT_LAUNCH(1, 8); break;
+        case 6: EA_ATT_LAUNCH(2, 8); break;
+        default: EA_ATT_LAUNCH(3, 8); break;
     }
 #undef EA_ATT_LAUNCH
+#undef EA_ATT_LAUNCH3
     return ea_check_launch("ea_attention_fwd");
 }
 
@@ -570,18 +603,36 @@ static int attention_segments_launch(const ea_bf16* q, const ea_bf16* k_seg0, co
     sg.rows = seg_rows; sg.tiles = seg_used_rows / ATT_KV; sg.skip = (skip_seg >= 0 && skip_seg < n_seg) ? skip_seg : n_seg;
     sg.total_tiles = used * sg.tiles; sg.stride = seg_stride; sg.first = seg_first_row / ATT_KV;
     sg.q_head0 = q_head0; sg.q_heads = q_heads; sg.kv_bstride = kv_bstride;
-    const dim3 grid((unsigned)att3_grid_blocks(bh, nqb)), blk(256);
+    const int nw = g_attn_nw;
+    const int nqb3 = (q_end - q_begin + nw * 64 - 1) / (nw * 64);
+    const dim3 grid((unsigned)att3_grid_blocks(bh, nqb3)), blk(nw * 64);
     hipStream_t st = (hipStream_t)stream;
     unsigned short* o16 = (unsigned short*)out;
     f32x4* st4 = reinterpret_cast<f32x4*>(state);
     ea_count("attention_v3_segments");
-#define EA_ATT_SEG(MODE) hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE, true>), grid, blk, ATT_LDS, st, q, k_seg0, vt_seg0, o16, \
-                                            out_batch_stride, heads, bh, 0, kv_valid, q_pad, q_begin, q_end, nqb, 1.0f, st4, sg)
-    switch (flags) {
-        case 0: EA_ATT_SEG(0); break;
-        case 1: EA_ATT_SEG(1); break;
-        case 2: EA_ATT_SEG(2); break;
-        default: EA_ATT_SEG(3); break;
+#define EA_ATT_SEG(MODE, NW_) hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE, true, NW_>), grid, blk, ATT_LDS, st, q, k_seg0, vt_seg0, o16, \
+                                                 out_batch_stride, heads, bh, 0, kv_valid, q_pad, q_begin, q_end, nqb3, 1.0f, st4, sg)
+#define EA_ATT_SEG3(MODE) hipLaunchKernelGGL((attention_fwd_v3_kernel<MODE, true, 4, 3>), grid, blk, 3 * ATT_STAGE, st, q, k_seg0, vt_seg0, o16, \
+                                             out_batch_stride, heads, bh, 0, kv_valid, q_pad, q_begin, q_end, nqb3, 1.0f, st4, sg)
+    if (nw == 4 && g_attn_stages == 3) {
+        switch (flags) {
+            case 0: EA_ATT_SEG3(0); break;
+            case 1: EA_ATT_SEG3(1); break;
+            case 2: EA_ATT_SEG3(2); break;
+            default: EA_ATT_SEG3(3); break;
+        }
+        return ea_check_launch("ea_attention_fwd_segments_bf16");
+    }
+#undef EA_ATT_SEG3
+    switch (flags + (nw == 8 ? 4 : 0)) {
+        case 0: EA_ATT_SEG(0, 4); break;
+        case 1: EA_ATT_SEG(1, 4); break;
+        case 2: EA_ATT_SEG(2, 4); break;
+        case 3: EA_ATT_SEG(3, 4); break;
+        case 4: EA_ATT_SEG(0, 8); break;
+        case 5: EA_ATT_SEG(1, 8); break;
+        case 6: EA_ATT_SEG(2, 8); break;
+        default: EA_ATT_SEG(3, 8); break;
     }
 #undef EA_ATT_SEG
     return ea_check_launch("ea_attention_fwd_segments_bf16");

@@ -765,6 +765,80 @@ def test_attention_segments_equals_contiguous_keys(P, rank, nl, n_last):
     assert torch.equal(o1, o2) and not torch.equal(o1, o_ref)
 
 
+@pytest.mark.parametrize("B,H,S,qb,qe", [(1, 3, 1000, 0, 1000), (2, 2, 2300, 64, 2100), (1, 9, 777, 100, 300), (1, 1, 5000, 0, 5000)])
+def test_attention_eight_wave_workgroups_bit_identical(B, H, S, qb, qe):
+    """Round 6: ea_set_option("attn_nw", 8) -- 512 queries per workgroup, one workgroup per CU, ONE K / V^T stream per CU (half the
+    LDS-DMA requests per wave) -- runs every wave's instruction stream over the same 64 queries and the same key tiles as the
+    four-wave shape: bit-identical outputs for the plain launch, for chained key ranges whose fp32 state is written by one shape and
+    read by the other (the state keeps the 256-query geometry), and for the segment form; head counts that are no multiple of 8
+    (the tail split over the XCDs) and query ranges that end inside a 512-row block included."""
+    from easyanimate_amd import _lib
+    ops = _ops()
+    q, k, vt, v = _attn_inputs(B, H, S, 77 + S, scale_q=1.5)
+    k[:, 0, S // 2] = q[:, 0, min(5, S - 1)] * 40                       # one head leaves RAW mode half-way
+    qs, sc = _fold(q), ops.FOLDED_ATTN_SCALE
+    outs = {}
+
+    def shape(nw, stages):
+        _lib.set_option("attn_nw", nw)
+        _lib.set_option("attn_stages", stages)
+    SHAPES = ((4, 2), (8, 2), (4, 3))          # (waves per workgroup, LDS stages): the product shape, one stream per CU, a deeper ring
+    try:
+        for sh in SHAPES:
+            shape(*sh)
+            o = torch.full((B, S, H * 64), 3.0, dtype=torch.bfloat16, device=DEV)
+            ops.attention(qs, k, vt, S, sc, out=o, q_begin=qb, q_end=qe)
+            outs[sh] = o
+        assert all(torch.equal(outs[(4, 2)], o) for o in outs.values()) and torch.isfinite(outs[(4, 2)][:, qb:qe].float()).all()
+        # key ranges: the state written with one shape, resumed with another
+        mid = (S // 2) // 64 * 64
+        res = {}
+        for first in SHAPES:
+            for second in SHAPES:
+                st = ops.attention_state(B, H, qb, qe, DEV)
+                o = torch.full((B, S, H * 64), 3.0, dtype=torch.bfloat16, device=DEV)
+                shape(*first)
+                ops.attention_range(qs, k, vt, sc, qb, qe, mid, S, state=st, store_state=True)
+                shape(*second)
+                ops.attention_range(qs, k, vt, sc, qb, qe, 0, mid, state=st, load_state=True, out=o)
+                res[(first, second)] = o
+        assert all(torch.equal(res[((4, 2), (4, 2))], r) for r in res.values())
+        assert (res[((4, 2), (4, 2))][:, qb:qe].float() - outs[(4, 2)][:, qb:qe].float()).abs().max().item() < 0.03
+    finally:
+        shape(4, 2)
+
+
+@pytest.mark.parametrize("P,rank,nl,n_last", [(4, 1, 192, 192), (4, 3, 192, 100), (3, 2, 320, 17)])
+def test_attention_segments_eight_wave_workgroups_bit_identical(P, rank, nl, n_last):
+    from easyanimate_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(131 + P + rank)
+    B, H, T, n_own = 2, 3, 64, (n_last if rank == P - 1 else nl)
+    S_q = T + n_own
+    q_pad = ops.round_up(S_q, 256)
+    q = torch.zeros(B, H, q_pad, 64, dtype=torch.bfloat16, device=DEV)
+    q[:, :, :S_q] = _bf(torch.randn(B, H, S_q, 64, generator=g) * 0.3).to(DEV)
+    gathered = torch.zeros(P, 2, B, H, nl * 64, dtype=torch.bfloat16, device=DEV)
+    shard_rows = [nl] * (P - 1) + [n_last]
+    for r in range(P):
+        gathered[r, 0].view(B, H, nl, 64)[:, :, :shard_rows[r]] = _bf(torch.randn(B, H, shard_rows[r], 64, generator=g)).to(DEV)
+        gathered[r, 1].view(B, H, 64, nl)[:, :, :, :shard_rows[r]] = _bf(torch.randn(B, H, 64, shard_rows[r], generator=g)).to(DEV)
+    others = [r for r in range(P) if r != rank]
+    kv_valid = sum(nl for r in others[:-1]) + shard_rows[others[-1]]
+    outs = {}
+    try:
+        for nw, stages in ((4, 2), (8, 2), (4, 3)):
+            _lib.set_option("attn_nw", nw)
+            _lib.set_option("attn_stages", stages)
+            o = torch.empty(B, S_q, H * 64, dtype=torch.bfloat16, device=DEV)
+            ops.attention_segments(q, gathered, P, rank, nl, kv_valid, 0, S_q, out=o)
+            outs[(nw, stages)] = o
+    finally:
+        _lib.set_option("attn_nw", 4)
+        _lib.set_option("attn_stages", 2)
+    assert all(torch.equal(outs[(4, 2)], o) for o in outs.values())
+
+
 def test_attention_full_size_config3():
     """BASELINE.json config 3 sequence (S = 53 504 = 836 key tiles, 209 query blocks), 2 heads: the product kernel against
     a chunked fp32 torch evaluation of the same attention on the GPU (checker only), plus the size-independent
