@@ -94,6 +94,8 @@ def load() -> ctypes.CDLL:
     lib.ea_attention_state_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.ea_conv3d_cl_tmerge_ok.restype = c_int
     lib.ea_conv3d_cl_tmerge_ok.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.ea_conv3d_cl_blocked_ok.restype = c_int
+    lib.ea_conv3d_cl_blocked_ok.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.ea_set_option.restype = c_int
     lib.ea_set_option.argtypes = [ctypes.c_char_p, c_int]
     lib.ea_get_option.restype = c_int

@@ -42,6 +42,7 @@ struct ConvArgs {
     // p.w holds two merged-weight classes [2][C_out, 18 * C_in] (even t: {W0, W1+W2}; odd t: {W0+W1, W2}) and the K loop runs
     // over 2 x 3 x 3 taps: 2/3 of the MFMA work (row-slab kernels only)
     int tmerge;
+    int x_cb;            // x is channel-blocked [C_in / 32][T_in][H_in][W_in][32] (conv3d_cl_row16_w4a_kernel<.., .., true> only)
     int tiles_m, tiles_n;
     int64_t M;
     float* gn_partial;   // optional (row-slab 16x16x32 kernel): per-(frame, row tile, wave row, 4-channel bundle) (sum, sumsq)
@@ -1579,7 +1580,11 @@ __device__ __forceinline__ void conv_w4a_epilogue_img(const ConvArgs& p, f32x4 (
     }
 }
 
-template <int BN, int TM>   // 128 x 512 or 256 x 256: (channels, voxels) per workgroup
+// CB (round 6): x is CHANNEL-BLOCKED, [C_in / 32][T_in][H_in][W_in][32] (what ea_groupnorm_apply_bf16 writes on request): a slab's
+// 16-voxel LDS-DMA piece is then 1 KiB of consecutive memory instead of sixteen 64-byte runs C_in * 2 bytes apart (the slab fill the
+// main loop waits on: 55 -> 124 GB/s per CU in profiles/r04m_conv_slab_dma_pattern.jsonl).  Same values into the same LDS rows:
+// bit-identical to the voxel-major input.
+template <int BN, int TM, bool CB = false>   // 128 x 512 or 256 x 256: (channels, voxels) per workgroup
 __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
     static_assert((BN == 128 && TM == 512) || (BN == 256 && TM == 256), "wave tile 128 voxels x 128 channels, four waves");
     constexpr int RB = 64, KC = 32;
@@ -1621,7 +1626,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
         const int q = wave * PPW + i;
         const int r = q * 16 + (lane >> 2), c = lane & 3;
         const int w = w0 - 1 + r;
-        a_voff[i] = (r < NROW && w >= 0 && w < p.W_in) ? (w * p.C_in + (c ^ ((r >> 1) & 3)) * 8) * 2 : 0x40000000;
+        a_voff[i] = (r < NROW && w >= 0 && w < p.W_in) ? (w * (CB ? 32 : p.C_in) + (c ^ ((r >> 1) & 3)) * 8) * 2 : 0x40000000;
     }
     const int wk = (p.tmerge ? 18 : 27) * p.C_in;
     int w_voff[WP];
@@ -1632,7 +1637,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
     }
     const unsigned short* const w_tile = p.w + (p.tmerge ? (int64_t)(t_out & 1) * p.C_out * wk : 0) + (int64_t)col0 * wk;
     const unsigned w_bytes = (unsigned)(BN * wk * 2);
-    const int row_bytes = p.W_in * p.C_in * 2;
+    const int row_bytes = p.W_in * (CB ? 32 : p.C_in) * 2;              // (blocked: one row of ONE channel block)
 
     // the (dt, dh) -> input row table: lane l < ntab holds the row of dtdh = l (base address, extent; extent 0 = zero padding)
     const int ntab = p.tmerge ? 6 : 9;
@@ -1649,7 +1654,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
         }
         const int hu = h_out + dh - 1;
         const bool ok = hu >= 0 && hu < p.H_in;
-        const unsigned short* row = p.x + ((int64_t)ti * p.H_in + (ok ? hu : 0)) * p.W_in * p.C_in;
+        const unsigned short* row = p.x + ((int64_t)ti * p.H_in + (ok ? hu : 0)) * p.W_in * (CB ? 32 : p.C_in);   // (blocked: channel block 0)
         t_lo = (unsigned)(uintptr_t)row;
         t_hi = (unsigned)((uintptr_t)row >> 32);
         t_ext = ok ? (unsigned)row_bytes : 0u;
@@ -1671,25 +1676,31 @@ __global__ __launch_bounds__(256) void conv3d_cl_row16_w4a_kernel(ConvArgs p) {
     const unsigned cblocks = __builtin_amdgcn_readfirstlane((unsigned)(p.C_in / KC));
     const unsigned nslabs = __builtin_amdgcn_readfirstlane((unsigned)(ntab * (p.C_in / KC)));
     const unsigned cin2 = __builtin_amdgcn_readfirstlane((unsigned)(p.C_in * 2));
+    const uint64_t cb_bytes = (uint64_t)(p.vin ? (p.T_in + 1) >> 1 : p.T_in) * p.H_in * p.W_in * 64;      // one channel block of a blocked input (PHYSICAL frames)
+    const unsigned cb_lo = __builtin_amdgcn_readfirstlane((unsigned)cb_bytes), cb_hi = __builtin_amdgcn_readfirstlane((unsigned)(cb_bytes >> 32));
 #define EA_CW4_COMMON                                                                                                             \
     [t_lo] "v"(t_lo), [t_hi] "v"(t_hi), [t_ext] "v"(t_ext), [ak0] "v"(ak[0]), [ak1] "v"(ak[1]), [ak2] "v"(ak[2]), [wk] "v"(wkf),   \
         [w_lo] "s"(w_lo), [w_hi] "s"(w_hi), [w_ext] "s"(w_ext), [cblocks] "s"(cblocks), [nslabs] "s"(nslabs), [cin2] "s"(cin2),     \
         [lds_w] "s"(lds_w), [lds_a] "s"(lds_a)
     f32x4 accq[64];        // the 256 accumulators a0..a255, as the main asm's outputs: live until the read-outs consume them
-    if constexpr (TM == 512) {
-        asm volatile(EA_CONV_W4A_ASM_M512
-                     : EA_W4A_ACC_OUTPUTS(accq)
-                     : EA_CW4_COMMON, [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]),
-                       [aoff4] "v"(a_voff[4]), [aoff5] "v"(a_voff[5]), [aoff6] "v"(a_voff[6]), [aoff7] "v"(a_voff[7]), [aoff8] "v"(a_voff[8]),
-                       [woff0] "v"(w_voff[0]), [woff1] "v"(w_voff[1])
+#define EA_CW4_M512 [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]), [aoff4] "v"(a_voff[4]),      \
+                    [aoff5] "v"(a_voff[5]), [aoff6] "v"(a_voff[6]), [aoff7] "v"(a_voff[7]), [aoff8] "v"(a_voff[8]), [woff0] "v"(w_voff[0]),       \
+                    [woff1] "v"(w_voff[1])
+#define EA_CW4_N256 [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]), [aoff4] "v"(a_voff[4]),      \
+                    [woff0] "v"(w_voff[0]), [woff1] "v"(w_voff[1]), [woff2] "v"(w_voff[2]), [woff3] "v"(w_voff[3])
+    if constexpr (TM == 512 && !CB) {
+        asm volatile(EA_CONV_W4A_ASM_M512 : EA_W4A_ACC_OUTPUTS(accq) : EA_CW4_COMMON, EA_CW4_M512 : EA_CONV_W4A_CLOBBERS);
+    } else if constexpr (TM == 512) {
+        asm volatile(EA_CONV_W4A_ASM_M512_CB : EA_W4A_ACC_OUTPUTS(accq) : EA_CW4_COMMON, EA_CW4_M512, [cb_lo] "s"(cb_lo), [cb_hi] "s"(cb_hi)
                      : EA_CONV_W4A_CLOBBERS);
+    } else if constexpr (!CB) {
+        asm volatile(EA_CONV_W4A_ASM_N256 : EA_W4A_ACC_OUTPUTS(accq) : EA_CW4_COMMON, EA_CW4_N256 : EA_CONV_W4A_CLOBBERS);
     } else {
-        asm volatile(EA_CONV_W4A_ASM_N256
-                     : EA_W4A_ACC_OUTPUTS(accq)
-                     : EA_CW4_COMMON, [aoff0] "v"(a_voff[0]), [aoff1] "v"(a_voff[1]), [aoff2] "v"(a_voff[2]), [aoff3] "v"(a_voff[3]),
-                       [aoff4] "v"(a_voff[4]), [woff0] "v"(w_voff[0]), [woff1] "v"(w_voff[1]), [woff2] "v"(w_voff[2]), [woff3] "v"(w_voff[3])
+        asm volatile(EA_CONV_W4A_ASM_N256_CB : EA_W4A_ACC_OUTPUTS(accq) : EA_CW4_COMMON, EA_CW4_N256, [cb_lo] "s"(cb_lo), [cb_hi] "s"(cb_hi)
                      : EA_CONV_W4A_CLOBBERS);
     }
+#undef EA_CW4_M512
+#undef EA_CW4_N256
 #undef EA_CW4_COMMON
 
     // ---- epilogue: the wave's 128 channels as two halves of 64 (accumulator column blocks 0..3, then 4..7)
@@ -1809,8 +1820,9 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.ss = ss; p.pad = pad; p.ups = ups;
     // tdup flags: 1 = store every output frame but the first twice; 2 = the input's frames are virtually duplicated (x holds
     // T_in physical frames, the convolution sees 2 T_in - 1); 4 = the residual's frames are virtually duplicated
-    EA_REQUIRE((tdup & ~15) == 0, "ea_conv3d_cl_bf16: tdup is a bit set of 1 (duplicate store), 2 (virtual input), 4 (virtual residual), 8 (merged temporal taps)");
-    p.tdup = tdup & 1; p.vin = (tdup >> 1) & 1; p.vres = (tdup >> 2) & 1; p.tmerge = (tdup >> 3) & 1;
+    EA_REQUIRE((tdup & ~31) == 0, "ea_conv3d_cl_bf16: tdup is a bit set of 1 (duplicate store), 2 (virtual input), 4 (virtual residual), 8 (merged temporal taps), "
+                                  "16 (channel-blocked input)");
+    p.tdup = tdup & 1; p.vin = (tdup >> 1) & 1; p.vres = (tdup >> 2) & 1; p.tmerge = (tdup >> 3) & 1; p.x_cb = (tdup >> 4) & 1;
     tdup = p.tdup;   // from here on `tdup` is the duplicate-store flag alone (the kernel choice below tests it)
     EA_REQUIRE(!(p.vin && (kt != 3 || st != 1 || C_in == 8)), "ea_conv3d_cl_bf16: virtual input frames need a 3x3x3 temporal-stride-1 layer");
     EA_REQUIRE(!(p.vres && !res), "ea_conv3d_cl_bf16: virtual residual without a residual");
@@ -1826,6 +1838,8 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     p.W_out = conv_out_dim(We, kw, ss, pad, pad_hi);
     p.M = (int64_t)p.T_out * p.H_out * p.W_out;
     EA_REQUIRE(p.M > 0 && p.M < (1ll << 40), "ea_conv3d_cl_bf16: bad output size");
+    EA_REQUIRE(!p.x_cb || (kt == 3 && st == 1 && ss == 1 && pad == 1 && !ups && !tdup && ea_conv3d_cl_blocked_ok(p.T_out, p.H_out, p.W_out, C_in, C_out)),
+               "ea_conv3d_cl_bf16: a channel-blocked input (tdup bit 4) is read by the four-wave row-slab kernels only: ask ea_conv3d_cl_blocked_ok first");
     if (C_in == 8) {   // one 16-byte chunk per voxel: eight taps per K tile (conv3d_cl_kernel<true>)
         EA_REQUIRE(p.M < (1ll << 31), "ea_conv3d_cl_bf16: too many output voxels for the 8-channel kernel");
         p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -1945,6 +1959,22 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
                     (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
                     attr6_done = true;
                 }
+                if (p.x_cb) {
+                    static bool attr7_done = false;
+                    if (!attr7_done) {
+                        (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<128, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                        (void)hipFuncSetAttribute((const void*)conv3d_cl_row16_w4a_kernel<256, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                        attr7_done = true;
+                    }
+                    ea_count("conv_w4a");
+                    ea_count("conv_blocked_input");
+                    ea_count(k32_128 ? "conv_row16_m512" : "conv_row16_256_k32");
+                    if (k32_128)
+                        hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<128, 512, true>), dim3((unsigned)grid5), dim3(256), 128 * 1024, (hipStream_t)stream, p);
+                    else
+                        hipLaunchKernelGGL((conv3d_cl_row16_w4a_kernel<256, 256, true>), dim3((unsigned)grid5), dim3(256), 128 * 1024, (hipStream_t)stream, p);
+                    return ea_check_launch("ea_conv3d_cl_bf16");
+                }
                 if (k32_128) {
                     ea_count("conv_w4a");            // (marker first: ea_last_dispatch() names the kernel family, as before)
                     ea_count("conv_row16_m512");
@@ -1956,6 +1986,7 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
                 }
                 return ea_check_launch("ea_conv3d_cl_bf16");
             }
+            EA_REQUIRE(!p.x_cb, "ea_conv3d_cl_bf16: a channel-blocked input is served by the four-wave row-slab kernels only (ea_conv3d_cl_blocked_ok)");
             if (k32_128) {
                 ea_count("conv_row16_m512");
                 hipLaunchKernelGGL((conv3d_cl_row16_k32_kernel<128, 512, false>), dim3((unsigned)grid5), b3, lds5, (hipStream_t)stream, p);
@@ -2077,6 +2108,20 @@ extern "C" int ea_conv3d_cl_tmerge_ok(int T_logical, int H, int W, int C_in, int
     return (g_conv_tile == 1024 || (g_conv_tile == 0 && tiles256 * (C_out / bn) >= 512)) ? 1 : 0;
 }
 
+// Would ea_conv3d_cl_bf16 serve a 3x3x3 / stride 1 / pad 1 layer of this shape (no folded up-sampling, no duplicate store) with the
+// kernels that read a channel-blocked input (tdup bit 4)?  Mirrors the kernel choice of conv3d_cl_impl; T = the layer's output
+// (= logical input) frame count.
+extern "C" int ea_conv3d_cl_blocked_ok(int T, int H, int W, int C_in, int C_out) {
+    const int bn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 0);
+    if (bn == 0 || C_in % 64 != 0 || W % 256 != 0 || g_conv_mfma != 16 || T < 1) return 0;
+    const int64_t tiles256 = ((int64_t)T * H * W + 255) / 256;
+    if (!(g_conv_tile == 1024 || (g_conv_tile == 0 && tiles256 * (C_out / bn) >= 512))) return 0;
+    const bool k32_128 = C_out == 128 && W % 512 == 0 && (g_conv_m512 & 1);
+    const bool k32_256 = bn == 256 && ((g_conv_m512 & 2) || (g_conv_w4a & 2));
+    if (!(k32_128 || k32_256)) return 0;
+    return ((k32_128 && (g_conv_w4a & 1)) || (!k32_128 && (g_conv_w4a & 2))) ? 1 : 0;
+}
+
 extern "C" int ea_conv3d_cl_subpixel_bf16(const ea_bf16* x, const ea_bf16* w4, const float* bias, ea_bf16* y, int T_in, int H_in,
                                           int W_in, int C_in, int C_out, int tdup, float* gn_partial, int64_t gn_capacity_floats,
                                           int* gn_nblk_out, void* stream) {
@@ -2091,7 +2136,7 @@ extern "C" int ea_conv3d_cl_subpixel_bf16(const ea_bf16* x, const ea_bf16* w4, c
     p.x = x; p.w = w4; p.bias = bias; p.res = nullptr; p.y = y; p.zeros = nullptr;
     p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.C_in = C_in; p.C_out = C_out;
     p.T_out = T_in; p.H_out = 2 * H_in; p.W_out = 2 * W_in;
-    p.kt = p.kh = p.kw = 3; p.st = p.ss = 1; p.pad = 1; p.ups = 0; p.tdup = tdup; p.vin = 0; p.vres = 0; p.tmerge = 0;
+    p.kt = p.kh = p.kw = 3; p.st = p.ss = 1; p.pad = 1; p.ups = 0; p.tdup = tdup; p.vin = 0; p.vres = 0; p.tmerge = 0; p.x_cb = 0;
     p.M = (int64_t)p.T_out * H_in * W_in;          // source voxels: the M axis of ONE parity class
     EA_REQUIRE(p.M < (1ll << 31) && (int64_t)p.T_out * p.H_out * p.W_out < (1ll << 40), "ea_conv3d_cl_subpixel_bf16: clip too large");
     p.tiles_m = (int)(p.M / 256);

@@ -168,7 +168,10 @@ __device__ __forceinline__ gn_u32x4 gn_apply_chunk(const gn_u32x4 raw, const gn_
     return o;
 }
 
-template <int ACT>
+// CB (round 6): the output is written CHANNEL-BLOCKED, [C / 32][T][hw][32] -- the layout the four-wave row-slab convolutions read
+// their slabs from in 1 KiB pieces (conv3d_cl_row16_w4a_kernel<.., .., true>).  A thread's 16-byte chunk of 8 channels lands in the
+// 64-byte record of its voxel inside its channel block: a wave's store is C / 32 runs of (2048 / C) consecutive voxels.
+template <int ACT, bool CB = false>
 __global__ __launch_bounds__(256) void gn_apply_frame_kernel(const unsigned short* __restrict__ x,
                                                              unsigned short* __restrict__ y,
                                                              const float* __restrict__ stats,
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(256) void gn_apply_frame_kernel(const unsigned shor
         b[j >> 1][j & 1] = beta[c0 + j] - st[0] * aj;
     }
     const unsigned short* xf = x + (int64_t)t * hw * C + c0;
-    unsigned short* yf = y + (int64_t)t * hw * C + c0;
+    const int64_t ys = CB ? 32 : C;                       // elements between consecutive voxels of the output
+    unsigned short* yf = CB ? y + (((int64_t)(vc >> 2) * gridDim.y + t) * hw) * 32 + (vc & 3) * 8 : y + (int64_t)t * hw * C + c0;
     // four voxels per trip: all four loads are in flight before the first is used (one 16-byte load per thread and trip left
     // the kernel latency-bound at 2.6 TB/s); streaming loads / stores -- nothing here is read twice.
     // a trip covers 4 * rows CONSECUTIVE voxels: a wave's four loads are 4 x 1 KiB side by side.  The first version of this loop
@@ -202,10 +206,10 @@ __global__ __launch_bounds__(256) void gn_apply_frame_kernel(const unsigned shor
         for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const gn_u32x4*>(xf + (v + u * rows) * C));
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            __builtin_nontemporal_store(gn_apply_chunk<ACT>(raw[u], a, b), reinterpret_cast<gn_u32x4*>(yf + (v + u * rows) * C));
+            __builtin_nontemporal_store(gn_apply_chunk<ACT>(raw[u], a, b), reinterpret_cast<gn_u32x4*>(yf + (v + u * rows) * ys));
     }
     for (int64_t v = ngrp * grp + (int64_t)blockIdx.x * rows + vr; v < hw; v += (int64_t)gridDim.x * rows)
-        *reinterpret_cast<gn_u32x4*>(yf + v * C) = gn_apply_chunk<ACT>(*reinterpret_cast<const gn_u32x4*>(xf + v * C), a, b);
+        *reinterpret_cast<gn_u32x4*>(yf + v * ys) = gn_apply_chunk<ACT>(*reinterpret_cast<const gn_u32x4*>(xf + v * C), a, b);
 }
 
 // ---- row softmax: y = softmax(x * scale) per row, bf16 in/out, fp32 math; one block per row --------------------
@@ -384,7 +388,24 @@ extern "C" int ea_groupnorm_apply_bf16(const ea_bf16* x, ea_bf16* y, const float
                                        const float* beta, int T, int64_t hw, int C, int groups, int act, void* stream) {
     EA_REQUIRE(x && y && stats && gamma && beta, "ea_groupnorm_apply_bf16: null tensor");
     EA_REQUIRE(C % 8 == 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "ea_groupnorm_apply_bf16: bad channels/groups");
+    EA_REQUIRE((act & ~3) == 0, "ea_groupnorm_apply_bf16: act is 0 / 1 (SiLU), + 2 for a channel-blocked output");
+    const int blocked = act >> 1;
+    act &= 1;
     const int nvec = C / 8;
+    EA_REQUIRE(!blocked || (C % 32 == 0 && nvec <= 256 && 256 % nvec == 0 && T <= 65535 && x != y),
+               "ea_groupnorm_apply_bf16: the channel-blocked output needs C a multiple of 32 dividing 2048, T <= 65535, and y != x");
+    if (blocked) {
+        const int rows = 256 / nvec;
+        int64_t bx = (hw + rows - 1) / rows;
+        bx = bx > 4096 ? 4096 : bx;
+        if (act == 1)
+            hipLaunchKernelGGL((gn_apply_frame_kernel<1, true>), dim3((unsigned)bx, (unsigned)T), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma,
+                               beta, hw, C, groups);
+        else
+            hipLaunchKernelGGL((gn_apply_frame_kernel<0, true>), dim3((unsigned)bx, (unsigned)T), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma,
+                               beta, hw, C, groups);
+        return ea_check_launch("ea_groupnorm_apply_bf16");
+    }
     if (nvec <= 256 && 256 % nvec == 0 && T <= 65535) {
         const int rows = 256 / nvec;
         int64_t bx = (hw + rows - 1) / rows;

@@ -663,7 +663,8 @@ def conv_out_shape(T, H, W, k: int, st: int, ss: int, pad: int, ups: bool = Fals
 
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], k: int, st: int = 1, ss: int = 1,
               pad: int = 1, ups: bool = False, tdup: bool = False, res: Optional[torch.Tensor] = None,
-              want_stats: bool = True, vin: bool = False, vres: bool = False, tmerge: bool = False) -> torch.Tensor:
+              want_stats: bool = True, vin: bool = False, vres: bool = False, tmerge: bool = False,
+              blocked: bool = False) -> torch.Tensor:
     """x bf16 [T,H,W,Cin] (Cin % 64 == 0), w_packed bf16 [Cout, k^3*Cin] -> bf16 [T',H',W',Cout].
     Cin == 8 (RGB padded to one 16-byte chunk per voxel; k = 3): w_packed [Cout, 256] = 32 tap slots x 8 channels, zero beyond
     tap 26 / the real channels (pack_conv_weight_c8).
@@ -673,8 +674,12 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     logical frame f = physical frame (f + 1) >> 1; ea_mi355x.h, tdup bits 2 / 4)."""
     _dev(x, w_packed, bias, res)
     _chk(x, _BF16, "x"); _chk(w_packed, _BF16, "w")
-    assert x.is_contiguous() and w_packed.is_contiguous() and x.dim() == 4
-    T, H, W, Cin = x.shape
+    if blocked:     # channel-blocked input [Cin/32, T, H, W, 32] (groupnorm_silu(..., blocked=True); tdup bit 16; conv3d_blocked_ok)
+        assert x.is_contiguous() and w_packed.is_contiguous() and x.dim() == 5 and x.shape[4] == 32
+        T, H, W, Cin = x.shape[1], x.shape[2], x.shape[3], x.shape[0] * 32
+    else:
+        assert x.is_contiguous() and w_packed.is_contiguous() and x.dim() == 4
+        T, H, W, Cin = x.shape
     if tmerge:      # merged temporal taps (tdup bit 8): w_packed [2, Cout, 18*Cin], see vae_modules._pack_tmerge_weight
         assert vin and k == 3 and w_packed.dim() == 3 and w_packed.shape[0] == 2 and w_packed.shape[2] == 18 * Cin
         Cout = w_packed.shape[1]
@@ -687,7 +692,7 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     y = torch.empty((Ty, Ho, Wo, Cout), dtype=_BF16, device=x.device)
     if res is not None:
         assert res.is_contiguous() and res.shape == ((To + 1) // 2 if vres else To, Ho, Wo, Cout) and res.dtype == _BF16
-    dup = int(tdup and To > 1) | (2 if vin else 0) | (4 if (vres and res is not None) else 0) | (8 if tmerge else 0)
+    dup = int(tdup and To > 1) | (2 if vin else 0) | (4 if (vres and res is not None) else 0) | (8 if tmerge else 0) | (16 if blocked else 0)
     if want_stats and k == 3 and ((st, ss, pad) == (1, 1, 1) or (ss == 2 and pad == 0 and not ups)) and Wo % 256 == 0 and Cout % 128 == 0:
         cap = Ty * Ho * (Wo // 256) * 4 * (Cout // 4) * 2       # the largest layout the kernel may choose
         partial = torch.empty(cap, dtype=_F32, device=x.device)
@@ -702,6 +707,11 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                                        _p(_zeros_page(x.device)), T, H, W, Cin, Cout, k, k, k, st, ss, pad, int(ups),
                                        dup, _stream()))
     return y
+
+
+def conv3d_blocked_ok(T: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    """Will this 3x3x3 / stride 1 / pad 1 layer (T output frames) be served by a kernel that reads a channel-blocked input?"""
+    return bool(_lib.load().ea_conv3d_cl_blocked_ok(int(T), int(H), int(W), int(Cin), int(Cout)))
 
 
 def conv3d_tmerge_ok(T_logical: int, H: int, W: int, Cin: int, Cout: int) -> bool:
@@ -775,9 +785,10 @@ def im2col3d(x: torch.Tensor, k: int, st: int, ss: int, pad: int, k_pad: int):
 
 
 def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
-                   act: bool = True) -> torch.Tensor:
+                   act: bool = True, blocked: bool = False) -> torch.Tensor:
     """Per-frame GroupNorm (+SiLU) of x bf16 [T, H, W, C] (or [T, HW, C]).  When x came out of a convolution that already
-    reduced its output (x.gn_partial, see conv3d_cl) only the finalize kernel runs; otherwise the statistics pass."""
+    reduced its output (x.gn_partial, see conv3d_cl) only the finalize kernel runs; otherwise the statistics pass.
+    blocked: the result is written channel-blocked, bf16 [C / 32, T, H, W, 32] (for conv3d_cl(..., blocked=True))."""
     _dev(x, gamma, beta)
     _chk(x, _BF16, "x"); _chk(gamma, _F32, "gamma"); _chk(beta, _F32, "beta")
     assert x.is_contiguous()
@@ -792,8 +803,12 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
         nblk = max(1, min(256, hw // 2048))
         partial = torch.empty((T, nblk, C // 4, 2), dtype=_F32, device=x.device)
         _lib.call("ea_groupnorm_stats_bf16", _p(x), _p(partial), _p(stats), T, hw, C, groups, nblk, float(eps), _stream())
-    y = torch.empty_like(x)
-    _lib.call("ea_groupnorm_apply_bf16", _p(x), _p(y), _p(stats), _p(gamma), _p(beta), T, hw, C, groups, int(act), _stream())
+    if blocked:
+        assert x.dim() == 4 and C % 32 == 0
+        y = torch.empty((C // 32, T, x.shape[1], x.shape[2], 32), dtype=_BF16, device=x.device)
+    else:
+        y = torch.empty_like(x)
+    _lib.call("ea_groupnorm_apply_bf16", _p(x), _p(y), _p(stats), _p(gamma), _p(beta), T, hw, C, groups, int(act) | (2 if blocked else 0), _stream())
     return y
 
 

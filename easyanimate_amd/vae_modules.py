@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -78,6 +80,9 @@ def _pad_bias(b: Optional[torch.Tensor], n_pad: int) -> Optional[torch.Tensor]:
 
 
 FLASH_MID_BLOCK = True   # False: mid-block attention as Q K^T GEMM -> fp32 logits -> row softmax -> P V GEMM per frame (A/B, tests)
+# True: a GroupNorm whose one consumer is a 3x3x3 layer served by the four-wave row-slab kernels writes its output channel-blocked
+# ([C / 32, T, H, W, 32]) and the convolution fills its slabs from 1 KiB pieces (bit-identical; False / EA_VAE_BLOCKED=0: A/B, tests)
+BLOCKED_GN_OUTPUT = os.environ.get("EA_VAE_BLOCKED", "1") != "0"
 VIRTUAL_TDUP = True   # False: SpatialTemporalUpsampler3D materialises its duplicated frames (A/B, tests)
 
 
@@ -148,6 +153,20 @@ def _pack_conv_weight_c8(w: torch.Tensor, n_pad: int) -> torch.Tensor:
     return out.view(n_pad, 256)
 
 
+def _wants_blocked(conv: nn.Conv3d, x: torch.Tensor) -> bool:
+    """Will `conv` applied to the GroupNorm of x (voxel-major [T, H, W, C], possibly virtual) read a channel-blocked input?  Mirrors the
+    route _conv_cl_local takes for a plain 3x3x3 / stride 1 / pad 1 layer (no up-sampling, no narrow output) with no VAE split."""
+    from . import vae_parallel
+    if not BLOCKED_GN_OUTPUT or vae_parallel.current() is not None or x.dim() != 4:
+        return False
+    co, ci, kt, kh, kw = conv.weight.shape
+    if not (kt == kh == kw == 3 and tuple(conv.stride) == (1, 1, 1) and conv.padding[1] == 1 and ci % 64 == 0 and co > 4 and x.shape[-1] == ci):
+        return False
+    T = x.shape[0]
+    Tl = 2 * T - 1 if (is_virtual(x) and T > 1) else T
+    return ops.conv3d_blocked_ok(Tl, x.shape[1], x.shape[2], ci, ops.round_up(co, 8))
+
+
 def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor] = None, ups: bool = False,
                    tdup: bool = False) -> torch.Tensor:
     co, ci, kt, kh, kw = conv.weight.shape
@@ -156,6 +175,17 @@ def _conv_cl_local(conv: nn.Conv3d, x: torch.Tensor, res: Optional[torch.Tensor]
     assert sh == sw
     pad = conv.padding[1] if kt == 3 else 0
     n_pad = ops.round_up(co, 8)
+    if getattr(x, "cblocked", False):
+        # a channel-blocked GroupNorm output [ci / 32, T, H, W, 32] (_gn(..., consumer=conv) asked _wants_blocked first)
+        assert x.dim() == 5 and x.shape[0] * 32 == ci and kt == 3 and (st, sh, pad) == (1, 1, 1) and not ups and not tdup
+        w = derived(conv.weight, f"cl{n_pad}", lambda t: _pack_conv_weight(t, None, n_pad))
+        b = derived(conv.bias, f"b{n_pad}", lambda t: _pad_bias(t, n_pad)) if conv.bias is not None else None
+        vin = is_virtual(x)
+        T, H, W = x.shape[1:4]
+        if vin and TEMPORAL_TAP_MERGE and T > 1 and ops.conv3d_tmerge_ok(2 * T - 1, H, W, ci, n_pad):
+            wm = derived(conv.weight, f"tmerge{n_pad}", lambda t: _pack_tmerge_weight(t, n_pad))
+            return ops.conv3d_cl(x, wm, b, kt, st, sh, pad, res=res, vin=True, vres=is_virtual(res), tmerge=True, blocked=True)
+        return ops.conv3d_cl(x, w, b, kt, st, sh, pad, res=res, vin=vin, vres=is_virtual(res), blocked=True)
     c8 = ci <= 8 and kt == 3 and x.shape[-1] == 8 and res is None and not ups and not tdup
     if is_virtual(x) or is_virtual(res):
         assert ci % 64 == 0 and not (co <= 4 and kt == 3), "virtual clips feed the wide 3x3x3 / 1x1x1 layers of the up blocks only"
@@ -227,10 +257,18 @@ class CausalConv3d(nn.Conv3d):
         return conv_cl(self, x, res=res, ups=ups, tdup=tdup)
 
 
-def _gn(norm: nn.GroupNorm, x: torch.Tensor, act: bool) -> torch.Tensor:
-    """Per-frame GroupNorm: a virtual clip is normalised on its physical frames (duplicated frames have equal statistics)."""
+def _gn(norm: nn.GroupNorm, x: torch.Tensor, act: bool, consumer: Optional[nn.Conv3d] = None) -> torch.Tensor:
+    """Per-frame GroupNorm: a virtual clip is normalised on its physical frames (duplicated frames have equal statistics).
+    consumer: the ONE layer that reads the result; if it is a convolution that fills its slabs faster from a channel-blocked
+    tensor, the result is written that way (y.cblocked)."""
     from . import vae_parallel
     tp = vae_parallel.current()
+    if consumer is not None and _wants_blocked(consumer, x):
+        y = ops.groupnorm_silu(x, f32(norm.weight), f32(norm.bias), norm.num_groups, norm.eps, act=act, blocked=True)
+        y.cblocked = True
+        if is_virtual(x):
+            y.tvirt = True
+        return y
     if tp is not None and tp.ps > 1:
         # spatial split: the statistics are over the WHOLE frame -- all-reduce the additive half over the frame's ranks
         sums = tp.all_reduce_rows(ops.groupnorm_local_sums(x, norm.num_groups))
@@ -265,9 +303,9 @@ class ResidualBlock3D(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         shortcut = x if isinstance(self.shortcut, nn.Identity) else conv_cl(self.shortcut, x)
-        h = _gn(self.norm1, x, act=True)
+        h = _gn(self.norm1, x, act=True, consumer=self.conv1)
         h = self.conv1(h)
-        h = _gn(self.norm2, h, act=True)
+        h = _gn(self.norm2, h, act=True, consumer=self.conv2)
         return self.conv2(h, res=shortcut)  # (x + shortcut) / 1.0 fused in the conv epilogue
 
 

@@ -434,6 +434,12 @@ int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, con
  * accepts tdup bit 8 (merged temporal taps), else 0. */
 int ea_conv3d_cl_tmerge_ok(int T_logical, int H, int W, int C_in, int C_out);
 
+/* Would ea_conv3d_cl_bf16 read a CHANNEL-BLOCKED input for this layer (3x3x3, stride 1, pad 1, no folded up-sampling / duplicate
+ * store; T = output frames)?  tdup bit 4 (16) of ea_conv3d_cl_bf16 / ea_conv3d_cl_stats_bf16 declares x as [C_in/32][T_in][H_in][W_in][32]
+ * (T_in PHYSICAL frames) -- the layout ea_groupnorm_apply_bf16 writes with act bit 1 (2) -- which only the four-wave row-slab
+ * kernels read: a slab's 16-voxel LDS-DMA piece is then 1 KiB of consecutive memory.  Same values, same results. */
+int ea_conv3d_cl_blocked_ok(int T, int H, int W, int C_in, int C_out);
+
 /* "Nearest x2 spatial up-sampling, then 3x3x3 causal convolution" (SpatialUpsampler3D / SpatialTemporalUpsampler3D,
  * upsamplers.py:21-37,123-153) in SUB-PIXEL form: output pixel (2i + a, 2j + b) sees only 2 x 2 distinct source pixels, so each
  * of the four parity classes (a, b) is a 3 x 2 x 2 convolution on the SOURCE grid whose weights are sums of the original
@@ -487,7 +493,8 @@ int ea_im2col3d_bf16(const ea_bf16* x, ea_bf16* cols, int T_in, int H_in, int W_
 int ea_groupnorm_stats_bf16(const ea_bf16* x, float* partial, float* stats, int T, int64_t hw, int C, int groups,
                             int nblk, float eps, void* stream);
 
-/* y = act((x - mean) * rstd * gamma + beta); act: 0 none, 1 SiLU (common.py:306,318). */
+/* y = act((x - mean) * rstd * gamma + beta); act: 0 none, 1 SiLU (common.py:306,318); + 2: y is written channel-blocked,
+ * [C/32][T][hw][32], for a convolution that reads it with tdup bit 4 (ea_conv3d_cl_blocked_ok); y must not alias x then. */
 int ea_groupnorm_apply_bf16(const ea_bf16* x, ea_bf16* y, const float* stats, const float* gamma,
                             const float* beta, int T, int64_t hw, int C, int groups, int act, void* stream);
 

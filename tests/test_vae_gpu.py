@@ -943,3 +943,89 @@ def test_vae_tiling_vs_reference_golden():
     assert torch.equal(dec_d, dec) and torch.equal(mom_d, mom_u)
     with pytest.raises(NotImplementedError, match="upcast_vae"):
         AutoencoderKLMagvit.from_config(dict(g["cfg"], upcast_vae=True))
+
+
+# ---- round 6: channel-blocked GroupNorm output read by the four-wave row-slab convolutions --------------------------------------------
+@pytest.mark.parametrize("T,H,W,C,act", [(3, 24, 256, 128, True), (2, 16, 256, 256, True), (2, 9, 256, 512, False), (1, 5, 72, 128, True)])
+def test_groupnorm_blocked_output_is_the_permuted_output(T, H, W, C, act):
+    """ea_groupnorm_apply_bf16 with act bit 1: the same values, written [C / 32][T][H][W][32]."""
+    from easyanimate_amd import ops
+    g = torch.Generator().manual_seed(C + T)
+    x = _bf(torch.randn(T, H, W, C, generator=g) * 2 + 0.3).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    y = ops.groupnorm_silu(x, gamma, beta, 32, 1e-6, act=act)
+    yb = ops.groupnorm_silu(x, gamma, beta, 32, 1e-6, act=act, blocked=True)
+    assert yb.shape == (C // 32, T, H, W, 32)
+    assert torch.equal(yb, y.view(T, H, W, C // 32, 32).permute(3, 0, 1, 2, 4).contiguous())
+
+
+@pytest.mark.parametrize("T,H,W,Ci,Co,res,virt", [(3, 3, 512, 128, 128, True, False), (4, 4, 256, 128, 256, True, False), (3, 2, 256, 512, 512, False, False),
+                                                  (3, 3, 512, 256, 128, True, True), (2, 4, 256, 256, 256, False, True)])
+def test_conv_on_blocked_input_bit_identical(T, H, W, Ci, Co, res, virt):
+    """ops.conv3d_cl(..., blocked=True) (tdup bit 4; conv3d_cl_row16_w4a_kernel<.., .., true>): the slabs come in as 1 KiB pieces of
+    the channel-blocked tensor -- same values into the same LDS rows: output and GroupNorm partial sums bit-identical to the
+    voxel-major input, with a residual, with a virtually duplicated input and merged temporal taps."""
+    from easyanimate_amd import _lib, ops
+    from easyanimate_amd.vae_modules import _pack_conv_weight, _pack_tmerge_weight
+    g = torch.Generator().manual_seed(91 + W + Ci + Co)
+    x = _bf(torch.randn(T, H, W, Ci, generator=g)).to(DEV)
+    xb = x.view(T, H, W, Ci // 32, 32).permute(3, 0, 1, 2, 4).contiguous()
+    w = _bf(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5)
+    b = torch.randn(Co, generator=g).to(DEV)
+    wp = (_pack_tmerge_weight(w, Co) if virt else _pack_conv_weight(w)).to(DEV)
+    Tl = 2 * T - 1 if virt else T
+    r = _bf(torch.randn(Tl, H, W, Co, generator=g)).to(DEV) if res else None
+    prev = _lib.get_option("conv_tile"), _lib.get_option("conv_w4a")
+    try:
+        _lib.set_option("conv_tile", 1024)       # (the shapes are too small for the automatic choice of the row-slab kernels)
+        _lib.set_option("conv_w4a", 3)
+        assert ops.conv3d_blocked_ok(Tl, H, W, Ci, Co)
+        kw = dict(res=r, vin=virt, tmerge=virt)
+        _lib.reset_counters()
+        y0 = ops.conv3d_cl(x, wp, b, 3, **kw)
+        y1 = ops.conv3d_cl(xb, wp, b, 3, blocked=True, **kw)
+        torch.cuda.synchronize()
+        c = _lib.counters()
+        assert c.get("conv_blocked_input", 0) == 1 and c.get("conv_w4a", 0) == 2, c
+        assert torch.equal(y0, y1) and y0.shape == (Tl, H, W, Co)
+        assert y0.gn_partial[1] == y1.gn_partial[1] and torch.equal(y0.gn_partial[0][:y0.gn_partial[1] * Tl * (Co // 4) * 2], y1.gn_partial[0][:y1.gn_partial[1] * Tl * (Co // 4) * 2])
+        _lib.set_option("conv_w4a", 0)
+        assert not ops.conv3d_blocked_ok(Tl, H, W, Ci, Co)
+        with pytest.raises(RuntimeError, match="channel-blocked"):
+            ops.conv3d_cl(xb, wp, b, 3, blocked=True, **kw)
+    finally:
+        _lib.set_option("conv_tile", prev[0])
+        _lib.set_option("conv_w4a", prev[1])
+
+
+def test_vae_blocked_groupnorm_outputs_change_no_bit():
+    """vae_modules.BLOCKED_GN_OUTPUT: the decode and encode of a clip wide enough for the four-wave row-slab kernels (5 x 512 x 512)
+    with and without the channel-blocked GroupNorm -> convolution edges: identical bits, and the blocked path really ran."""
+    from easyanimate_amd import AutoencoderKLMagvit, _lib, vae_modules
+    from easyanimate_amd.synthetic import synth_state_dict
+    g = torch.load(os.path.join(GOLD, "vae_dec_5x512.pt"), weights_only=False)
+    with torch.device("meta"):
+        vae = AutoencoderKLMagvit.from_config(g["cfg"])
+    shapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    vae = vae.to_empty(device="cpu")
+    vae.load_state_dict(synth_state_dict(shapes, g["seed"], g["style"]), strict=True)
+    vae = vae.to(torch.bfloat16).to(DEV).eval()
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 16, 2, 64, 64, generator=gen).to(DEV).bfloat16()
+    video = (torch.rand(1, 3, 5, 512, 512, generator=gen) * 2 - 1).to(DEV).bfloat16()
+    outs = {}
+    prev = vae_modules.BLOCKED_GN_OUTPUT
+    prev_w4a = _lib.get_option("conv_w4a")
+    try:
+        _lib.set_option("conv_w4a", 3)            # (this file's fixture pins the eight-wave kernels; the blocked input is the four-wave kernels')
+        for flag in (False, True):
+            vae_modules.BLOCKED_GN_OUTPUT = flag
+            _lib.reset_counters()
+            with torch.no_grad():
+                outs[flag] = (vae.decode(z)[0], vae.encode(video)[0].parameters, _lib.counters().get("conv_blocked_input", 0))
+    finally:
+        vae_modules.BLOCKED_GN_OUTPUT = prev
+        _lib.set_option("conv_w4a", prev_w4a)
+    print(f"[dispatch] convolutions on a channel-blocked input in one 5 x 512^2 decode + encode: {outs[True][2]} (switch off: {outs[False][2]})")
+    assert outs[False][2] == 0 and outs[True][2] >= 8
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])

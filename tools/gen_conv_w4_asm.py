@@ -52,8 +52,13 @@ def mfma(b, n):
 
 
 class Geo:
-    def __init__(self, name, TM, BN):
+    def __init__(self, name, TM, BN, cb=False):
         self.name, self.TM, self.BN = name, TM, BN
+        # cb (round 6): the input is CHANNEL-BLOCKED, [C_in / 32][T][H][W][32] -- a slab's 16-voxel piece is 1 KiB of consecutive
+        # memory instead of sixteen 64-byte runs a voxel (C_in * 2 bytes) apart.  The table rows then describe channel block 0 and the
+        # slab's block moves the resource BASE (64-bit: a block is T * H * W * 64 bytes, beyond any 32-bit offset); the scalar offset
+        # of the request stays 0.
+        self.cb = cb
         self.NROW = TM + 2
         self.NPIECE = (self.NROW + 15) // 16
         self.PPW = (self.NPIECE + 3) // 4            # A pieces (1 KiB = 16 rows) per wave and slab
@@ -91,6 +96,17 @@ def advance(d, c):
 def load_row(d):
     """A resource words 0..2 of table entry s<d> (the extent is overridden by the caller when the slab does not exist)."""
     return [f"v_readlane_b32 s{S_RA}, %[t_lo], s{d}", f"v_readlane_b32 s{S_RA + 1}, %[t_hi], s{d}", f"v_readlane_b32 s{S_RA + 2}, %[t_ext], s{d}"]
+
+
+def block_base(c):
+    """channel-blocked input: resource base += (channel block s<c>) * (bytes per block, %[cb_lo] / %[cb_hi]), 64-bit."""
+    return [f"s_mul_hi_u32 s{S_T1}, s{c}, %[cb_lo]", f"s_mul_i32 s{S_T0}, s{c}, %[cb_lo]", f"s_add_u32 s{S_RA}, s{S_RA}, s{S_T0}",
+            f"s_addc_u32 s{S_RA + 1}, s{S_RA + 1}, s{S_T1}", f"s_mul_i32 s{S_T0}, s{c}, %[cb_hi]", f"s_add_u32 s{S_RA + 1}, s{S_RA + 1}, s{S_T0}"]
+
+
+def asoff(g, c):
+    """scalar byte offset of a slab's request: the channel block inside a voxel's channels -- or nothing (blocked input)."""
+    return f"s_mov_b32 s{S_ASOFF}, 0" if g.cb else f"s_lshl_b32 s{S_ASOFF}, s{c}, 6"
 
 
 def tile(g, dw, par):
@@ -140,14 +156,14 @@ def slab_tail(g):
     t += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_xor_b32 s{S_MA}, s{S_MA}, 0x{g.A_XOR:x}"]
     # W offset of the new slab s + 1: (d1 * 3 * C_in + c1 * 32) * 2 bytes
     t += [f"s_mul_i32 s{S_T0}, s{S_D1}, 3", f"s_mul_i32 s{S_T0}, s{S_T0}, s{S_CIN2}", f"s_lshl_b32 s{S_T1}, s{S_C1}, 6", f"s_add_u32 s{S_KOFF1}, s{S_T0}, s{S_T1}",
-          f"s_lshl_b32 s{S_ASOFF}, s{S_C2}, 6"]
+          asoff(g, S_C2)]
     return t
 
 
-def validity():
+def validity(g):
     """Resource extents for the coming slab's requests: W needs slab s + 1 (left > 1), A needs slab s + 2 (left > 2)."""
     return [f"s_cmp_gt_u32 s{S_LEFT}, 1", f"s_cselect_b32 s{S_RW + 2}, s{S_WEXT}, 0"] + load_row(S_D2) + \
-           ["s_nop 1", f"s_cmp_gt_u32 s{S_LEFT}, 2", f"s_cselect_b32 s{S_RA + 2}, s{S_RA + 2}, 0"]
+           ["s_nop 1", f"s_cmp_gt_u32 s{S_LEFT}, 2", f"s_cselect_b32 s{S_RA + 2}, s{S_RA + 2}, 0"] + (block_base(S_C2) if g.cb else [])
 
 
 def body(g):
@@ -190,12 +206,16 @@ def body(g):
     # slab 1 -> A stage 1
     for ins in advance(S_D2, S_C2):
         A(ins)
-    A(f"s_lshl_b32 s{S_ASOFF}, s{S_C2}, 6")
+    A(asoff(g, S_C2))
     A("s_nop 3")
     for ins in load_row(S_D2):
         A(ins)
     A(f"s_xor_b32 s{S_MA}, s{S_MA}, 0x{g.A_XOR:x}")
     A("s_nop 4")
+    if g.cb:
+        for ins in block_base(S_C2):
+            A(ins)
+        A("s_nop 0")
     for i in range(g.PPW):
         A(f"s_add_u32 m0, s{S_MA}, 0x{i * 1024:x}")
         A("s_nop 0")
@@ -210,9 +230,9 @@ def body(g):
     A(f"s_mul_i32 s{S_T0}, s{S_T0}, s{S_CIN2}")
     A(f"s_lshl_b32 s{S_T1}, s{S_C1}, 6")
     A(f"s_add_u32 s{S_KOFF1}, s{S_T0}, s{S_T1}")
-    A(f"s_lshl_b32 s{S_ASOFF}, s{S_C2}, 6")
+    A(asoff(g, S_C2))
     A("s_nop 3")
-    for ins in validity():
+    for ins in validity(g):
         A(ins)
     for r in range(256):
         A(f"v_accvgpr_write_b32 a{r}, 0")
@@ -229,12 +249,18 @@ def body(g):
     for slab in range(2):
         for dw in range(3):
             sch = tile(g, dw, t & 1)
-            last = slab_tail(g) + validity() if dw == 2 else []
-            # the scalar tail goes one instruction per slot behind the tile's last request
+            last = slab_tail(g) + validity(g) if dw == 2 else []
+            # the scalar tail goes one instruction per slot behind the tile's last request (blocked input: six more scalar
+            # instructions than slots -- the first ones go two to a slot)
             slot = 38                                           # behind the last fragment read (slot 36) and the last request
-            assert slot + len(last) <= 64, (slot, len(last))
-            for k, ins in enumerate(last):
-                sch[slot + k].append(ins)
+            extra = max(0, slot + len(last) - 64)
+            assert extra <= 12, (slot, len(last))
+            k = 0
+            for n_ in range(slot, 64):
+                take = 2 if n_ - slot < extra else 1
+                sch[n_] += last[k:k + take]
+                k += take
+            assert k >= len(last)
             for n in range(64):
                 for ins in sch[n]:
                     A(ins)
@@ -252,7 +278,7 @@ def body(g):
 
 def emit():
     L = ["// GENERATED by tools/gen_conv_w4_asm.py -- do not edit; see that file for the schedule."]
-    for g in (Geo("M512", 512, 128), Geo("N256", 256, 256)):
+    for g in (Geo("M512", 512, 128), Geo("N256", 256, 256), Geo("M512_CB", 512, 128, cb=True), Geo("N256_CB", 256, 256, cb=True)):
         b = body(g)
         n_m = sum("v_mfma" in x for x in b)
         assert n_m == 384, n_m
