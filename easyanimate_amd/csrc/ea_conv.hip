@@ -1839,7 +1839,7 @@ static int conv3d_cl_impl(const ea_bf16* x, const ea_bf16* w, const float* bias,
     p.M = (int64_t)p.T_out * p.H_out * p.W_out;
     EA_REQUIRE(p.M > 0 && p.M < (1ll << 40), "ea_conv3d_cl_bf16: bad output size");
     EA_REQUIRE(!p.x_cb || (kt == 3 && st == 1 && ss == 1 && pad == 1 && !ups && !tdup && ea_conv3d_cl_blocked_ok(p.T_out, p.H_out, p.W_out, C_in, C_out)),
-               "ea_conv3d_cl_bf16: a channel-blocked input (tdup bit 4) is read by the four-wave row-slab kernels only: ask ea_conv3d_cl_blocked_ok first");
+               "ea_conv3d_cl_bf16: a channel-blocked input (tdup bit 16) is read by the four-wave row-slab kernels only: ask ea_conv3d_cl_blocked_ok first");
     if (C_in == 8) {   // one 16-byte chunk per voxel: eight taps per K tile (conv3d_cl_kernel<true>)
         EA_REQUIRE(p.M < (1ll << 31), "ea_conv3d_cl_bf16: too many output voxels for the 8-channel kernel");
         p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -2109,7 +2109,7 @@ extern "C" int ea_conv3d_cl_tmerge_ok(int T_logical, int H, int W, int C_in, int
 }
 
 // Would ea_conv3d_cl_bf16 serve a 3x3x3 / stride 1 / pad 1 layer of this shape (no folded up-sampling, no duplicate store) with the
-// kernels that read a channel-blocked input (tdup bit 4)?  Mirrors the kernel choice of conv3d_cl_impl; T = the layer's output
+// kernels that read a channel-blocked input (tdup bit 16)?  Mirrors the kernel choice of conv3d_cl_impl; T = the layer's output
 // (= logical input) frame count.
 extern "C" int ea_conv3d_cl_blocked_ok(int T, int H, int W, int C_in, int C_out) {
     const int bn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 0);

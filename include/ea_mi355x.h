@@ -424,6 +424,9 @@ int ea_gated_residual_bf16(const ea_bf16* x, const ea_bf16* res, const float* ga
  *      w is [2, C_out, 18 * C_in]: class 0 (even t) = {W_dt0, W_dt1 + W_dt2}, class 1 (odd t) = {W_dt0 + W_dt1, W_dt2}, summed in
  *      fp32 and rounded to bf16 once, taps ordered (dt', kh, kw); 2/3 of the MFMA work.  Row-slab shapes only
  *      (ea_conv3d_cl_tmerge_ok).
+ *  16: x is CHANNEL-BLOCKED, bf16 [C_in/32][T_in][H_in][W_in][32] (ea_groupnorm_apply_bf16 with act bit 1 writes it): the four-wave
+ *      row-slab kernels then stage a slab's 16-voxel pieces as 1 KiB of consecutive memory.  Only where ea_conv3d_cl_blocked_ok says
+ *      so (3x3x3, stride 1, pad 1, ups = 0, no bit 1); combines with bits 2 / 4 / 8.  Same values, same result.
  * res (optional, same shape as the un-duplicated output -- or its physical frames with tdup & 4): y = conv + bias + res.
  * zeros: any device buffer holding >= 128 zero bytes (source of the spatial zero padding). */
 int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, const ea_bf16* res, ea_bf16* y,
@@ -435,7 +438,7 @@ int ea_conv3d_cl_bf16(const ea_bf16* x, const ea_bf16* w, const float* bias, con
 int ea_conv3d_cl_tmerge_ok(int T_logical, int H, int W, int C_in, int C_out);
 
 /* Would ea_conv3d_cl_bf16 read a CHANNEL-BLOCKED input for this layer (3x3x3, stride 1, pad 1, no folded up-sampling / duplicate
- * store; T = output frames)?  tdup bit 4 (16) of ea_conv3d_cl_bf16 / ea_conv3d_cl_stats_bf16 declares x as [C_in/32][T_in][H_in][W_in][32]
+ * store; T = output frames)?  tdup bit 16 of ea_conv3d_cl_bf16 / ea_conv3d_cl_stats_bf16 declares x as [C_in/32][T_in][H_in][W_in][32]
  * (T_in PHYSICAL frames) -- the layout ea_groupnorm_apply_bf16 writes with act bit 1 (2) -- which only the four-wave row-slab
  * kernels read: a slab's 16-voxel LDS-DMA piece is then 1 KiB of consecutive memory.  Same values, same results. */
 int ea_conv3d_cl_blocked_ok(int T, int H, int W, int C_in, int C_out);
@@ -494,7 +497,7 @@ int ea_groupnorm_stats_bf16(const ea_bf16* x, float* partial, float* stats, int 
                             int nblk, float eps, void* stream);
 
 /* y = act((x - mean) * rstd * gamma + beta); act: 0 none, 1 SiLU (common.py:306,318); + 2: y is written channel-blocked,
- * [C/32][T][hw][32], for a convolution that reads it with tdup bit 4 (ea_conv3d_cl_blocked_ok); y must not alias x then. */
+ * [C/32][T][hw][32], for a convolution that reads it with tdup bit 16 (ea_conv3d_cl_blocked_ok); y must not alias x then. */
 int ea_groupnorm_apply_bf16(const ea_bf16* x, ea_bf16* y, const float* stats, const float* gamma,
                             const float* beta, int T, int64_t hw, int C, int groups, int act, void* stream);
 

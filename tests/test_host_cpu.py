@@ -24,7 +24,8 @@ def test_c_abi_exports_every_declared_symbol(lib_built):
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     from easyanimate_amd import _lib
     assert set(_lib.PROTOTYPES) | {"ea_last_error_string", "ea_version", "ea_set_option", "ea_get_option", "ea_attention_state_bytes",
-                                    "ea_get_counter", "ea_counter_name", "ea_reset_counters", "ea_last_dispatch", "ea_conv3d_cl_tmerge_ok"} == declared
+                                    "ea_get_counter", "ea_counter_name", "ea_reset_counters", "ea_last_dispatch", "ea_conv3d_cl_tmerge_ok",
+                                    "ea_conv3d_cl_blocked_ok"} == declared
     assert _lib.counters() == {} and _lib.load().ea_get_counter(b"conv_row16_128") == 0   # host-side bookkeeping, no GPU
     assert _lib.load().ea_version() >= 100
     # tuning switches: host-side state, readable and restorable without a GPU

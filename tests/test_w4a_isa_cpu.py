@@ -17,7 +17,9 @@ CSRC = os.path.join(ROOT, "easyanimate_amd", "csrc")
 # (source file, kernel symbol fragment, MFMAs inside each hand-placed loop body)
 KERNELS = [("ea_gemm.hip", "gemm256_w4a_kernelILi0E", [128]), ("ea_gemm.hip", "gemm256_w4a_kernelILi1E", [128]),
            ("ea_gemm.hip", "gemm256_w4a_kernelILi2E", [128]), ("ea_gemm.hip", "gemm256_qkv_w4a_kernel", [128, 128]),
-           ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi128ELi512E", [384]), ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi256ELi256E", [384])]
+           ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi128ELi512ELb0E", [384]), ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi256ELi256ELb0E", [384]),
+           # the channel-blocked-input variants (round 6)
+           ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi128ELi512ELb1E", [384]), ("ea_conv.hip", "conv3d_cl_row16_w4a_kernelILi256ELi256ELb1E", [384])]
 
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
