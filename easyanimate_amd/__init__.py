@@ -18,6 +18,8 @@ _LAZY = {
     "get_teacache_coefficients": "teacache",
     "name_to_transformer3d": "registry",
     "name_to_autoencoder_magvit": "registry",
+    "Qwen2VLTextEncoderHIP": "text_encoder",
+    "use_hip_text_encoder": "text_encoder",
 }
 
 
