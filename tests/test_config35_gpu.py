@@ -119,6 +119,10 @@ def test_declared_depth_forward_vs_reference_golden(case):
     assert cnt.get("attention_v3", 0) == 48 and cnt.get("gemm_qkv_fused", 0) == 96 and cnt.get("gemm_qkv_fused_w4a", 0) == 96, cnt
     assert cnt.get("gemm_256_w4a", 0) >= 48 * 3, cnt
     assert S == (53504 if case == "config3" else 30208)
+    del m, v
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def _worker_sp(rank, world, port, case, ret):
@@ -182,6 +186,9 @@ def test_declared_depth_forward_under_sequence_parallel(case):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()          # the four ranks share this GPU with the parent: hand its cached blocks back first
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_sp, args=(4, port, case, ret), nprocs=4, join=True)
