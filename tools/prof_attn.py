@@ -9,6 +9,10 @@ what = sys.argv[1] if len(sys.argv) > 1 else "attn"
 if what == "attn":
     var = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     _lib.set_option("attn_variant", var)
+    # EA_PROF_ATTN_SHAPE="nw,stages": the workgroup shape of v3 (round 6: 8,2 = one K / V^T stream per CU; 4,3 = a three-stage ring)
+    nw, stages = (int(v) for v in os.environ.get("EA_PROF_ATTN_SHAPE", "4,2").split(","))
+    _lib.set_option("attn_nw", nw)
+    _lib.set_option("attn_stages", stages)
     B, H, S = 2, 48, 53504
     s_pad = ops.round_up(S, 256)
     q = (torch.randn(B, H, s_pad, 64, device="cuda") * ops.FOLDED_Q_SCALE).to(torch.bfloat16)   # scale folded into Q
