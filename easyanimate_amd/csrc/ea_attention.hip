@@ -425,6 +425,9 @@ int g_attn_variant = 3;  // ea_set_option("attn_variant", 3): v3 (16x16x32 MFMA)
 #include "ea_attention_v2.inc"   // the 32x32x16 generation (and the only one that takes an un-folded softmax scale): cross-check builds only
 #endif
 #include "ea_attention_v3.inc"
+#if EA_BUILD_VARIANTS
+#include "ea_attention_v5.inc"   // the ping-pong measurement kernel (round 6; 15 % slower than v3): cross-check builds only
+#endif
 
 }  // namespace
 
@@ -438,7 +441,7 @@ int ea_attn_stages_set(int v) {
 int g_attn_nw = 4;   // ea_set_option("attn_nw", 4 | 8): waves per workgroup of attention_fwd_v3_kernel (8: one 512-query workgroup per CU shares ONE K / V^T stream)
 int ea_attn_nw_get() { return g_attn_nw; }
 int ea_attn_nw_set(int v) {
-    if (v != 4 && v != 8) return -1;
+    if (v != 4 && v != 8 && !(v == 16 && EA_BUILD_VARIANTS)) return -1;     // 16: the ping-pong measurement kernel (attention_fwd_v5_kernel; EA_BUILD_VARIANTS=1 libraries, plain launches)
     g_attn_nw = v;
     return 0;
 }
@@ -529,7 +532,15 @@ static int attention_launch(const ea_bf16* q, const ea_bf16* k, const ea_bf16* v
     ea_count("attention_v3");
     AttSegments hw = AttSegments();          // not a segment launch: only the head window fields are read
     hw.q_head0 = q_head0; hw.q_heads = q_heads; hw.kv_bstride = kv_bstride;
-    const int nw = g_attn_nw;
+#if EA_BUILD_VARIANTS
+    if (g_attn_nw == 16 && flags == 0 && kv_begin == 0 && q_heads == 0 && kv_bstride == 0) {
+        const int nqb5 = (q_end - q_begin + 511) / 512;
+        hipLaunchKernelGGL(attention_fwd_v5_kernel, dim3((unsigned)att3_grid_blocks(bh, nqb5)), dim3(512), 3 * ATT_STAGE, st, q, k, vt, o16,
+                           out_batch_stride, heads, bh, kv_end, s_pad, q_begin, q_end, nqb5);
+        return ea_check_launch("ea_attention_fwd");
+    }
+#endif
+    const int nw = g_attn_nw == 16 ? 4 : g_attn_nw;
     const int nqb3 = (q_end - q_begin + nw * 64 - 1) / (nw * 64);     // query blocks of nw * 64 rows
     const dim3 grid3((unsigned)att3_grid_blocks(bh, nqb3)), blk3(nw * 64);
 #define EA_ATT_LAUNCH(MODE, NW_)                                                                                          \
@@ -603,7 +614,7 @@ static int attention_segments_launch(const ea_bf16* q, const ea_bf16* k_seg0, co
     sg.rows = seg_rows; sg.tiles = seg_used_rows / ATT_KV; sg.skip = (skip_seg >= 0 && skip_seg < n_seg) ? skip_seg : n_seg;
     sg.total_tiles = used * sg.tiles; sg.stride = seg_stride; sg.first = seg_first_row / ATT_KV;
     sg.q_head0 = q_head0; sg.q_heads = q_heads; sg.kv_bstride = kv_bstride;
-    const int nw = g_attn_nw;
+    const int nw = g_attn_nw == 16 ? 4 : g_attn_nw;
     const int nqb3 = (q_end - q_begin + nw * 64 - 1) / (nw * 64);
     const dim3 grid((unsigned)att3_grid_blocks(bh, nqb3)), blk(nw * 64);
     hipStream_t st = (hipStream_t)stream;

@@ -839,6 +839,32 @@ def test_attention_segments_eight_wave_workgroups_bit_identical(P, rank, nl, n_l
     assert all(torch.equal(outs[(4, 2)], o) for o in outs.values())
 
 
+@pytest.mark.parametrize("B,H,S", [(1, 3, 1024), (2, 2, 2300), (1, 9, 777), (1, 1, 5003)])
+def test_attention_ping_pong_experiment_kernel(B, H, S):
+    """attention_fwd_v5_kernel (ea_set_option("attn_nw", 16) in an EA_BUILD_VARIANTS=1 library; a measurement kernel, DESIGN 3.1:
+    15 % slower than v3, profiles/r06l_attention_pingpong_ab.jsonl): the v3 arithmetic with the MFMA and
+    softmax phases of the two waves of a SIMD run one phase apart.  Same products and exponentials; the row sums are fp32 adds of the
+    unrounded weights instead of an MFMA over the rounded ones -> equal to v3 to bf16 noise, and to the fp64 reference inside the
+    usual tolerance; ragged last tiles, head counts that are no multiple of 8, query counts that are no multiple of 512."""
+    from easyanimate_amd import _lib
+    _needs_variants()
+    ops = _ops()
+    q, k, vt, v = _attn_inputs(B, H, S, 177 + S, scale_q=1.5)
+    qs, sc = _fold(q), ops.FOLDED_ATTN_SCALE
+    ref = _attn_ref((qs.float() / ops.FOLDED_Q_SCALE).double(), k, v, S)
+    try:
+        _lib.set_option("attn_nw", 4)
+        o3 = ops.attention(qs, k, vt, S, sc)
+        _lib.set_option("attn_nw", 16)
+        o5 = ops.attention(qs, k, vt, S, sc)
+        o5b = ops.attention(qs, k, vt, S, sc)
+    finally:
+        _lib.set_option("attn_nw", 4)
+    err, rel = _report(f"attention v5 (ping-pong) B={B} H={H} S={S}", o5, ref)
+    assert torch.isfinite(o5.float()).all() and torch.equal(o5, o5b)
+    assert rel < 8e-3 and err < 0.05 and (o5.float() - o3.float()).abs().max().item() < 0.03
+
+
 def test_attention_full_size_config3():
     """BASELINE.json config 3 sequence (S = 53 504 = 836 key tiles, 209 query blocks), 2 heads: the product kernel against
     a chunked fp32 torch evaluation of the same attention on the GPU (checker only), plus the size-independent
