@@ -60,8 +60,8 @@ _frozen = 0
 
 class weights_frozen:
     """`with weights_frozen():` -- the caller promises that no parameter is written inside (a sampling loop).  Outside of it
-    FeedForward.forward re-derives the K-blocked copy of its ff.net.2 weight on each call (kblocked_weight: 1.5 ms per forward at
-    the 12B size), because a `weight.data += delta` LoRA merge (utils/lora_utils.py:369-433) between two forwards is invisible
+    FeedForward.forward re-derives the K-blocked copy of its ff.net.2 weight on each call (kblocked_weight: 2 x 75 MB of traffic = about
+    30 us per use, 96 uses = about 3 ms per forward at the 12B size, 0.1 % of a config-3 step), because a `weight.data += delta` LoRA merge (utils/lora_utils.py:369-433) between two forwards is invisible
     to the version counter; the pipelines' loops run frozen (they drop every derived copy once per call instead)."""
 
     def __enter__(self):
@@ -117,8 +117,9 @@ def bf16_weight(p, k_pad: int | None = None):
 def kblocked_weight(p):
     """The K-blocked copy [K / 64, N, 64] of a bf16 Linear weight [N, K] (ops.gemm_kblocked; cached like every derived weight:
     load_state_dict / in-place writes are seen through the version counter).  `.data` writes are not, so outside a
-    weights_frozen() region the copy is re-derived IN PLACE on every use (2 x 75 MB of traffic = 30 us at the 12B size): 2 more
-    bytes per weight for the layers that use it."""
+    weights_frozen() region the copy is re-derived IN PLACE on every use (2 x 75 MB of traffic = about 30 us at the 12B size; 96 uses =
+    about 3 ms per forward -- the pipelines' loops, bench.py included, run frozen and pay it once per call): 2 more bytes per weight for
+    the layers that use it."""
     make = lambda t: t.to(torch.bfloat16).reshape(t.shape[0], t.shape[1] // 64, 64).permute(1, 0, 2)
     ent = _cache.get((id(p), "kblock"))
     val = derived(p, "kblock", lambda t: make(t).contiguous())
