@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GUARDED = os.path.join(ROOT, "tools", "guarded.py")
 SELECTION = ("permute_cols or swa_window_mapped or attention_window or segments or exchange_slot or kblocked_ffn_pair or "
-             "gemm_w4a or qkv_fused_w4a or head_window or grouped_destination")       # round 5: the hand-placed kernels and the head groups
+             "gemm_w4a or qkv_fused_w4a or head_window or grouped_destination or "    # round 5: the hand-placed kernels and the head groups
+             "eight_wave or layernorm_sweep")                                          # round 6: attention workgroup shapes / stages, LayerNorm sweep
 
 
 def _run(args, env=None, timeout=600):
@@ -35,9 +36,19 @@ def test_kernels_behind_the_fence(mode):
 
 def test_conv_w4a_behind_the_fence():
     """The four-wave row-slab convolutions (buffer-addressed slab requests, zero padding by the descriptor's range check)."""
-    r = _run(["-m", "pytest", "tests/test_vae_gpu.py", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x", "-k", "conv_w4a"])
+    r = _run(["-m", "pytest", "tests/test_vae_gpu.py", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x", "-k",
+              "conv_w4a or conv_on_blocked_input or groupnorm_blocked or tile_blend"])      # round 6: + the channel-blocked slab fill (64-bit base moves), tile blends
     tail = (r.stdout[-1500:] + r.stderr[-1500:])
     print(f"[fence] conv w4a: rc {r.returncode}\n{tail}")
+    assert r.returncode == 0 and "passed" in r.stdout and "slack_hits=0" in r.stderr and "Memory access fault" not in r.stderr, tail
+
+
+def test_text_encoder_kernels_behind_the_fence():
+    """Round 6: the prompt-sized attention (operands straight from global memory, clamped rows), rotate-half scatter, SiLU-mul."""
+    r = _run(["-m", "pytest", "tests/test_text_encoder_gpu.py", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x", "-k",
+              "attention_causal_gqa or rope_half"])
+    tail = (r.stdout[-1500:] + r.stderr[-1500:])
+    print(f"[fence] text kernels: rc {r.returncode}\n{tail}")
     assert r.returncode == 0 and "passed" in r.stdout and "slack_hits=0" in r.stderr and "Memory access fault" not in r.stderr, tail
 
 
