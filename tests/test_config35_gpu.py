@@ -173,10 +173,11 @@ def _worker_sp(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["config5"])
+# (config 3 through four ranks costs four more minutes of gloo staging: EA_TEST_SP_CONFIG3=1 adds it; profiles/r06q_* holds one run)
+@pytest.mark.parametrize("case", ["config5"] + (["config3"] if os.environ.get("EA_TEST_SP_CONFIG3") == "1" else []))
 def test_declared_depth_forward_under_sequence_parallel(case):
     """The config-5 golden (L = 48, 33 channels, S = 30 208) through 4 ranks sharing cuda:0 over gloo: B = 1, so the four ranks are
-    four sequence shards of 7 488 tokens; K / V^T exchanged per block in two head groups.  Every rank's gathered velocity against
+    four sequence shards of 7 488 tokens (config 3: 13 312); K / V^T exchanged per block in two head groups.  Every rank's gathered velocity against
     the reference golden, the residual streams of its shard at depth, and the drift of the replicated text stream between ranks
     after block 48 (SURVEY 8(e) wanted bit-identical text rows; the product replicates them un-synchronised: this is the number)."""
     import socket
